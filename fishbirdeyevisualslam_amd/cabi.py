@@ -1,0 +1,150 @@
+"""ctypes mirror of include/fishbird.h (the C-ABI drop-in boundary).
+
+Every Structure here matches a struct in include/fishbird.h field for field.  Pointer
+fields are c_void_p so the same struct can carry host pointers (numpy) for the
+drop-in entry points or device pointers (torch tensors on the GPU) for the *_dev ones.
+"""
+import ctypes as C
+
+import numpy as np
+
+FB_MAX_LEVELS = 16
+FB_OK, FB_ERR_ARG, FB_ERR_HIP, FB_ERR_CAPACITY, FB_ERR_NODEVICE = 0, -1, -2, -3, -4
+FB_POSE_FRONT, FB_POSE_FRONT_BIRD, FB_POSE_BIRD = 0, 1, 2
+
+KP_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4")]
+)
+assert KP_DTYPE.itemsize == 24
+
+_vp = C.c_void_p
+_i32 = C.c_int32
+_f32 = C.c_float
+
+
+def ptr(x):
+    """Address of a numpy array / torch tensor / int / None as an integer."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        assert x.is_contiguous()
+        return x.data_ptr()
+    raise TypeError(type(x))
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", _i32), ("scale_factor", _f32), ("nlevels", _i32), ("ini_th_fast", _i32),
+                ("min_th_fast", _i32)]
+
+
+class OrbTables(C.Structure):
+    _fields_ = [("scale_factor", _f32 * FB_MAX_LEVELS), ("inv_scale_factor", _f32 * FB_MAX_LEVELS),
+                ("level_sigma2", _f32 * FB_MAX_LEVELS), ("inv_level_sigma2", _f32 * FB_MAX_LEVELS),
+                ("features_per_level", _i32 * FB_MAX_LEVELS), ("umax", _i32 * 16)]
+
+
+class GridGeom(C.Structure):
+    _fields_ = [("min_x", _f32), ("min_y", _f32), ("inv_w", _f32), ("inv_h", _f32), ("cols", _i32), ("rows", _i32)]
+
+
+class MatcherParams(C.Structure):
+    _fields_ = [("nnratio", _f32), ("check_orientation", _i32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", _f32), ("fy", _f32), ("cx", _f32), ("cy", _f32), ("min_x", _f32), ("min_y", _f32),
+                ("max_x", _f32), ("max_y", _f32)]
+
+
+class ProjFrameArgs(C.Structure):
+    _fields_ = [("batch", _i32), ("cur_stride", _i32), ("last_stride", _i32),
+                ("n_cur", _vp), ("cur_kps", _vp), ("cur_desc", _vp), ("cur_cell_start", _vp),
+                ("cur_cell_items", _vp), ("cur_blocked", _vp), ("cur_Tcw", _vp),
+                ("n_last", _vp), ("last_valid", _vp), ("last_obs_pos", _vp), ("last_xw", _vp),
+                ("last_desc", _vp), ("last_octave", _vp), ("last_angle", _vp),
+                ("cam", Camera), ("grid", GridGeom), ("scale_factors", _f32 * FB_MAX_LEVELS), ("th", _f32),
+                ("matcher", MatcherParams), ("match_cur_to_last", _vp), ("nmatches", _vp)]
+
+
+class BirdMpArgs(C.Structure):
+    _fields_ = [("batch", _i32), ("cur_stride", _i32), ("ref_stride", _i32),
+                ("n_cur", _vp), ("cur_kps", _vp), ("cur_desc", _vp), ("cur_cam_xyz", _vp),
+                ("cur_cell_start", _vp), ("cur_cell_items", _vp), ("cur_Tcw", _vp),
+                ("n_ref", _vp), ("ref_valid", _vp), ("ref_xw", _vp), ("ref_desc", _vp),
+                ("Tbc", _f32 * 12), ("bird_cols", _i32), ("bird_rows", _i32), ("meter2pixel", C.c_double),
+                ("rear_axle_to_center", C.c_double), ("grid", GridGeom), ("window_size", _i32),
+                ("filter_size", _f32), ("matcher", MatcherParams), ("match_cur_to_ref", _vp), ("ninliers", _vp)]
+
+
+class ProjPointsArgs(C.Structure):
+    _fields_ = [("batch", _i32), ("cur_stride", _i32), ("mp_stride", _i32),
+                ("n_cur", _vp), ("cur_kps", _vp), ("cur_desc", _vp), ("cur_cell_start", _vp),
+                ("cur_cell_items", _vp), ("cur_blocked", _vp),
+                ("n_mp", _vp), ("mp_track", _vp), ("mp_obs_pos", _vp), ("mp_proj", _vp), ("mp_level", _vp),
+                ("mp_view_cos", _vp), ("mp_desc", _vp),
+                ("grid", GridGeom), ("scale_factors", _f32 * FB_MAX_LEVELS), ("th", _f32),
+                ("matcher", MatcherParams), ("match_cur_to_mp", _vp), ("nmatches", _vp)]
+
+
+class BirdviewArgs(C.Structure):
+    _fields_ = [("batch", _i32), ("cur_stride", _i32), ("ref_stride", _i32),
+                ("n_cur", _vp), ("cur_kps", _vp), ("cur_desc", _vp), ("cur_cell_start", _vp),
+                ("cur_cell_items", _vp), ("n_ref", _vp), ("ref_kps", _vp), ("ref_desc", _vp),
+                ("grid", GridGeom), ("window_size", _i32), ("matcher", MatcherParams),
+                ("match_ref_to_cur", _vp), ("match_dist", _vp), ("nmatches", _vp), ("n_dmatches", _vp)]
+
+
+class PoseOptArgs(C.Structure):
+    _fields_ = [("batch", _i32), ("mode", _i32), ("front_stride", _i32), ("bird_stride", _i32),
+                ("fx", _f32), ("fy", _f32), ("cx", _f32), ("cy", _f32), ("wF", _f32), ("wB", _f32),
+                ("n_front", _vp), ("front_xw", _vp), ("front_obs", _vp), ("front_inv_sigma2", _vp),
+                ("front_valid", _vp),
+                ("n_bird", _vp), ("bird_xw", _vp), ("bird_xc", _vp), ("bird_inv_sigma2", _vp),
+                ("bird_valid", _vp), ("bird_outlier", _vp),
+                ("Tcw", _vp), ("front_outlier", _vp), ("ninliers", _vp)]
+
+
+class LocalBAArgs(C.Structure):
+    _fields_ = [("with_odom", _i32), ("fx", _f32), ("fy", _f32), ("cx", _f32), ("cy", _f32),
+                ("wF", _f32), ("wB", _f32), ("wP", _f32),
+                ("n_kf", _i32), ("kf_Tcw", _vp), ("kf_fixed", _vp),
+                ("n_mp", _i32), ("mp_xw", _vp), ("n_mpb", _i32), ("mpb_xw", _vp),
+                ("n_obs", _i32), ("obs_kf", _vp), ("obs_mp", _vp), ("obs_uv", _vp), ("obs_inv_sigma2", _vp),
+                ("n_bobs", _i32), ("bobs_kf", _vp), ("bobs_mpb", _vp), ("bobs_xc", _vp), ("bobs_inv_sigma2", _vp),
+                ("n_odom", _i32), ("odom_kf_i", _vp), ("odom_kf_j", _vp), ("odom_Tij", _vp), ("odom_info", _vp),
+                ("stop_flag", _vp), ("obs_outlier", _vp), ("bobs_outlier", _vp)]
+
+
+def fill(struct, **kw):
+    """Set fields of a Structure; array-likes become pointers, lists fill fixed arrays."""
+    for k, v in kw.items():
+        ftype = dict(struct._fields_)[k]
+        if ftype is _vp:
+            setattr(struct, k, ptr(v))
+        elif hasattr(ftype, "_length_") and not isinstance(v, ftype):
+            arr = getattr(struct, k)
+            for i, x in enumerate(v):
+                arr[i] = x
+        else:
+            setattr(struct, k, v)
+    return struct
+
+
+# every symbol include/fishbird.h declares (checked by tests/test_cabi_exports.py)
+EXPORTS = [
+    "fb_abi_version", "fb_last_error", "fb_device_count", "fb_set_device",
+    "fb_orb_create", "fb_orb_destroy", "fb_orb_get_tables", "fb_orb_capacity", "fb_orb_extract", "fb_orb_extract_batch_dev",
+    "fb_orb_get_level", "fb_grid_build_batch_dev", "fb_bird_keys_to_cam_dev",
+    "fb_descriptor_distance_dev", "fb_descriptor_distance",
+    "fb_match_projection_frame_dev", "fb_match_projection_frame",
+    "fb_match_bird_mappoints_dev", "fb_match_bird_mappoints",
+    "fb_match_projection_points_dev", "fb_match_projection_points",
+    "fb_match_birdview_dev", "fb_match_birdview",
+    "fb_pose_opt_batch_dev", "fb_pose_opt", "fb_pose_gather_front_dev", "fb_pose_gather_bird_dev",
+    "fb_local_ba",
+]

@@ -1,0 +1,357 @@
+/*
+ * fishbird.h -- C ABI of the MI355X-native front-end + optimiser path.
+ *
+ * This header is the drop-in boundary: every entry point names the reference
+ * interface it replaces (file:line in JingruiYu/FishBirdEyeVisualSLAM).  Plain
+ * pointers and sizes only; no C++/torch/OpenCV types.  INTEGRATION.md shows the
+ * shim a maintainer adds inside ORBextractor / ORBmatcher / Optimizer.
+ *
+ * Pointer convention
+ *   *_dev entry points take DEVICE pointers (HBM resident) and a hipStream_t
+ *   passed as void*; they enqueue work and return without synchronising.
+ *   Entry points without the suffix take HOST pointers, copy, run the same
+ *   kernels and synchronise before returning (drop-in for the reference call).
+ *
+ * Status: 0 = ok, <0 = error (fb_last_error() gives the text).
+ * There is no CPU fallback: without a HIP device every compute call fails with
+ * FB_ERR_NODEVICE.
+ */
+#ifndef FISHBIRD_H_
+#define FISHBIRD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FB_ABI_VERSION 1
+#define FB_MAX_LEVELS 16
+#define FB_DESC_BYTES 32 /* 256-bit rBRIEF, ORBextractor.cc:1068 */
+
+enum {
+  FB_OK = 0,
+  FB_ERR_ARG = -1,      /* bad argument */
+  FB_ERR_HIP = -2,      /* HIP runtime error */
+  FB_ERR_CAPACITY = -3, /* an internal/declared capacity was exceeded */
+  FB_ERR_NODEVICE = -4  /* no HIP device / kernels not loadable */
+};
+
+/* ---- runtime ------------------------------------------------------------ */
+int fb_abi_version(void);
+const char *fb_last_error(void);
+int fb_device_count(void);
+int fb_set_device(int device);
+
+/* cv::KeyPoint as POD (ORBextractor.cc:837-847: pt, size, angle, response, octave) */
+typedef struct fb_keypoint {
+  float x, y;
+  float size;
+  float angle;
+  float response;
+  int32_t octave;
+} fb_keypoint;
+
+/* ======================================================================== */
+/* ORBextractor  (include/ORBextractor.h:51-85, src/ORBextractor.cc:410-1132) */
+/* ======================================================================== */
+typedef struct fb_orb fb_orb;
+
+typedef struct fb_orb_params { /* ctor args, ORBextractor.h:51-52 */
+  int32_t nfeatures;
+  float scale_factor;
+  int32_t nlevels;
+  int32_t ini_th_fast;
+  int32_t min_th_fast;
+} fb_orb_params;
+
+typedef struct fb_orb_tables { /* getters ORBextractor.h:63-83 + mnFeaturesPerLevel, umax */
+  float scale_factor[FB_MAX_LEVELS];
+  float inv_scale_factor[FB_MAX_LEVELS];
+  float level_sigma2[FB_MAX_LEVELS];
+  float inv_level_sigma2[FB_MAX_LEVELS];
+  int32_t features_per_level[FB_MAX_LEVELS];
+  int32_t umax[16];
+} fb_orb_tables;
+
+/* replaces ORBextractor::ORBextractor (ORBextractor.cc:410-470) */
+int fb_orb_create(const fb_orb_params *params, fb_orb **out);
+void fb_orb_destroy(fb_orb *h);
+int fb_orb_get_tables(const fb_orb *h, fb_orb_tables *out);
+/* Output capacity per image.  DistributeOctTree stops at >= N nodes, so a level can
+ * return up to N+2 keypoints (ORBextractor.cc:669,729): capacity = nfeatures + 8*nlevels. */
+int fb_orb_capacity(const fb_orb_params *params);
+
+/* replaces ORBextractor::operator() (ORBextractor.cc:1043-1105), host buffers.
+ * image: u8, row-major, `stride` bytes per row.  keypoints/descriptors must hold
+ * cap = fb_orb_capacity() entries (desc: cap*32 bytes).  *n_out <= cap.        */
+int fb_orb_extract(fb_orb *h, const uint8_t *image, int width, int height, int stride,
+                   fb_keypoint *keypoints, uint8_t *descriptors, int32_t *n_out);
+
+/* same, `batch` equally sized images resident in HBM; image b starts at
+ * d_images + b*image_stride.  Outputs: d_keypoints[batch][cap],
+ * d_descriptors[batch][cap][32], d_n[batch], cap = fb_orb_capacity().          */
+int fb_orb_extract_batch_dev(fb_orb *h, const uint8_t *d_images, int batch, int width, int height,
+                             int stride, size_t image_stride, fb_keypoint *d_keypoints,
+                             uint8_t *d_descriptors, int32_t *d_n, void *stream);
+
+/* debug/parity access to the pyramid level of image `b` of the last batch
+ * (public member mvImagePyramid, ORBextractor.h:85). dst is host, w*h bytes.  */
+int fb_orb_get_level(fb_orb *h, int b, int level, uint8_t *dst, int *w, int *hgt);
+
+/* ======================================================================== */
+/* Frame grid (src/Frame.cc:381-411, 548-570; include/Frame.h:38-40)         */
+/* ======================================================================== */
+typedef struct fb_grid_geom {
+  float min_x, min_y;       /* mnMinX, mnMinY (0 for the bird grid)            */
+  float inv_w, inv_h;       /* mfGridElementWidthInv / HeightInv               */
+  int32_t cols, rows;       /* 64x48 front, 32x32 bird                         */
+} fb_grid_geom;
+
+/* AssignFeaturesToGrid (Frame.cc:381-411): CSR with cell id = ix*rows+iy, items
+ * in ascending keypoint index.  d_cell_start[batch][cols*rows+1],
+ * d_cell_items[batch][cap].  Keypoints are read at kp_stride entries per image. */
+int fb_grid_build_batch_dev(const fb_keypoint *d_keypoints, const int32_t *d_n, int batch,
+                            int kp_stride, const fb_grid_geom *geom, int32_t *d_cell_start,
+                            int32_t *d_cell_items, void *stream);
+
+/* Bird keypoint -> base XY -> camera XYZ (Frame.cc:365-373, Converter.cc:284-292,312-318):
+ * d_cam_xyz[b][i] = Tcb * BirdPixel2BaseXY(kps[i]).  Tcb = rows 0..2 of Frame::Tcb. */
+int fb_bird_keys_to_cam_dev(const fb_keypoint *d_kps, const int32_t *d_n, int batch, int kp_stride,
+                            int bird_cols, int bird_rows, double pixel2meter,
+                            double rear_axle_to_center, const float *Tcb12 /* host */,
+                            float *d_cam_xyz, void *stream);
+
+/* ======================================================================== */
+/* ORBmatcher (include/ORBmatcher.h:41-88, src/ORBmatcher.cc)                */
+/* ======================================================================== */
+typedef struct fb_matcher_params { /* ORBmatcher.h:41 */
+  float nnratio;
+  int32_t check_orientation;
+} fb_matcher_params;
+
+/* DescriptorDistance (ORBmatcher.cc:1951-1967): out[i] = popcount(a[i]^b[i]) over 32 bytes */
+int fb_descriptor_distance_dev(const uint8_t *d_a, const uint8_t *d_b, int n, int32_t *d_out,
+                               void *stream);
+int fb_descriptor_distance(const uint8_t *a, const uint8_t *b, int n, int32_t *out);
+
+/* Camera + frame constants used by the projection matchers (Frame.h statics) */
+typedef struct fb_camera {
+  float fx, fy, cx, cy;
+  float min_x, min_y, max_x, max_y; /* mnMinX.. image bounds, Frame.cc:741-795 */
+} fb_camera;
+
+/* --- M3: SearchByProjection(Frame& cur, const Frame& last, th, bMono=true)
+ *     (ORBmatcher.cc:1329-1471).  One problem per batch entry.  All arrays are
+ *     [batch][stride] with the per-problem counts in n_cur / n_last.            */
+typedef struct fb_proj_frame_args {
+  int32_t batch;
+  int32_t cur_stride;  /* entries per problem in the cur_* arrays            */
+  int32_t last_stride; /* entries per problem in the last_* arrays           */
+  /* current frame = search targets */
+  const int32_t *n_cur;          /* [batch]                                   */
+  const fb_keypoint *cur_kps;    /* mvKeysUn: x,y,octave,angle used            */
+  const uint8_t *cur_desc;       /* mDescriptors rows                          */
+  const int32_t *cur_cell_start; /* [batch][cols*rows+1]                       */
+  const int32_t *cur_cell_items; /* [batch][cur_stride]                        */
+  const uint8_t *cur_blocked;    /* mvpMapPoints[i] && Observations()>0 on entry; may be NULL */
+  const float *cur_Tcw;          /* [batch][12] row-major 3x4 of mTcw          */
+  /* last frame = queries */
+  const int32_t *n_last;         /* [batch]                                   */
+  const uint8_t *last_valid;     /* mvpMapPoints[i] && !mvbOutlier[i]          */
+  const uint8_t *last_obs_pos;   /* pMP->Observations()>0                      */
+  const float *last_xw;          /* [..][3] pMP->GetWorldPos()                 */
+  const uint8_t *last_desc;      /* pMP->GetDescriptor()                       */
+  const int32_t *last_octave;    /* LastFrame.mvKeys[i].octave                 */
+  const float *last_angle;       /* LastFrame.mvKeysUn[i].angle                */
+  /* constants */
+  fb_camera cam;
+  fb_grid_geom grid;
+  float scale_factors[FB_MAX_LEVELS]; /* CurrentFrame.mvScaleFactors           */
+  float th;
+  fb_matcher_params matcher;
+  /* outputs */
+  int32_t *match_cur_to_last; /* [batch][cur_stride]: index into last, or -1   */
+  int32_t *nmatches;          /* [batch] return value                          */
+} fb_proj_frame_args;
+int fb_match_projection_frame_dev(const fb_proj_frame_args *args, void *stream);
+int fb_match_projection_frame(const fb_proj_frame_args *args); /* host pointers */
+
+/* --- M9: BirdMapPointMatch(CurF, vRefMapPointsBird, windowSize, filterSize)
+ *     (ORBmatcher.cc:1763-1902)                                               */
+typedef struct fb_bird_mp_args {
+  int32_t batch;
+  int32_t cur_stride;
+  int32_t ref_stride;
+  const int32_t *n_cur;           /* mvKeysBird.size() == mDescriptorsBird.rows */
+  const fb_keypoint *cur_kps;     /* mvKeysBird                                */
+  const uint8_t *cur_desc;        /* mDescriptorsBird                          */
+  const float *cur_cam_xyz;       /* [..][3] mvKeysBirdCamXYZ                  */
+  const int32_t *cur_cell_start;  /* bird grid CSR                             */
+  const int32_t *cur_cell_items;
+  const float *cur_Tcw;           /* [batch][12]                               */
+  const int32_t *n_ref;
+  const uint8_t *ref_valid;       /* vRefMapPointsBird[i] != NULL              */
+  const float *ref_xw;            /* [..][3]                                   */
+  const uint8_t *ref_desc;
+  float Tbc[12];                  /* Frame::Tbc rows 0..2 (Frame.cc:1018-1030) */
+  int32_t bird_cols, bird_rows;   /* Frame::birdviewCols/Rows                  */
+  double meter2pixel;             /* Frame.cc:41                               */
+  double rear_axle_to_center;     /* Frame.cc:42                               */
+  fb_grid_geom grid;              /* 32x32, min=0                              */
+  int32_t window_size;
+  float filter_size;
+  fb_matcher_params matcher;
+  int32_t *match_cur_to_ref;      /* [batch][cur_stride]: mvpMapPointsBird as ref index or -1 (in/out: pre-fill) */
+  int32_t *ninliers;              /* [batch] return value                      */
+} fb_bird_mp_args;
+int fb_match_bird_mappoints_dev(const fb_bird_mp_args *args, void *stream);
+int fb_match_bird_mappoints(const fb_bird_mp_args *args);
+
+/* --- M2: SearchByProjection(Frame&, vector<MapPoint*>&, th) (ORBmatcher.cc:46-130) */
+typedef struct fb_proj_points_args {
+  int32_t batch;
+  int32_t cur_stride;
+  int32_t mp_stride;
+  const int32_t *n_cur;
+  const fb_keypoint *cur_kps;
+  const uint8_t *cur_desc;
+  const int32_t *cur_cell_start;
+  const int32_t *cur_cell_items;
+  const uint8_t *cur_blocked;    /* F.mvpMapPoints[idx] && Observations()>0 on entry */
+  const int32_t *n_mp;
+  const uint8_t *mp_track;       /* mbTrackInView && !isBad()                  */
+  const uint8_t *mp_obs_pos;     /* pMP->Observations()>0                      */
+  const float *mp_proj;          /* [..][2] mTrackProjX, mTrackProjY           */
+  const int32_t *mp_level;       /* mnTrackScaleLevel                          */
+  const float *mp_view_cos;      /* mTrackViewCos                              */
+  const uint8_t *mp_desc;
+  fb_grid_geom grid;
+  float scale_factors[FB_MAX_LEVELS];
+  float th;
+  fb_matcher_params matcher;
+  int32_t *match_cur_to_mp;      /* [batch][cur_stride] index into mp or -1     */
+  int32_t *nmatches;
+} fb_proj_points_args;
+int fb_match_projection_points_dev(const fb_proj_points_args *args, void *stream);
+int fb_match_projection_points(const fb_proj_points_args *args);
+
+/* --- M8: BirdviewMatch(CurF, refKeys, refDesc, refMPBirds, matches, isProject=0, window)
+ *     (ORBmatcher.cc:1602-1760), live form isProject=0                        */
+typedef struct fb_birdview_args {
+  int32_t batch;
+  int32_t cur_stride;
+  int32_t ref_stride;
+  const int32_t *n_cur;
+  const fb_keypoint *cur_kps;
+  const uint8_t *cur_desc;
+  const int32_t *cur_cell_start;
+  const int32_t *cur_cell_items;
+  const int32_t *n_ref;
+  const fb_keypoint *ref_kps;
+  const uint8_t *ref_desc;
+  fb_grid_geom grid;
+  int32_t window_size;
+  fb_matcher_params matcher;
+  int32_t *match_ref_to_cur; /* [batch][ref_stride] vnMatches12 after culling (-1 = none) */
+  int32_t *match_dist;       /* [batch][ref_stride] vMatchedDistance                      */
+  int32_t *nmatches;         /* [batch] return value                                      */
+  int32_t *n_dmatches;       /* [batch] number of DMatch emitted (vnMatches12[i] > 0)     */
+} fb_birdview_args;
+int fb_match_birdview_dev(const fb_birdview_args *args, void *stream);
+int fb_match_birdview(const fb_birdview_args *args);
+
+/* ======================================================================== */
+/* Optimizer::PoseOptimization / PoseOptimizationWithBird / BirdOptimization */
+/* (include/Optimizer.h:40-68, src/Optimizer.cc:246-835)                     */
+/* ======================================================================== */
+enum { FB_POSE_FRONT = 0, FB_POSE_FRONT_BIRD = 1, FB_POSE_BIRD = 2 };
+
+typedef struct fb_pose_opt_args {
+  int32_t batch;
+  int32_t mode;          /* FB_POSE_*                                          */
+  int32_t front_stride;  /* entries per problem in front_* arrays              */
+  int32_t bird_stride;
+  float fx, fy, cx, cy;
+  float wF, wB;          /* Optimizer.h:52 defaults 1,1                        */
+  /* front edges: one per mvpMapPoints[i] != NULL (Optimizer.cc:525-571)        */
+  const int32_t *n_front;        /* [batch]                                    */
+  const float *front_xw;         /* [..][3]                                    */
+  const float *front_obs;        /* [..][2] kpUn.pt                            */
+  const float *front_inv_sigma2; /* mvInvLevelSigma2[kpUn.octave]              */
+  const uint8_t *front_valid;    /* slot i carries an edge (mvpMapPoints[i] != NULL); NULL = all */
+  /* bird edges: one per mvpMapPointsBird[i] != NULL (Optimizer.cc:575-602)     */
+  const int32_t *n_bird;
+  const float *bird_xw;          /* [..][3]                                    */
+  const float *bird_xc;          /* [..][3] mvKeysBirdCamXYZ                   */
+  const float *bird_inv_sigma2;
+  const uint8_t *bird_valid;     /* mvpMapPointsBird[i] != NULL; NULL = all       */
+  uint8_t *bird_outlier;         /* in/out mvBirdOutlier (not reset by the reference) */
+  /* pose in/out: pFrame->mTcw rows 0..2, row-major 3x4 float                   */
+  float *Tcw;                    /* [batch][12]                                */
+  uint8_t *front_outlier;        /* out mvbOutlier                             */
+  int32_t *ninliers;             /* [batch] return value                       */
+} fb_pose_opt_args;
+int fb_pose_opt_batch_dev(const fb_pose_opt_args *args, void *stream);
+
+/* Device-side form of the edge construction loops of PoseOptimizationWithBird
+ * (Optimizer.cc:525-571 front, :575-602 bird): slot i of the frame becomes edge i.
+ *   front: valid = match[i] >= 0, Xw = mp_xw[match[i]], obs = kps[i].pt,
+ *          inv_sigma2 = inv_level_sigma2[kps[i].octave]
+ *   bird : additionally Xc = cam_xyz[i]                                        */
+int fb_pose_gather_front_dev(int batch, int kp_stride, int mp_stride, const int32_t *d_n,
+                             const fb_keypoint *d_kps, const int32_t *d_match, const float *d_mp_xw,
+                             const float *inv_level_sigma2 /* host, nlevels */, int nlevels,
+                             float *d_front_xw, float *d_front_obs, float *d_front_inv_sigma2,
+                             uint8_t *d_front_valid, void *stream);
+int fb_pose_gather_bird_dev(int batch, int kp_stride, int mp_stride, const int32_t *d_n,
+                            const fb_keypoint *d_kps, const float *d_cam_xyz, const int32_t *d_match,
+                            const float *d_mpb_xw, const float *inv_level_sigma2, int nlevels,
+                            float *d_bird_xw, float *d_bird_xc, float *d_bird_inv_sigma2,
+                            uint8_t *d_bird_valid, void *stream);
+int fb_pose_opt(const fb_pose_opt_args *args); /* host pointers */
+
+/* ======================================================================== */
+/* Optimizer::LocalBundleAdjustment / LocalBundleAdjustmentWithOdom          */
+/* (src/Optimizer.cc:838-1165, 2137-2670)                                    */
+/* ======================================================================== */
+typedef struct fb_local_ba_args {
+  int32_t with_odom;   /* 0: LocalBundleAdjustment (SE3Expmap edges), 1: ...WithOdom (Quat edges + bird + odom) */
+  float fx, fy, cx, cy;
+  float wF, wB, wP;
+  int32_t n_kf;               /* local + fixed keyframes, graph insertion order */
+  float *kf_Tcw;              /* in/out [n_kf][12]                              */
+  const uint8_t *kf_fixed;    /* [n_kf]                                         */
+  int32_t n_mp;
+  float *mp_xw;               /* in/out [n_mp][3]                               */
+  int32_t n_mpb;
+  float *mpb_xw;              /* in/out [n_mpb][3]                              */
+  /* front observations, grouped by map point in insertion order */
+  int32_t n_obs;
+  const int32_t *obs_kf;      /* index into kf                                  */
+  const int32_t *obs_mp;      /* index into mp                                  */
+  const float *obs_uv;        /* [n_obs][2]                                     */
+  const float *obs_inv_sigma2;
+  /* bird observations */
+  int32_t n_bobs;
+  const int32_t *bobs_kf;
+  const int32_t *bobs_mpb;
+  const float *bobs_xc;       /* [n_bobs][3]                                    */
+  const float *bobs_inv_sigma2;
+  /* odometry edges (Optimizer.cc:2419-2495) */
+  int32_t n_odom;
+  const int32_t *odom_kf_i;
+  const int32_t *odom_kf_j;
+  const float *odom_Tij;      /* [n_odom][12]                                   */
+  const double *odom_info;    /* information scale per edge (1e4*wP, 2e3, 1e3*wP) */
+  const volatile uint8_t *stop_flag; /* host-visible pbStopFlag, may be NULL    */
+  uint8_t *obs_outlier;       /* out [n_obs]                                    */
+  uint8_t *bobs_outlier;      /* out [n_bobs]                                   */
+} fb_local_ba_args;
+int fb_local_ba(const fb_local_ba_args *args); /* host pointers */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FISHBIRD_H_ */
