@@ -1,0 +1,87 @@
+/*
+ * fb_common.h -- shared host/device plumbing of the HIP library (gfx950 only).
+ */
+#ifndef FB_COMMON_H_
+#define FB_COMMON_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <climits>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/fishbird.h"
+
+#define FB_HD __host__ __device__
+#include "fb_detmath.h"
+
+namespace fb {
+
+void set_error(const char *fmt, ...);
+int check_device();  // FB_OK or FB_ERR_NODEVICE (sets error)
+
+#define FB_HIP(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      fb::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+      return FB_ERR_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+#define FB_ARG(cond)                                                        \
+  do {                                                                      \
+    if (!(cond)) {                                                          \
+      fb::set_error("%s:%d: bad argument: %s", __FILE__, __LINE__, #cond); \
+      return FB_ERR_ARG;                                                    \
+    }                                                                       \
+  } while (0)
+
+#define FB_TRY(expr)           \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ != FB_OK) return rc_; \
+  } while (0)
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Device scratch that lives for one host-pointer call.
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t n) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = n ? n : 1;
+    FB_HIP(hipMalloc(&p, bytes));
+    return FB_OK;
+  }
+  int upload(const void *src, size_t n) {
+    FB_TRY(alloc(n));
+    if (n && src) FB_HIP(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
+    return FB_OK;
+  }
+  int download(void *dst, size_t n) const {
+    if (n) FB_HIP(hipMemcpy(dst, p, n, hipMemcpyDeviceToHost));
+    return FB_OK;
+  }
+  template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// 256-bit Hamming distance of two 32-byte rows given as 8 dwords each
+// (DescriptorDistance, ORBmatcher.cc:1951-1967; v_bcnt_u32_b32 instead of the SWAR bithack)
+__device__ __forceinline__ int hamming256(const uint32_t a[8], const uint4 *__restrict__ b) {
+  const uint4 b0 = b[0], b1 = b[1];
+  return __popc(a[0] ^ b0.x) + __popc(a[1] ^ b0.y) + __popc(a[2] ^ b0.z) + __popc(a[3] ^ b0.w) +
+         __popc(a[4] ^ b1.x) + __popc(a[5] ^ b1.y) + __popc(a[6] ^ b1.z) + __popc(a[7] ^ b1.w);
+}
+
+}  // namespace fb
+#endif

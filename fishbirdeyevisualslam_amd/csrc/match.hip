@@ -1,0 +1,782 @@
+// match.hip -- ORBmatcher hot-path entry points as CDNA4 kernels (gfx950).
+//
+// Replaces (reference file:line):
+//   DescriptorDistance                         src/ORBmatcher.cc:1951-1967
+//   Frame::AssignFeaturesToGrid / PosInGrid*   src/Frame.cc:381-411, 548-570
+//   Frame::GetFeaturesInArea[Birdview]         src/Frame.cc:493-546, 572-626
+//   SearchByProjection(Frame&, const Frame&)   src/ORBmatcher.cc:1329-1471   (M3)
+//   SearchByProjection(Frame&, vector<MP*>&)   src/ORBmatcher.cc:46-138      (M2)
+//   BirdMapPointMatch                          src/ORBmatcher.cc:1763-1902   (M9)
+//   BirdviewMatch (isProject=0)                src/ORBmatcher.cc:1602-1760   (M8)
+//   ComputeThreeMaxima                         src/ORBmatcher.cc:1905-1946
+//
+// Layout: one workgroup per problem (frame pair).  The target frame's descriptor table
+// (n x 32 B), keypoint x/y/octave and the grid CSR are staged once into LDS with coalesced
+// 16-byte loads; every query lane then walks its grid window out of LDS and scores
+// candidates with v_bcnt_u32_b32.  HBM traffic per problem is therefore the algorithmic
+// minimum (each input byte read once, each output written once).
+//
+// Serial semantics: M2/M3 skip a candidate that an EARLIER query already took (with a map
+// point that has observations).  That dependency is resolved by a fixed-point iteration:
+// every round all queries re-pick their best candidate given the previous round's claims
+// ("owner[c] = smallest claiming query index"); query q only honours claims of q' < q.
+// By induction on q the iteration converges to exactly the serial result (query 0 is final
+// after round 0, query q after at most round q); in practice 2-3 rounds.
+#include "fb_common.h"
+
+namespace {
+
+constexpr int TH_HIGH = 100;      // ORBmatcher.cc:38
+constexpr int TH_LOW = 50;        // :39
+constexpr int HISTO_LENGTH = 30;  // :40
+constexpr int NONE = 0x7fffffff;
+constexpr int MATCH_THREADS = 1024;
+
+struct TargetLds {  // target frame staged in LDS
+  const uint4 *desc;     // [n][2]
+  const float2 *xy;      // [n]
+  const uint8_t *oct;    // [n]
+  const uint16_t *cs;    // [ncell+1]
+  const uint16_t *items; // [n]
+};
+
+// Frame::GetFeaturesInArea (Frame.cc:493-546, inclusive cell loops) and
+// Frame::GetFeaturesInAreaBirdview (Frame.cc:572-626, exclusive loops, no min offset).
+template <bool BIRD, typename F>
+__device__ __forceinline__ void for_area(const fb_grid_geom &g, const TargetLds &T, float x, float y, float r,
+                                         int minLevel, int maxLevel, F &&f) {
+  int nMinCellX, nMaxCellX, nMinCellY, nMaxCellY;
+  if (BIRD) {
+    nMinCellX = max(0, (int)floorf((x - r) * g.inv_w));
+    if (nMinCellX >= g.cols) return;
+    nMaxCellX = min(g.cols - 1, (int)ceilf((x + r) * g.inv_w));
+    if (nMaxCellX < 0) return;
+    nMinCellY = max(0, (int)floorf((y - r) * g.inv_h));
+    if (nMinCellY >= g.rows) return;
+    nMaxCellY = min(g.rows - 1, (int)ceilf((y + r) * g.inv_h));
+    if (nMaxCellY < 0) return;
+    nMaxCellX -= 1;  // ix < nMaxCellX
+    nMaxCellY -= 1;
+  } else {
+    nMinCellX = max(0, (int)floorf((x - g.min_x - r) * g.inv_w));
+    if (nMinCellX >= g.cols) return;
+    nMaxCellX = min(g.cols - 1, (int)ceilf((x - g.min_x + r) * g.inv_w));
+    if (nMaxCellX < 0) return;
+    nMinCellY = max(0, (int)floorf((y - g.min_y - r) * g.inv_h));
+    if (nMinCellY >= g.rows) return;
+    nMaxCellY = min(g.rows - 1, (int)ceilf((y - g.min_y + r) * g.inv_h));
+    if (nMaxCellY < 0) return;
+  }
+  const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+  for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+    const int cbase = ix * g.rows;
+    // cells (ix, nMinCellY..nMaxCellY) are contiguous in the CSR (cell id = ix*rows+iy)
+    const int j0 = T.cs[cbase + nMinCellY], j1 = T.cs[cbase + nMaxCellY + 1];
+    for (int j = j0; j < j1; j++) {
+      const int idx = T.items[j];
+      if (bCheckLevels) {
+        const int o = T.oct[idx];
+        if (o < minLevel) continue;
+        if (maxLevel >= 0 && o > maxLevel) continue;
+      }
+      const float2 p = T.xy[idx];
+      const float distx = p.x - x, disty = p.y - y;
+      if (fabsf(distx) < r && fabsf(disty) < r) f(idx);
+    }
+  }
+}
+
+__device__ __forceinline__ int rot_bin(float rot) {  // ORBmatcher.cc:1434-1439
+  const float factor = 1.0f / HISTO_LENGTH;
+  if (rot < 0.0f) rot += 360.0f;
+  int bin = (int)roundf(rot * factor);
+  if (bin == HISTO_LENGTH) bin = 0;
+  return bin;
+}
+
+// ComputeThreeMaxima, ORBmatcher.cc:1905-1946
+__device__ void three_maxima(const int *sz, int &ind1, int &ind2, int &ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  ind1 = ind2 = ind3 = -1;
+  for (int i = 0; i < HISTO_LENGTH; i++) {
+    const int s = sz[i];
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+__device__ __forceinline__ void xform(const float *T, const float *X, float *o) {  // rows 0..2 of a 3x4
+#pragma unroll
+  for (int r = 0; r < 3; r++) o[r] = ((T[r * 4 + 0] * X[0] + T[r * 4 + 1] * X[1]) + T[r * 4 + 2] * X[2]) + T[r * 4 + 3];
+}
+
+// LDS carve for a target frame of n keypoints / ncell cells. All offsets 16-B aligned.
+struct Carve {
+  size_t desc, xy, oct, cs, items, end;
+  __host__ __device__ Carve(int n, int ncell) {
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    desc = 0;
+    xy = up(desc + (size_t)n * 32);
+    oct = up(xy + (size_t)n * 8);
+    cs = up(oct + (size_t)n);
+    items = up(cs + (size_t)(ncell + 1) * 2);
+    end = up(items + (size_t)n * 2);
+  }
+};
+
+__device__ __forceinline__ TargetLds stage_target(uint8_t *smem, const Carve &cv, int n, int ncell,
+                                                  const fb_keypoint *kps, const uint8_t *desc, const int32_t *cs,
+                                                  const int32_t *items) {
+  uint32_t *ldesc = reinterpret_cast<uint32_t *>(smem + cv.desc);
+  float2 *lxy = reinterpret_cast<float2 *>(smem + cv.xy);
+  uint8_t *loct = smem + cv.oct;
+  uint16_t *lcs = reinterpret_cast<uint16_t *>(smem + cv.cs);
+  uint16_t *litems = reinterpret_cast<uint16_t *>(smem + cv.items);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // descriptor table: n*32 B as 16-byte vectors (rows are 32-B aligned in the C-ABI arrays)
+  const uint4 *src = reinterpret_cast<const uint4 *>(desc);
+  uint4 *dst = reinterpret_cast<uint4 *>(ldesc);
+  for (int i = tid; i < n * 2; i += nt) dst[i] = src[i];
+  for (int i = tid; i < n; i += nt) {
+    const fb_keypoint k = kps[i];
+    lxy[i] = make_float2(k.x, k.y);
+    loct[i] = (uint8_t)k.octave;
+  }
+  for (int i = tid; i <= ncell; i += nt) lcs[i] = (uint16_t)cs[i];
+  const int nitems = cs[ncell];
+  for (int i = tid; i < nitems; i += nt) litems[i] = (uint16_t)items[i];
+  TargetLds T{reinterpret_cast<const uint4 *>(ldesc), lxy, loct, lcs, litems};
+  return T;
+}
+
+// ---------------------------------------------------------------------------------------
+// M3  SearchByProjection(CurrentFrame, LastFrame, th, bMono=true)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int ncell = A.grid.cols * A.grid.rows;
+  const size_t co = (size_t)b * A.cur_stride, lo = (size_t)b * A.last_stride;
+  const int ncur = A.n_cur[b], nlast = A.n_last[b];
+  const Carve cv(A.cur_stride, ncell);
+  const TargetLds T = stage_target(smem, cv, ncur, ncell, A.cur_kps + co, A.cur_desc + co * 32,
+                                   A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co);
+  int *ownerA = reinterpret_cast<int *>(smem + cv.end);  // [cur_stride]
+  int *ownerB = ownerA + A.cur_stride;                   // [cur_stride]
+  int *assignA = ownerB + A.cur_stride;                  // [last_stride]
+  int *assignB = assignA + A.last_stride;                // [last_stride]
+  __shared__ int s_changed, s_n, s_hist[HISTO_LENGTH], s_ind[3];
+  __shared__ float s_T[12];
+  if (tid < 12) s_T[tid] = A.cur_Tcw[(size_t)b * 12 + tid];
+  const uint8_t *blocked0 = A.cur_blocked ? A.cur_blocked + co : nullptr;
+  for (int i = tid; i < ncur; i += nt) ownerA[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
+  for (int q = tid; q < nlast; q += nt) assignA[q] = NONE;
+  __syncthreads();
+
+  for (int round = 0; round <= nlast + 1; round++) {
+    for (int i = tid; i < ncur; i += nt) ownerB[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    for (int q = tid; q < nlast; q += nt) {
+      int best = NONE;
+      if (A.last_valid[lo + q]) {
+        float X[3] = {A.last_xw[(lo + q) * 3], A.last_xw[(lo + q) * 3 + 1], A.last_xw[(lo + q) * 3 + 2]};
+        float pc[3];
+        xform(s_T, X, pc);
+        const float xc = pc[0], yc = pc[1];
+        const float invzc = (float)(1.0 / pc[2]);
+        if (!(invzc < 0)) {
+          const float u = A.cam.fx * xc * invzc + A.cam.cx;
+          const float v = A.cam.fy * yc * invzc + A.cam.cy;
+          if (!(u < A.cam.min_x || u > A.cam.max_x) && !(v < A.cam.min_y || v > A.cam.max_y)) {
+            const int oct = A.last_octave[lo + q];
+            const float radius = A.th * A.scale_factors[oct];
+            uint32_t d[8];
+            const uint4 *dq = reinterpret_cast<const uint4 *>(A.last_desc + (lo + q) * 32);
+            const uint4 d0 = dq[0], d1 = dq[1];
+            d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+            int bestDist = 256;
+            for_area<false>(A.grid, T, u, v, radius, oct - 1, oct + 1, [&](int i2) {
+              if (ownerA[i2] < q) return;  // taken by an earlier query / occupied on entry
+              const int dist = fb::hamming256(d, T.desc + i2 * 2);
+              if (dist < bestDist) { bestDist = dist; best = i2; }
+            });
+            if (bestDist > TH_HIGH) best = NONE;
+          }
+        }
+      }
+      assignB[q] = best;
+      if (best != assignA[q]) s_changed = 1;
+      if (best != NONE && A.last_obs_pos[lo + q]) atomicMin(&ownerB[best], q);
+    }
+    __syncthreads();
+    const int changed = s_changed;
+    int *t = ownerA; ownerA = ownerB; ownerB = t;
+    t = assignA; assignA = assignB; assignB = t;
+    __syncthreads();
+    if (!changed) break;
+  }
+
+  // commit: last writer wins; rotation histogram culling (ORBmatcher.cc:1446-1468)
+  int *matchL = ownerB;  // reuse
+  for (int i = tid; i < ncur; i += nt) matchL[i] = -1;
+  if (tid < HISTO_LENGTH) s_hist[tid] = 0;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  const bool ori = A.matcher.check_orientation != 0;
+  for (int q = tid; q < nlast; q += nt) {
+    const int c = assignA[q];
+    if (c == NONE) continue;
+    atomicMax(&matchL[c], q);
+    atomicAdd(&s_n, 1);
+    if (ori) {
+      const int bin = rot_bin(A.last_angle[lo + q] - A.cur_kps[co + c].angle);
+      atomicAdd(&s_hist[bin], 1);
+      assignB[q] = bin;
+    }
+  }
+  __syncthreads();
+  if (ori) {
+    if (tid == 0) three_maxima(s_hist, s_ind[0], s_ind[1], s_ind[2]);
+    __syncthreads();
+    for (int q = tid; q < nlast; q += nt) {
+      const int c = assignA[q];
+      if (c == NONE) continue;
+      const int bin = assignB[q];
+      if (bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2]) {
+        matchL[c] = -1;
+        atomicSub(&s_n, 1);
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < ncur; i += nt) A.match_cur_to_last[co + i] = matchL[i];
+  if (tid == 0) A.nmatches[b] = s_n;
+}
+
+// ---------------------------------------------------------------------------------------
+// M2  SearchByProjection(Frame&, const vector<MapPoint*>&, th)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MATCH_THREADS) void k_proj_points(fb_proj_points_args A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int ncell = A.grid.cols * A.grid.rows;
+  const size_t co = (size_t)b * A.cur_stride, mo = (size_t)b * A.mp_stride;
+  const int ncur = A.n_cur[b], nmp = A.n_mp[b];
+  const Carve cv(A.cur_stride, ncell);
+  const TargetLds T = stage_target(smem, cv, ncur, ncell, A.cur_kps + co, A.cur_desc + co * 32,
+                                   A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co);
+  int *ownerA = reinterpret_cast<int *>(smem + cv.end);
+  int *ownerB = ownerA + A.cur_stride;
+  int *assignA = ownerB + A.cur_stride;
+  int *assignB = assignA + A.mp_stride;
+  __shared__ int s_changed, s_n;
+  const uint8_t *blocked0 = A.cur_blocked ? A.cur_blocked + co : nullptr;
+  for (int i = tid; i < ncur; i += nt) ownerA[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
+  for (int q = tid; q < nmp; q += nt) assignA[q] = NONE;
+  const bool bFactor = A.th != 1.0f;
+  __syncthreads();
+  for (int round = 0; round <= nmp + 1; round++) {
+    for (int i = tid; i < ncur; i += nt) ownerB[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    for (int q = tid; q < nmp; q += nt) {
+      int best = NONE;
+      if (A.mp_track[mo + q]) {
+        const int lvl = A.mp_level[mo + q];
+        float r = A.mp_view_cos[mo + q] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos
+        if (bFactor) r *= A.th;
+        uint32_t d[8];
+        const uint4 *dq = reinterpret_cast<const uint4 *>(A.mp_desc + (mo + q) * 32);
+        const uint4 d0 = dq[0], d1 = dq[1];
+        d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for_area<false>(A.grid, T, A.mp_proj[(mo + q) * 2], A.mp_proj[(mo + q) * 2 + 1], r * A.scale_factors[lvl],
+                        lvl - 1, lvl, [&](int idx) {
+          if (ownerA[idx] < q) return;
+          const int dist = fb::hamming256(d, T.desc + idx * 2);
+          if (dist < bestDist) {
+            bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = T.oct[idx]; bestIdx = idx;
+          } else if (dist < bestDist2) {
+            bestLevel2 = T.oct[idx]; bestDist2 = dist;
+          }
+        });
+        if (bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && bestDist > A.matcher.nnratio * bestDist2)) best = bestIdx;
+      }
+      assignB[q] = best;
+      if (best != assignA[q]) s_changed = 1;
+      if (best != NONE && A.mp_obs_pos[mo + q]) atomicMin(&ownerB[best], q);
+    }
+    __syncthreads();
+    const int changed = s_changed;
+    int *t = ownerA; ownerA = ownerB; ownerB = t;
+    t = assignA; assignA = assignB; assignB = t;
+    __syncthreads();
+    if (!changed) break;
+  }
+  int *matchL = ownerB;
+  for (int i = tid; i < ncur; i += nt) matchL[i] = -1;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  for (int q = tid; q < nmp; q += nt) {
+    const int c = assignA[q];
+    if (c == NONE) continue;
+    atomicMax(&matchL[c], q);
+    atomicAdd(&s_n, 1);
+  }
+  __syncthreads();
+  for (int i = tid; i < ncur; i += nt) A.match_cur_to_mp[co + i] = matchL[i];
+  if (tid == 0) A.nmatches[b] = s_n;
+}
+
+// ---------------------------------------------------------------------------------------
+// M9  BirdMapPointMatch
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MATCH_THREADS) void k_bird_mappoints(fb_bird_mp_args A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int ncell = A.grid.cols * A.grid.rows;
+  const size_t co = (size_t)b * A.cur_stride, ro = (size_t)b * A.ref_stride;
+  const int ncur = A.n_cur[b], nref = A.n_ref[b];
+  const Carve cv(A.cur_stride, ncell);
+  const TargetLds T = stage_target(smem, cv, ncur, ncell, A.cur_kps + co, A.cur_desc + co * 32,
+                                   A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co);
+  int *writer = reinterpret_cast<int *>(smem + cv.end);  // [cur_stride]
+  __shared__ float s_Tcw[12], s_Tbw[12];
+  __shared__ int s_n;
+  if (tid < 12) s_Tcw[tid] = A.cur_Tcw[(size_t)b * 12 + tid];
+  for (int i = tid; i < ncur; i += nt) writer[i] = -1;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  if (tid < 12) {  // Tbw = Frame::Tbc * CurF.mTcw, ORBmatcher.cc:1784
+    const int r = tid / 4, c = tid % 4;
+    float s = (A.Tbc[r * 4 + 0] * s_Tcw[0 * 4 + c] + A.Tbc[r * 4 + 1] * s_Tcw[1 * 4 + c]) + A.Tbc[r * 4 + 2] * s_Tcw[2 * 4 + c];
+    if (c == 3) s = s + A.Tbc[r * 4 + 3];
+    s_Tbw[tid] = s;
+  }
+  __syncthreads();
+  for (int i1 = tid; i1 < nref; i1 += nt) {
+    if (!A.ref_valid[ro + i1]) continue;
+    const float X[3] = {A.ref_xw[(ro + i1) * 3], A.ref_xw[(ro + i1) * 3 + 1], A.ref_xw[(ro + i1) * 3 + 2]};
+    float lp[3];
+    xform(s_Tbw, X, lp);
+    if (fabsf(lp[2]) > 0.2) continue;
+    // Converter::BaseXY2BirdPixel, Converter.cc:304-310
+    const float ptx = (float)(A.bird_cols / 2 - lp[1] * A.meter2pixel);
+    const float pty = (float)(A.bird_rows / 2 - (lp[0] - A.rear_axle_to_center) * A.meter2pixel);
+    if (ptx < 0 || ptx >= A.bird_cols || pty < 0 || pty >= A.bird_rows) continue;
+    uint32_t d[8];
+    const uint4 *dq = reinterpret_cast<const uint4 *>(A.ref_desc + (ro + i1) * 32);
+    const uint4 d0 = dq[0], d1 = dq[1];
+    d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+    int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx = -1;
+    for_area<true>(A.grid, T, ptx, pty, (float)A.window_size, -1, -1, [&](int i2) {
+      if (i2 >= ncur) return;
+      const int dist = fb::hamming256(d, T.desc + i2 * 2);
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = i2; }
+      else if (dist < bestDist2) bestDist2 = dist;
+    });
+    if (bestDist > TH_LOW) continue;
+    if (!(bestDist < (float)bestDist2 * A.matcher.nnratio)) continue;
+    if (!(bestIdx > 0)) continue;  // sic: vnMatches12[i1] > 0, ORBmatcher.cc:1871
+    float pc[3];
+    xform(s_Tcw, X, pc);
+    const float *qv = A.cur_cam_xyz + (co + bestIdx) * 3;
+    const float e0 = pc[0] - qv[0], e1 = pc[1] - qv[1], e2 = pc[2] - qv[2];
+    const double disC = sqrt((double)e0 * e0 + (double)e1 * e1 + (double)e2 * e2);
+    if (disC < A.filter_size) {
+      atomicMax(&writer[bestIdx], i1);  // later i1 overwrites earlier
+      atomicAdd(&s_n, 1);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < ncur; i += nt)
+    if (writer[i] >= 0) A.match_cur_to_ref[co + i] = writer[i];
+  if (tid == 0) A.ninliers[b] = s_n;
+}
+
+// ---------------------------------------------------------------------------------------
+// M8  BirdviewMatch, isProject = 0
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MATCH_THREADS) void k_birdview(fb_birdview_args A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int ncell = A.grid.cols * A.grid.rows;
+  const size_t co = (size_t)b * A.cur_stride, ro = (size_t)b * A.ref_stride;
+  const int ncur = A.n_cur[b], nref = A.n_ref[b];
+  const Carve cv(A.cur_stride, ncell);
+  const TargetLds T = stage_target(smem, cv, ncur, ncell, A.cur_kps + co, A.cur_desc + co * 32,
+                                   A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co);
+  int *m12 = reinterpret_cast<int *>(smem + cv.end);  // [ref_stride]
+  int *bins = m12 + A.ref_stride;                      // [ref_stride] histogram bin of i1 or -1
+  __shared__ int s_n, s_nd, s_hist[HISTO_LENGTH], s_ind[3];
+  if (tid < HISTO_LENGTH) s_hist[tid] = 0;
+  if (tid == 0) { s_n = 0; s_nd = 0; }
+  __syncthreads();
+  const bool ori = A.matcher.check_orientation != 0;
+  for (int i1 = tid; i1 < nref; i1 += nt) {
+    int m = -1, md = INT_MAX, bin = -1;
+    const fb_keypoint kp1 = A.ref_kps[ro + i1];
+    if (!(kp1.octave > 0)) {
+      uint32_t d[8];
+      const uint4 *dq = reinterpret_cast<const uint4 *>(A.ref_desc + (ro + i1) * 32);
+      const uint4 d0 = dq[0], d1 = dq[1];
+      d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+      int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx = -1;
+      for_area<true>(A.grid, T, kp1.x, kp1.y, (float)A.window_size, kp1.octave, kp1.octave, [&](int i2) {
+        if (i2 >= ncur) return;
+        const int dist = fb::hamming256(d, T.desc + i2 * 2);
+        if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = i2; }
+        else if (dist < bestDist2) bestDist2 = dist;
+      });
+      if (bestDist <= TH_LOW) {
+        if (bestDist < (float)bestDist2 * A.matcher.nnratio) { m = bestIdx; md = bestDist; atomicAdd(&s_n, 1); }
+        if (ori) {  // pushed even when the ratio test failed, ORBmatcher.cc:1712-1722
+          bin = rot_bin(kp1.angle - A.cur_kps[co + bestIdx].angle);
+          atomicAdd(&s_hist[bin], 1);
+        }
+      }
+    }
+    m12[i1] = m;
+    bins[i1] = bin;
+    A.match_dist[ro + i1] = md;
+  }
+  __syncthreads();
+  if (ori) {
+    if (tid == 0) three_maxima(s_hist, s_ind[0], s_ind[1], s_ind[2]);
+    __syncthreads();
+    for (int i1 = tid; i1 < nref; i1 += nt) {
+      const int bin = bins[i1];
+      if (bin < 0 || bin == s_ind[0] || bin == s_ind[1] || bin == s_ind[2]) continue;
+      if (m12[i1] >= 0) { m12[i1] = -1; atomicSub(&s_n, 1); }
+    }
+    __syncthreads();
+  }
+  for (int i1 = tid; i1 < nref; i1 += nt) {
+    const int m = m12[i1];
+    A.match_ref_to_cur[ro + i1] = m;
+    if (m > 0) atomicAdd(&s_nd, 1);  // sic: > 0, ORBmatcher.cc:1755
+  }
+  __syncthreads();
+  if (tid == 0) { A.nmatches[b] = s_n; A.n_dmatches[b] = s_nd; }
+}
+
+// ---------------------------------------------------------------------------------------
+// DescriptorDistance over n row pairs; one lane per pair, 2 x 16-byte loads per row.
+// ---------------------------------------------------------------------------------------
+__global__ void k_descriptor_distance(const uint4 *__restrict__ a, const uint4 *__restrict__ b, int n,
+                                      int32_t *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4 a0 = a[2 * i], a1 = a[2 * i + 1], b0 = b[2 * i], b1 = b[2 * i + 1];
+  out[i] = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// ---------------------------------------------------------------------------------------
+// AssignFeaturesToGrid: one workgroup per frame. count -> scan -> scatter -> per-cell sort
+// (cells hold <1 keypoint on average; the sort restores ascending keypoint index, which is
+// the push_back order of Frame.cc:389-396).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grid_build(const fb_keypoint *__restrict__ kps, const int32_t *__restrict__ n,
+                                                    int kp_stride, fb_grid_geom g, int32_t *__restrict__ cell_start,
+                                                    int32_t *__restrict__ cell_items) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int ncell = g.cols * g.rows;
+  int *cnt = reinterpret_cast<int *>(smem);  // [ncell+1]
+  int *fillp = cnt + ncell + 1;              // [ncell]
+  __shared__ int s_part[256];
+  const fb_keypoint *k = kps + (size_t)b * kp_stride;
+  int32_t *cs = cell_start + (size_t)b * (ncell + 1);
+  int32_t *ci = cell_items + (size_t)b * kp_stride;
+  const int nk = n[b];
+  for (int i = tid; i <= ncell; i += nt) cnt[i] = 0;
+  __syncthreads();
+  auto cell_of = [&](const fb_keypoint &kp) -> int {
+    const int posX = (int)roundf((kp.x - g.min_x) * g.inv_w);  // PosInGrid, Frame.cc:548-558
+    const int posY = (int)roundf((kp.y - g.min_y) * g.inv_h);
+    if (posX < 0 || posX >= g.cols || posY < 0 || posY >= g.rows) return -1;
+    return posX * g.rows + posY;
+  };
+  for (int i = tid; i < nk; i += nt) {
+    const int c = cell_of(k[i]);
+    if (c >= 0) atomicAdd(&cnt[c], 1);
+  }
+  __syncthreads();
+  // exclusive scan over ncell counters: per-thread chunk sums, then scan of 256 partials
+  const int chunk = (ncell + nt - 1) / nt;
+  const int c0 = min(tid * chunk, ncell), c1 = min(c0 + chunk, ncell);
+  int s = 0;
+  for (int c = c0; c < c1; c++) s += cnt[c];
+  s_part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int t = 0; t < nt; t++) { const int v = s_part[t]; s_part[t] = run; run += v; }
+    cnt[ncell] = run;
+  }
+  __syncthreads();
+  int run = s_part[tid];
+  for (int c = c0; c < c1; c++) { const int v = cnt[c]; cnt[c] = run; fillp[c] = run; run += v; }
+  __syncthreads();
+  for (int i = tid; i < nk; i += nt) {
+    const int c = cell_of(k[i]);
+    if (c >= 0) ci[atomicAdd(&fillp[c], 1)] = i;
+  }
+  __syncthreads();
+  __threadfence_block();
+  for (int c = tid; c < ncell; c += nt) {  // insertion sort inside each cell
+    const int a0 = cnt[c], a1 = cnt[c + 1];
+    for (int i = a0 + 1; i < a1; i++) {
+      const int v = ci[i];
+      int j = i - 1;
+      while (j >= a0 && ci[j] > v) { ci[j + 1] = ci[j]; j--; }
+      ci[j + 1] = v;
+    }
+  }
+  for (int i = tid; i <= ncell; i += nt) cs[i] = cnt[i];
+}
+
+// Frame.cc:365-373: BirdPixel2BaseXY (Converter.cc:284-292) then BaseXY2CamXYZ (:312-318)
+struct BirdCamK {
+  int cols, rows;
+  double pixel2meter, rear;
+  float Tcb[12];
+};
+__global__ void k_bird_keys_to_cam(const fb_keypoint *__restrict__ kps, const int32_t *__restrict__ n, int kp_stride,
+                                   BirdCamK K, float *__restrict__ cam) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n[b]) return;
+  const fb_keypoint kp = kps[(size_t)b * kp_stride + i];
+  float p[3];
+  p[0] = (float)((K.rows / 2 - kp.y) * K.pixel2meter + K.rear);
+  p[1] = (float)((K.cols / 2 - kp.x) * K.pixel2meter);
+  p[2] = 0.f;
+  float o[3];
+  xform(K.Tcb, p, o);
+  float *dst = cam + ((size_t)b * kp_stride + i) * 3;
+  dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+}
+
+size_t match_lds_bytes(int cur_stride, int ncell, int extra_ints) {
+  return Carve(cur_stride, ncell).end + (size_t)extra_ints * 4;
+}
+
+int check_lds(size_t bytes, const char *what) {
+  if (bytes > 160 * 1024) {
+    fb::set_error("%s: frame too large for the LDS-staged matcher (%zu B > 160 KiB)", what, bytes);
+    return FB_ERR_CAPACITY;
+  }
+  return FB_OK;
+}
+
+template <typename K>
+int set_max_lds(K kernel, size_t bytes) {
+  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return FB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fb_descriptor_distance_dev(const uint8_t *d_a, const uint8_t *d_b, int n, int32_t *d_out, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(n >= 0 && (n == 0 || (d_a && d_b && d_out)));
+  if (n == 0) return FB_OK;
+  k_descriptor_distance<<<(n + 255) / 256, 256, 0, fb::as_stream(stream)>>>(
+      reinterpret_cast<const uint4 *>(d_a), reinterpret_cast<const uint4 *>(d_b), n, d_out);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+int fb_descriptor_distance(const uint8_t *a, const uint8_t *b, int n, int32_t *out) {
+  FB_TRY(fb::check_device());
+  FB_ARG(n >= 0);
+  fb::DevBuf da, db, dout;
+  FB_TRY(da.upload(a, (size_t)n * 32));
+  FB_TRY(db.upload(b, (size_t)n * 32));
+  FB_TRY(dout.alloc((size_t)n * 4));
+  FB_TRY(fb_descriptor_distance_dev(da.as<uint8_t>(), db.as<uint8_t>(), n, dout.as<int32_t>(), nullptr));
+  FB_HIP(hipDeviceSynchronize());
+  return dout.download(out, (size_t)n * 4);
+}
+
+int fb_grid_build_batch_dev(const fb_keypoint *d_keypoints, const int32_t *d_n, int batch, int kp_stride,
+                            const fb_grid_geom *geom, int32_t *d_cell_start, int32_t *d_cell_items, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(geom && batch >= 0 && kp_stride > 0 && geom->cols > 0 && geom->rows > 0);
+  if (batch == 0) return FB_OK;
+  const int ncell = geom->cols * geom->rows;
+  const size_t lds = (size_t)(2 * ncell + 1) * 4;
+  FB_TRY(check_lds(lds, "fb_grid_build_batch_dev"));
+  FB_TRY(set_max_lds(k_grid_build, lds));
+  k_grid_build<<<batch, 256, lds, fb::as_stream(stream)>>>(d_keypoints, d_n, kp_stride, *geom, d_cell_start, d_cell_items);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+int fb_bird_keys_to_cam_dev(const fb_keypoint *d_kps, const int32_t *d_n, int batch, int kp_stride, int bird_cols,
+                            int bird_rows, double pixel2meter, double rear_axle_to_center, const float *Tcb12,
+                            float *d_cam_xyz, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(Tcb12 && batch >= 0 && kp_stride > 0);
+  if (batch == 0) return FB_OK;
+  BirdCamK K;
+  K.cols = bird_cols; K.rows = bird_rows; K.pixel2meter = pixel2meter; K.rear = rear_axle_to_center;
+  memcpy(K.Tcb, Tcb12, sizeof(K.Tcb));
+  dim3 grid((kp_stride + 255) / 256, batch);
+  k_bird_keys_to_cam<<<grid, 256, 0, fb::as_stream(stream)>>>(d_kps, d_n, kp_stride, K, d_cam_xyz);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+int fb_match_projection_frame_dev(const fb_proj_frame_args *A, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(A && A->batch >= 0 && A->cur_stride > 0 && A->last_stride >= 0 && A->cur_stride < 65536);
+  if (A->batch == 0) return FB_OK;
+  const int ncell = A->grid.cols * A->grid.rows;
+  const size_t lds = match_lds_bytes(A->cur_stride, ncell, 2 * A->cur_stride + 2 * A->last_stride);
+  FB_TRY(check_lds(lds, "fb_match_projection_frame"));
+  FB_TRY(set_max_lds(k_proj_frame, lds));
+  k_proj_frame<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+int fb_match_projection_points_dev(const fb_proj_points_args *A, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(A && A->batch >= 0 && A->cur_stride > 0 && A->mp_stride >= 0 && A->cur_stride < 65536);
+  if (A->batch == 0) return FB_OK;
+  const int ncell = A->grid.cols * A->grid.rows;
+  const size_t lds = match_lds_bytes(A->cur_stride, ncell, 2 * A->cur_stride + 2 * A->mp_stride);
+  FB_TRY(check_lds(lds, "fb_match_projection_points"));
+  FB_TRY(set_max_lds(k_proj_points, lds));
+  k_proj_points<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+int fb_match_bird_mappoints_dev(const fb_bird_mp_args *A, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(A && A->batch >= 0 && A->cur_stride > 0 && A->ref_stride >= 0 && A->cur_stride < 65536);
+  if (A->batch == 0) return FB_OK;
+  const int ncell = A->grid.cols * A->grid.rows;
+  const size_t lds = match_lds_bytes(A->cur_stride, ncell, A->cur_stride);
+  FB_TRY(check_lds(lds, "fb_match_bird_mappoints"));
+  FB_TRY(set_max_lds(k_bird_mappoints, lds));
+  k_bird_mappoints<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+int fb_match_birdview_dev(const fb_birdview_args *A, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(A && A->batch >= 0 && A->cur_stride > 0 && A->ref_stride >= 0 && A->cur_stride < 65536);
+  if (A->batch == 0) return FB_OK;
+  const int ncell = A->grid.cols * A->grid.rows;
+  const size_t lds = match_lds_bytes(A->cur_stride, ncell, 2 * A->ref_stride);
+  FB_TRY(check_lds(lds, "fb_match_birdview"));
+  FB_TRY(set_max_lds(k_birdview, lds));
+  k_birdview<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+// ---- host-pointer drop-ins: upload, run the same kernels, download ----------------------
+#define UP(buf, field, bytes)                                        \
+  fb::DevBuf buf;                                                    \
+  if (H->field) { FB_TRY(buf.upload(H->field, (bytes))); D.field = buf.as<std::remove_pointer<decltype(D.field)>::type>(); }
+
+int fb_match_projection_frame(const fb_proj_frame_args *H) {
+  FB_TRY(fb::check_device());
+  FB_ARG(H && H->batch >= 0);
+  fb_proj_frame_args D = *H;
+  const size_t B = H->batch, cs = H->cur_stride, ls = H->last_stride, ncell = (size_t)H->grid.cols * H->grid.rows;
+  UP(b0, n_cur, B * 4) UP(b1, cur_kps, B * cs * sizeof(fb_keypoint)) UP(b2, cur_desc, B * cs * 32)
+  UP(b3, cur_cell_start, B * (ncell + 1) * 4) UP(b4, cur_cell_items, B * cs * 4) UP(b5, cur_blocked, B * cs)
+  UP(b6, cur_Tcw, B * 48) UP(b7, n_last, B * 4) UP(b8, last_valid, B * ls) UP(b9, last_obs_pos, B * ls)
+  UP(b10, last_xw, B * ls * 12) UP(b11, last_desc, B * ls * 32) UP(b12, last_octave, B * ls * 4)
+  UP(b13, last_angle, B * ls * 4)
+  fb::DevBuf o0, o1;
+  FB_TRY(o0.alloc(B * cs * 4));
+  FB_TRY(o1.alloc(B * 4));
+  D.match_cur_to_last = o0.as<int32_t>();
+  D.nmatches = o1.as<int32_t>();
+  FB_TRY(fb_match_projection_frame_dev(&D, nullptr));
+  FB_HIP(hipDeviceSynchronize());
+  FB_TRY(o0.download(H->match_cur_to_last, B * cs * 4));
+  return o1.download(H->nmatches, B * 4);
+}
+
+int fb_match_projection_points(const fb_proj_points_args *H) {
+  FB_TRY(fb::check_device());
+  FB_ARG(H && H->batch >= 0);
+  fb_proj_points_args D = *H;
+  const size_t B = H->batch, cs = H->cur_stride, ms = H->mp_stride, ncell = (size_t)H->grid.cols * H->grid.rows;
+  UP(b0, n_cur, B * 4) UP(b1, cur_kps, B * cs * sizeof(fb_keypoint)) UP(b2, cur_desc, B * cs * 32)
+  UP(b3, cur_cell_start, B * (ncell + 1) * 4) UP(b4, cur_cell_items, B * cs * 4) UP(b5, cur_blocked, B * cs)
+  UP(b6, n_mp, B * 4) UP(b7, mp_track, B * ms) UP(b8, mp_obs_pos, B * ms) UP(b9, mp_proj, B * ms * 8)
+  UP(b10, mp_level, B * ms * 4) UP(b11, mp_view_cos, B * ms * 4) UP(b12, mp_desc, B * ms * 32)
+  fb::DevBuf o0, o1;
+  FB_TRY(o0.alloc(B * cs * 4));
+  FB_TRY(o1.alloc(B * 4));
+  D.match_cur_to_mp = o0.as<int32_t>();
+  D.nmatches = o1.as<int32_t>();
+  FB_TRY(fb_match_projection_points_dev(&D, nullptr));
+  FB_HIP(hipDeviceSynchronize());
+  FB_TRY(o0.download(H->match_cur_to_mp, B * cs * 4));
+  return o1.download(H->nmatches, B * 4);
+}
+
+int fb_match_bird_mappoints(const fb_bird_mp_args *H) {
+  FB_TRY(fb::check_device());
+  FB_ARG(H && H->batch >= 0);
+  fb_bird_mp_args D = *H;
+  const size_t B = H->batch, cs = H->cur_stride, rs = H->ref_stride, ncell = (size_t)H->grid.cols * H->grid.rows;
+  UP(b0, n_cur, B * 4) UP(b1, cur_kps, B * cs * sizeof(fb_keypoint)) UP(b2, cur_desc, B * cs * 32)
+  UP(b3, cur_cam_xyz, B * cs * 12) UP(b4, cur_cell_start, B * (ncell + 1) * 4) UP(b5, cur_cell_items, B * cs * 4)
+  UP(b6, cur_Tcw, B * 48) UP(b7, n_ref, B * 4) UP(b8, ref_valid, B * rs) UP(b9, ref_xw, B * rs * 12)
+  UP(b10, ref_desc, B * rs * 32)
+  fb::DevBuf o0, o1;
+  FB_TRY(o0.upload(H->match_cur_to_ref, B * cs * 4));  // in/out
+  FB_TRY(o1.alloc(B * 4));
+  D.match_cur_to_ref = o0.as<int32_t>();
+  D.ninliers = o1.as<int32_t>();
+  FB_TRY(fb_match_bird_mappoints_dev(&D, nullptr));
+  FB_HIP(hipDeviceSynchronize());
+  FB_TRY(o0.download(H->match_cur_to_ref, B * cs * 4));
+  return o1.download(H->ninliers, B * 4);
+}
+
+int fb_match_birdview(const fb_birdview_args *H) {
+  FB_TRY(fb::check_device());
+  FB_ARG(H && H->batch >= 0);
+  fb_birdview_args D = *H;
+  const size_t B = H->batch, cs = H->cur_stride, rs = H->ref_stride, ncell = (size_t)H->grid.cols * H->grid.rows;
+  UP(b0, n_cur, B * 4) UP(b1, cur_kps, B * cs * sizeof(fb_keypoint)) UP(b2, cur_desc, B * cs * 32)
+  UP(b3, cur_cell_start, B * (ncell + 1) * 4) UP(b4, cur_cell_items, B * cs * 4) UP(b5, n_ref, B * 4)
+  UP(b6, ref_kps, B * rs * sizeof(fb_keypoint)) UP(b7, ref_desc, B * rs * 32)
+  fb::DevBuf o0, o1, o2, o3;
+  FB_TRY(o0.alloc(B * rs * 4));
+  FB_TRY(o1.alloc(B * rs * 4));
+  FB_TRY(o2.alloc(B * 4));
+  FB_TRY(o3.alloc(B * 4));
+  D.match_ref_to_cur = o0.as<int32_t>();
+  D.match_dist = o1.as<int32_t>();
+  D.nmatches = o2.as<int32_t>();
+  D.n_dmatches = o3.as<int32_t>();
+  FB_TRY(fb_match_birdview_dev(&D, nullptr));
+  FB_HIP(hipDeviceSynchronize());
+  FB_TRY(o0.download(H->match_ref_to_cur, B * rs * 4));
+  FB_TRY(o1.download(H->match_dist, B * rs * 4));
+  FB_TRY(o2.download(H->nmatches, B * 4));
+  return o3.download(H->n_dmatches, B * 4);
+}
+
+}  // extern "C"

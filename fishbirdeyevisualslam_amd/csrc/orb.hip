@@ -1,0 +1,872 @@
+// orb.hip -- ORBextractor as CDNA4 kernels (gfx950), batched over equally sized images.
+//
+// Replaces (reference file:line):
+//   ORBextractor::ORBextractor        src/ORBextractor.cc:410-470   (host tables)
+//   ORBextractor::ComputePyramid      :1107-1132   -> k_resize (one launch per level >= 1)
+//   ComputeKeyPointsOctTree cell loop :765-832     -> k_fast   (one workgroup per 30-px cell,
+//        cv::FAST 9-16 score + 3x3 NMS + ini/min threshold fallback on an LDS tile)
+//   DistributeOctTree / DivideNode    :481-763     -> k_octree (one workgroup per image level)
+//   IC_Angle / computeOrbDescriptor   :77-147, GaussianBlur :1086 -> k_describe (one wave per
+//        keypoint: 43x43 raw patch in LDS -> moments, separable 7x7 blur, 256 rBRIEF tests)
+//   ORBextractor::operator()          :1043-1105   -> fb_orb_extract*
+//
+// HBM layout per image: level 0 is the caller's image (never copied); levels 1..n-1 live in
+// one pitched buffer (pitch % 64 == 0).  The blurred image is never materialised: each
+// keypoint's wave blurs its own 37x37 footprint out of LDS.  FAST candidates are packed
+// x | y<<12 | score<<24 into a per-level array sized for the NMS worst case, so no kernel
+// can overflow a buffer.
+//
+// OpenCV semantics (not vendored in the reference -> "parity unpinned") are
+// those of oracle/orb_oracle.cpp; this file must agree with it bit for bit.
+#include "fb_common.h"
+
+namespace {
+
+constexpr int EDGE_THRESHOLD = 19;  // ORBextractor.cc:74
+constexpr int HALF_PATCH = 15;      // :73
+constexpr int PATCH_SIZE = 31;      // :72
+constexpr int BORDER = EDGE_THRESHOLD - 3;  // minBorderX/Y, :773
+
+__constant__ int c_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+struct LevelInfo {
+  int w, h, pitch;
+  long long off;  // byte offset of the level inside one image's pyramid buffer (levels >= 1)
+  int nCols, nRows, wCell, hCell, cellBase;
+  int N;                 // mnFeaturesPerLevel
+  long long candBase;    // element offset into one image's candidate array
+  int candCap;
+  int outBase, outCap;   // element offset / capacity in one image's per-level keypoint array
+  int nIni;
+  float hX;
+  float scale;
+  int patchSize;         // (int)(PATCH_SIZE*scale), :836
+};
+
+struct OrbK {
+  int nlevels, iniTh, minTh, totalCells, outStride, capOut;
+  long long pyrStride;   // bytes per image of levels >= 1
+  long long candStride;  // candidates per image
+  int umax[16];
+  LevelInfo L[FB_MAX_LEVELS];
+};
+
+struct ResizeTabs {  // per level >= 1, device pointers
+  const int *xofs;
+  const short *ialpha;
+  const int *yofs;
+  const short *ibeta;
+};
+
+// ------------------------------------------------------------------------------------------
+// cv::resize INTER_LINEAR, 8U, 11-bit fixed point (oracle: resize_linear_u8). 4 px per lane.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src0, long long srcImgStride, int sw,
+                                                int sh, int spitch, uint8_t *__restrict__ dst0, long long dstImgStride,
+                                                int dw, int dh, int dpitch, ResizeTabs tb) {
+  const int b = blockIdx.z;
+  const int dy = blockIdx.y * blockDim.y + threadIdx.y;
+  const int dx4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (dy >= dh || dx4 >= dpitch) return;
+  const uint8_t *src = src0 + (long long)b * srcImgStride;
+  uint8_t *dst = dst0 + (long long)b * dstImgStride;
+  int sy0 = tb.yofs[dy], sy1 = sy0 + 1;
+  sy0 = sy0 >= 0 ? (sy0 < sh ? sy0 : sh - 1) : 0;
+  sy1 = sy1 >= 0 ? (sy1 < sh ? sy1 : sh - 1) : 0;
+  const int b0 = tb.ibeta[dy * 2], b1 = tb.ibeta[dy * 2 + 1];
+  const uint8_t *r0p = src + (long long)sy0 * spitch, *r1p = src + (long long)sy1 * spitch;
+  uint32_t packed = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int dx = dx4 + k;
+    int v = 0;
+    if (dx < dw) {
+      const int sx = tb.xofs[dx];
+      const int sx1 = min(sx + 1, sw - 1);
+      const int a0 = tb.ialpha[dx * 2], a1 = tb.ialpha[dx * 2 + 1];
+      const int r0 = r0p[sx] * a0 + r0p[sx1] * a1;
+      const int r1 = r1p[sx] * a0 + r1p[sx1] * a1;
+      v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+      v = min(max(v, 0), 255);
+    }
+    packed |= (uint32_t)v << (8 * k);
+  }
+  *reinterpret_cast<uint32_t *>(dst + (long long)dy * dpitch + dx4) = packed;
+}
+
+// ------------------------------------------------------------------------------------------
+// FAST-9-16 score = max over the 16 arcs of 9 of min(d) (and of min(-d)), minus 1
+// (cv::cornerScore<16>); the pixel is a corner at threshold t iff score >= t.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_score16(const uint8_t *__restrict__ c, int tp) {
+  const int v = c[0];
+  int d[16];
+  d[0] = v - c[3 * tp];      d[1] = v - c[3 * tp + 1];   d[2] = v - c[2 * tp + 2];   d[3] = v - c[tp + 3];
+  d[4] = v - c[3];           d[5] = v - c[-tp + 3];      d[6] = v - c[-2 * tp + 2];  d[7] = v - c[-3 * tp + 1];
+  d[8] = v - c[-3 * tp];     d[9] = v - c[-3 * tp - 1];  d[10] = v - c[-2 * tp - 2]; d[11] = v - c[-tp - 3];
+  d[12] = v - c[-3];         d[13] = v - c[tp - 3];      d[14] = v - c[2 * tp - 2];  d[15] = v - c[3 * tp - 1];
+  int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { mn2[i] = min(d[i], d[(i + 1) & 15]); mx2[i] = max(d[i], d[(i + 1) & 15]); }
+#pragma unroll
+  for (int i = 0; i < 16; i++) { mn4[i] = min(mn2[i], mn2[(i + 2) & 15]); mx4[i] = max(mx2[i], mx2[(i + 2) & 15]); }
+  int A = -256, Bm = 256;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int mn9 = min(min(mn4[i], mn4[(i + 4) & 15]), d[(i + 8) & 15]);
+    const int mx9 = max(max(mx4[i], mx4[(i + 4) & 15]), d[(i + 8) & 15]);
+    A = max(A, mn9);
+    Bm = min(Bm, mx9);
+  }
+  return max(A, -Bm) - 1;
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v) {  // inclusive scan over the 64 lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o, 64);
+    if ((int)(threadIdx.x & 63) >= o) v += t;
+  }
+  return v;
+}
+
+// exclusive scan of one int per thread over a 256-thread block; *total = block sum
+__device__ __forceinline__ int block_excl_scan256(int v, int *s_w /*[4]*/, int *total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int inc = wave_incl_scan(v);
+  __syncthreads();
+  if (lane == 63) s_w[wv] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < wv; i++) base += s_w[i];
+  *total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  return base + inc - v;
+}
+
+constexpr int FAST_MAX_TILE = 72;  // cell window <= wCell+6 <= 65 px, +3 alignment slack
+
+__global__ __launch_bounds__(256) void k_fast(OrbK K, const uint8_t *__restrict__ img0, long long imgStride, int pitch0,
+                                              const uint8_t *__restrict__ pyr, uint32_t *__restrict__ cand,
+                                              int *__restrict__ candCount) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[FAST_MAX_TILE * FAST_MAX_TILE];
+  __shared__ uint8_t sc[FAST_MAX_TILE * FAST_MAX_TILE];
+  __shared__ int s_w[4], s_base;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  int cell = blockIdx.x, l = 0;
+  while (l + 1 < K.nlevels && cell >= K.L[l + 1].cellBase) l++;
+  const LevelInfo &Lv = K.L[l];
+  cell -= Lv.cellBase;
+  const int ci = cell / Lv.nCols, cj = cell % Lv.nCols;
+  const int maxBX = Lv.w - BORDER, maxBY = Lv.h - BORDER;
+  const int x0 = BORDER + cj * Lv.wCell, y0 = BORDER + ci * Lv.hCell;
+  if (y0 >= maxBY - 3 || x0 >= maxBX - 6) return;  // ORBextractor.cc:794,802
+  const int x1 = min(x0 + Lv.wCell + 6, maxBX), y1 = min(y0 + Lv.hCell + 6, maxBY);
+  const int cw = x1 - x0, ch = y1 - y0;
+  if (cw < 7 || ch < 7) return;
+  const uint8_t *img;
+  int pitch;
+  if (l == 0) { img = img0 + (long long)b * imgStride; pitch = pitch0; }
+  else { img = pyr + (long long)b * K.pyrStride + Lv.off; pitch = Lv.pitch; }
+  // stage the window: tile column 0 = image column xa (4-byte aligned when the image allows it)
+  const bool aligned = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch) & 3) == 0;
+  const int xa = aligned ? (x0 & ~3) : x0;
+  const int tp = aligned ? (((x1 - xa) + 3) & ~3) : cw;  // tile pitch
+  const int ox = x0 - xa;
+  if (aligned) {
+    const int wpr = tp >> 2;
+    for (int i = tid; i < wpr * ch; i += 256) {
+      const int yy = i / wpr, xw = i - yy * wpr;
+      *reinterpret_cast<uint32_t *>(&tile[yy * tp + xw * 4]) =
+          *reinterpret_cast<const uint32_t *>(img + (long long)(y0 + yy) * pitch + xa + xw * 4);
+    }
+  } else {
+    for (int i = tid; i < cw * ch; i += 256) {
+      const int yy = i / cw, xx = i - yy * cw;
+      tile[yy * tp + xx] = img[(long long)(y0 + yy) * pitch + x0 + xx];
+    }
+  }
+  for (int i = tid; i < tp * ch; i += 256) sc[i] = 0;
+  __syncthreads();
+  const int dwid = cw - 6, dhei = ch - 6, npix = dwid * dhei;
+  for (int p = tid; p < npix; p += 256) {
+    const int yy = p / dwid + 3, xx = p - (yy - 3) * dwid + 3;
+    const int s = fast_score16(&tile[yy * tp + ox + xx], tp);
+    sc[yy * tp + ox + xx] = (uint8_t)max(s, 0);
+  }
+  __syncthreads();
+  // raster-ordered emission: thread t owns raster positions [t*chunk, (t+1)*chunk)
+  const int chunk = (npix + 255) / 256;
+  const int p0 = min(tid * chunk, npix), p1 = min(p0 + chunk, npix);
+  for (int pass = 0; pass < 2; pass++) {
+    const int T = pass == 0 ? K.iniTh : K.minTh;
+    unsigned long long keep = 0;  // chunk <= 64 always (npix <= 60*60, 256 threads -> <= 15)
+    int cnt = 0;
+    for (int p = p0; p < p1; p++) {
+      const int yy = p / dwid + 3, xx = p - (yy - 3) * dwid + 3;
+      const uint8_t *q = &sc[yy * tp + ox + xx];
+      const int s = q[0];
+      if (s < T) continue;
+      // neighbours below T count as 0 (not corners in this cv::FAST call); the rim holds 0
+      int m = 0;
+#define NB(o) { const int n_ = q[o]; m = max(m, n_ >= T ? n_ : 0); }
+      NB(-1) NB(1) NB(-tp - 1) NB(-tp) NB(-tp + 1) NB(tp - 1) NB(tp) NB(tp + 1)
+#undef NB
+      if (s > m) { keep |= 1ull << (p - p0); cnt++; }
+    }
+    int total;
+    const int ex = block_excl_scan256(cnt, s_w, &total);
+    if (total == 0) continue;  // uniform: retry with minThFAST (ORBextractor.cc:811-816)
+    if (tid == 0) s_base = atomicAdd(&candCount[b * K.nlevels + l], total);
+    __syncthreads();
+    uint32_t *out = cand + (long long)b * K.candStride + Lv.candBase + s_base + ex;
+    for (int p = p0; p < p1; p++) {
+      if (!((keep >> (p - p0)) & 1)) continue;
+      const int yy = p / dwid + 3, xx = p - (yy - 3) * dwid + 3;
+      *out++ = (uint32_t)(x0 + xx) | ((uint32_t)(y0 + yy) << 12) | ((uint32_t)sc[yy * tp + ox + xx] << 24);
+    }
+    break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// DistributeOctTree.  The std::list of the reference is an ordered array here: every node is
+// pushed to the FRONT when created, so list order == descending creation order (initial nodes
+// last), which is also the "pointer" order used to break ties in the (size,pointer) sort
+// (modelled as creation sequence in the oracle).  Each round: count keypoints per child
+// quadrant (LDS atomics), rebuild the list with block scans, remap the keypoints.
+// ------------------------------------------------------------------------------------------
+struct ONode {
+  short x0, y0, x1, y1;
+  int cnt;
+};
+
+__device__ __forceinline__ int quadrant(const ONode &n, int rx, int ry) {
+  const int halfX = (int)ceilf((float)(n.x1 - n.x0) / 2), halfY = (int)ceilf((float)(n.y1 - n.y0) / 2);
+  const int mx = n.x0 + halfX, my = n.y0 + halfY;
+  return (rx < mx ? 0 : 1) + (ry < my ? 0 : 2);  // n1=0 (UL), n2=1 (UR), n3=2 (BL), n4=3 (BR)
+}
+
+__device__ __forceinline__ ONode child_of(const ONode &n, int q, int cnt) {
+  const int halfX = (int)ceilf((float)(n.x1 - n.x0) / 2), halfY = (int)ceilf((float)(n.y1 - n.y0) / 2);
+  const int mx = n.x0 + halfX, my = n.y0 + halfY;
+  ONode c;
+  c.x0 = (q & 1) ? mx : n.x0;
+  c.x1 = (q & 1) ? n.x1 : mx;
+  c.y0 = (q & 2) ? my : n.y0;
+  c.y1 = (q & 2) ? n.y1 : my;
+  c.cnt = cnt;
+  return c;
+}
+
+__global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restrict__ cand,
+                                                const int *__restrict__ candCount, uint16_t *__restrict__ nodeOf,
+                                                uint32_t *__restrict__ lvlOut, int *__restrict__ lvlCount, int maxNodes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const LevelInfo &Lv = K.L[l];
+  const int M = maxNodes;
+  ONode *listA = reinterpret_cast<ONode *>(smem);        // [M]
+  ONode *listB = listA + M;                              // [M]
+  int *ccnt = reinterpret_cast<int *>(listB + M);        // [M][4] child counts
+  unsigned short *cpos = reinterpret_cast<unsigned short *>(ccnt + 4 * M);  // [M][4] new position of child
+  unsigned short *npos = cpos + 4 * M;                   // [M] new position of a surviving node
+  unsigned short *order = npos + M;                      // [M] final phase: rank -> position
+  unsigned char *split = reinterpret_cast<unsigned char *>(order + M);  // [M] node is split this round
+  unsigned long long *best = reinterpret_cast<unsigned long long *>(smem + (((size_t)(split + M - smem)) + 7 & ~(size_t)7));
+  __shared__ int s_w[4], s_S, s_nexp, s_jstar;
+  const int n = candCount[b * K.nlevels + l];
+  const uint32_t *cd = cand + (long long)b * K.candStride + Lv.candBase;
+  uint16_t *nof = nodeOf + (long long)b * K.candStride + Lv.candBase;
+  int *outCount = lvlCount + b * K.nlevels + l;
+  uint32_t *out = lvlOut + (long long)b * K.outStride + Lv.outBase;
+  if (n == 0 || Lv.nIni < 1) { if (tid == 0) *outCount = 0; return; }
+  const int N = Lv.N;
+  const int Hh = Lv.h - 2 * BORDER;
+  // ---- initial nodes (ORBextractor.cc:543-593)
+  for (int i = tid; i < Lv.nIni; i += 256) {
+    ONode nd;
+    nd.x0 = (short)(int)(Lv.hX * (float)i);
+    nd.x1 = (short)(int)(Lv.hX * (float)(i + 1));
+    nd.y0 = 0; nd.y1 = (short)Hh; nd.cnt = 0;
+    listB[i] = nd;
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) {
+    const int rx = (int)(cd[k] & 0xFFF) - BORDER;
+    int idx = (int)((float)rx / Lv.hX);
+    idx = min(idx, Lv.nIni - 1);
+    nof[k] = (uint16_t)idx;
+    atomicAdd(&listB[idx].cnt, 1);
+  }
+  __syncthreads();
+  if (tid == 0) {  // drop empty initial nodes, keep order
+    int S = 0;
+    for (int i = 0; i < Lv.nIni; i++) {
+      npos[i] = (unsigned short)S;
+      if (listB[i].cnt > 0) listA[S++] = listB[i];
+    }
+    s_S = S;
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) nof[k] = npos[nof[k]];
+  __syncthreads();
+  ONode *cur = listA, *nxt = listB;
+  int S = s_S;
+  bool finalPhase = false;
+  for (int guard = 0; guard < 64; guard++) {
+    const int prevSize = S;
+    // ---- count children of every expandable node
+    for (int i = tid; i < 4 * S; i += 256) ccnt[i] = 0;
+    __syncthreads();
+    for (int k = tid; k < n; k += 256) {
+      const int p = nof[k];
+      const ONode nd = cur[p];
+      if (nd.cnt > 1) {
+        const uint32_t c = cd[k];
+        atomicAdd(&ccnt[4 * p + quadrant(nd, (int)(c & 0xFFF) - BORDER, (int)((c >> 12) & 0xFFF) - BORDER)], 1);
+      }
+    }
+    __syncthreads();
+    // ---- choose the nodes to split
+    if (!finalPhase) {
+      for (int p = tid; p < S; p += 256) split[p] = cur[p].cnt > 1;
+    } else {
+      // sort expandable nodes by (count desc, list position asc) == (size, pointer) sort walked
+      // from the back (ORBextractor.cc:684-686); split in that order until the list holds N
+      for (int p = tid; p < S; p += 256) {
+        split[p] = 0;
+        const int c = cur[p].cnt;
+        if (c > 1) {
+          int rank = 0;
+          for (int j = 0; j < S; j++) {
+            const int cj = cur[j].cnt;
+            if (cj > 1 && (cj > c || (cj == c && j < p))) rank++;
+          }
+          order[rank] = (unsigned short)p;
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int sz = S, j = 0;
+        const int C = s_nexp;
+        for (; j < C; j++) {
+          const int p = order[j];
+          const int kk = (ccnt[4 * p] > 0) + (ccnt[4 * p + 1] > 0) + (ccnt[4 * p + 2] > 0) + (ccnt[4 * p + 3] > 0);
+          sz += kk - 1;
+          split[p] = 1;
+          if (sz >= N) { j++; break; }
+        }
+        s_jstar = j;  // number of nodes split
+      }
+    }
+    __syncthreads();
+    // ---- new list: children of split nodes go to the front, most recently created first
+    // phase 1 : creation order = list order of parents, q = 0..3  -> position = reverse of it
+    // final   : creation order = rank order of parents,  q = 0..3
+    const int per = (S + 255) / 256;
+    const int a0 = min(tid * per, S), a1 = min(a0 + per, S);
+    int myKids = 0, myKeep = 0;
+    if (!finalPhase) {
+      for (int p = a0; p < a1; p++) {
+        if (split[p]) myKids += (ccnt[4 * p] > 0) + (ccnt[4 * p + 1] > 0) + (ccnt[4 * p + 2] > 0) + (ccnt[4 * p + 3] > 0);
+        else myKeep++;
+      }
+    } else {
+      const int J = s_jstar;
+      const int perj = (J + 255) / 256;
+      const int r0 = min(tid * perj, J), r1 = min(r0 + perj, J);
+      for (int r = r0; r < r1; r++) {
+        const int p = order[r];
+        myKids += (ccnt[4 * p] > 0) + (ccnt[4 * p + 1] > 0) + (ccnt[4 * p + 2] > 0) + (ccnt[4 * p + 3] > 0);
+      }
+      for (int p = a0; p < a1; p++) if (!split[p]) myKeep++;
+    }
+    int totalKids, totalKeep;
+    const int kidsBefore = block_excl_scan256(myKids, s_w, &totalKids);
+    const int keepBefore = block_excl_scan256(myKeep, s_w, &totalKeep);
+    // children created before mine: kidsBefore -> my first child has creation index kidsBefore,
+    // list position = totalKids-1-creationIndex
+    {
+      int ci = kidsBefore, kp = totalKids + keepBefore;
+      if (!finalPhase) {
+        for (int p = a0; p < a1; p++) {
+          if (split[p]) {
+            for (int q = 0; q < 4; q++)
+              if (ccnt[4 * p + q] > 0) {
+                const int pos = totalKids - 1 - ci++;
+                cpos[4 * p + q] = (unsigned short)pos;
+                nxt[pos] = child_of(cur[p], q, ccnt[4 * p + q]);
+              }
+          } else {
+            npos[p] = (unsigned short)kp;
+            nxt[kp++] = cur[p];
+          }
+        }
+      } else {
+        const int J = s_jstar;
+        const int perj = (J + 255) / 256;
+        const int r0 = min(tid * perj, J), r1 = min(r0 + perj, J);
+        for (int r = r0; r < r1; r++) {
+          const int p = order[r];
+          for (int q = 0; q < 4; q++)
+            if (ccnt[4 * p + q] > 0) {
+              const int pos = totalKids - 1 - ci++;
+              cpos[4 * p + q] = (unsigned short)pos;
+              nxt[pos] = child_of(cur[p], q, ccnt[4 * p + q]);
+            }
+        }
+        for (int p = a0; p < a1; p++)
+          if (!split[p]) { npos[p] = (unsigned short)kp; nxt[kp++] = cur[p]; }
+      }
+    }
+    const int Snew = totalKids + totalKeep;
+    __syncthreads();
+    // ---- remap keypoints
+    for (int k = tid; k < n; k += 256) {
+      const int p = nof[k];
+      if (split[p]) {
+        const uint32_t c = cd[k];
+        nof[k] = cpos[4 * p + quadrant(cur[p], (int)(c & 0xFFF) - BORDER, (int)((c >> 12) & 0xFFF) - BORDER)];
+      } else nof[k] = npos[p];
+    }
+    // nToExpand of the new list = children with more than one keypoint
+    int myExp = 0;
+    {
+      const int pern = (Snew + 255) / 256;
+      const int n0 = min(tid * pern, Snew), n1 = min(n0 + pern, Snew);
+      for (int p = n0; p < n1; p++) myExp += (p < totalKids && nxt[p].cnt > 1);
+    }
+    int nToExpand;
+    block_excl_scan256(myExp, s_w, &nToExpand);
+    if (tid == 0) s_nexp = nToExpand;
+    __syncthreads();
+    ONode *t = cur; cur = nxt; nxt = t;
+    S = Snew;
+    // ---- termination (ORBextractor.cc:669-739)
+    if (S >= N || S == prevSize) break;
+    if (!finalPhase) {
+      if (S + nToExpand * 3 > N) finalPhase = true;
+    }
+  }
+  // ---- best keypoint per node: max response, first in vToDistributeKeys order on ties
+  for (int p = tid; p < S; p += 256) best[p] = 0ull;
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) {
+    const uint32_t c = cd[k];
+    const int x = c & 0xFFF, y = (c >> 12) & 0xFFF, r = c >> 24;
+    const int cellI = (y - EDGE_THRESHOLD) / Lv.hCell, cellJ = (x - EDGE_THRESHOLD) / Lv.wCell;
+    const int dwid = min(Lv.wCell, Lv.w - 2 * EDGE_THRESHOLD - cellJ * Lv.wCell);
+    const int inCell = (y - EDGE_THRESHOLD - cellI * Lv.hCell) * dwid + (x - EDGE_THRESHOLD - cellJ * Lv.wCell);
+    const unsigned orderKey = (unsigned)(cellI * Lv.nCols + cellJ) * 4096u + (unsigned)inCell;  // < 2^24
+    const unsigned long long key = ((unsigned long long)r << 56) | ((unsigned long long)(0xFFFFFFu - orderKey) << 32) | (unsigned)k;
+    atomicMax(&best[nof[k]], key);
+  }
+  __syncthreads();
+  for (int p = tid; p < S; p += 256) out[p] = cd[(unsigned)(best[p] & 0xFFFFFFFFull)];
+  if (tid == 0) *outCount = S;
+}
+
+// ------------------------------------------------------------------------------------------
+// One wave per keypoint: orientation (IC_Angle), 7x7 Gaussian blur of the 37x37 footprint,
+// 256 steered BRIEF tests, and the final cv::KeyPoint record.
+// ------------------------------------------------------------------------------------------
+constexpr int RP = 43, RPITCH = 44;  // raw patch 43x43 (radius 21)
+constexpr int BP = 37;               // blurred footprint (radius 18)
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i;
+}
+
+__global__ __launch_bounds__(64) void k_describe(OrbK K, const uint8_t *__restrict__ img0, long long imgStride,
+                                                 int pitch0, const uint8_t *__restrict__ pyr,
+                                                 const uint32_t *__restrict__ lvlOut, const int *__restrict__ lvlCount,
+                                                 fb_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
+                                                 int32_t *__restrict__ nOut) {
+  __shared__ uint8_t raw[RP * RPITCH];
+  __shared__ unsigned short hb[RP * BP];
+  __shared__ uint8_t bl[BP * BP + 3];
+  __shared__ __attribute__((aligned(16))) uint8_t dbytes[32];
+  const int b = blockIdx.y, lane = threadIdx.x;
+  int idx = blockIdx.x, l = 0, total = 0;
+  const int *cnts = lvlCount + b * K.nlevels;
+  int myl = -1, myidx = 0;
+  for (l = 0; l < K.nlevels; l++) {
+    const int c = cnts[l];
+    if (myl < 0 && idx < total + c) { myl = l; myidx = idx - total; }
+    total += c;
+  }
+  if (blockIdx.x == 0 && lane == 0) nOut[b] = min(total, K.capOut);
+  if (myl < 0 || idx >= K.capOut) return;
+  const LevelInfo &Lv = K.L[myl];
+  const uint32_t rec = lvlOut[(long long)b * K.outStride + Lv.outBase + myidx];
+  const int cx = rec & 0xFFF, cy = (rec >> 12) & 0xFFF, resp = rec >> 24;
+  const uint8_t *img;
+  int pitch;
+  if (myl == 0) { img = img0 + (long long)b * imgStride; pitch = pitch0; }
+  else { img = pyr + (long long)b * K.pyrStride + Lv.off; pitch = Lv.pitch; }
+  for (int i = lane; i < RP * RP; i += 64) {
+    const int yy = i / RP, xx = i - yy * RP;
+    const int sx = reflect101(cx - 21 + xx, Lv.w), sy = reflect101(cy - 21 + yy, Lv.h);
+    raw[yy * RPITCH + xx] = img[(long long)sy * pitch + sx];
+  }
+  __syncthreads();
+  // IC_Angle (ORBextractor.cc:77-104): lane v+15 sums row v of the circular patch
+  int m10 = 0, m01 = 0;
+  if (lane < 31) {
+    const int v = lane - 15, dmax = K.umax[v < 0 ? -v : v];
+    const uint8_t *row = &raw[(21 + v) * RPITCH + 21];
+    int rs = 0;
+    for (int u = -dmax; u <= dmax; u++) { const int val = row[u]; m10 += u * val; rs += val; }
+    m01 = v * rs;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
+  const float angle = fb_fast_atan2((float)m01, (float)m10);
+  // separable blur, integer kernel {18,34,49,55,49,34,18}, (sum + 2^15) >> 16 (oracle gaussian_blur7)
+  for (int i = lane; i < RP * BP; i += 64) {
+    const int yy = i / BP, xx = i - yy * BP;
+    const uint8_t *r = &raw[yy * RPITCH + xx];
+    hb[i] = (unsigned short)(18 * (r[0] + r[6]) + 34 * (r[1] + r[5]) + 49 * (r[2] + r[4]) + 55 * r[3]);
+  }
+  __syncthreads();
+  for (int i = lane; i < BP * BP; i += 64) {
+    const int yy = i / BP, xx = i - yy * BP;
+    const unsigned short *c = &hb[yy * BP + xx];
+    const int s = 18 * ((int)c[0] + c[6 * BP]) + 34 * ((int)c[BP] + c[5 * BP]) + 49 * ((int)c[2 * BP] + c[4 * BP]) + 55 * (int)c[3 * BP];
+    bl[i] = (uint8_t)min((s + (1 << 15)) >> 16, 255);
+  }
+  __syncthreads();
+  // computeOrbDescriptor (ORBextractor.cc:107-147): lane computes tests 4*lane .. 4*lane+3
+  const float factorPI = 0x1.1df46ap-6f;
+  float sa, ca;
+  fb_sincos_f(angle * factorPI, &sa, &ca);
+  const float a = ca, bb = sa;
+  int nib = 0;
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int *pp = &c_pattern[(lane * 4 + t) * 4];
+    const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
+    const int t0 = bl[(18 + fb_cvround(x0 * bb + y0 * a)) * BP + 18 + fb_cvround(x0 * a - y0 * bb)];
+    const int t1 = bl[(18 + fb_cvround(x1 * bb + y1 * a)) * BP + 18 + fb_cvround(x1 * a - y1 * bb)];
+    nib |= (t0 < t1) << t;
+  }
+  const int hi = __shfl_down(nib, 1, 64);
+  if ((lane & 1) == 0) dbytes[lane >> 1] = (uint8_t)(nib | (hi << 4));
+  __syncthreads();
+  const long long o = (long long)b * K.capOut + idx;
+  if (lane < 2) reinterpret_cast<uint4 *>(desc + o * 32)[lane] = reinterpret_cast<const uint4 *>(dbytes)[lane];
+  if (lane == 0) {
+    fb_keypoint kp;
+    kp.x = (float)cx;
+    kp.y = (float)cy;
+    if (myl != 0) { kp.x *= Lv.scale; kp.y *= Lv.scale; }  // ORBextractor.cc:1095-1101
+    kp.size = (float)Lv.patchSize;
+    kp.angle = angle;
+    kp.response = (float)resp;
+    kp.octave = myl;
+    kps[o] = kp;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct fb_orb {
+  fb_orb_params p;
+  fb_orb_tables t;
+  // workspace, valid for (w, h, batchCap)
+  int w = 0, h = 0, batchCap = 0;
+  OrbK K;
+  int maxNodes = 0;
+  size_t octreeLds = 0;
+  fb::DevBuf pyr, cand, nodeOf, counts, lvlOut, tabs;
+  ResizeTabs rt[FB_MAX_LEVELS];
+  // last call (for fb_orb_get_level)
+  const uint8_t *lastImg = nullptr;
+  long long lastImgStride = 0;
+  int lastPitch0 = 0;
+  fb::DevBuf ownedImg;
+};
+
+namespace {
+
+void make_tables(const fb_orb_params &p, fb_orb_tables &t) {  // ORBextractor.cc:410-470
+  memset(&t, 0, sizeof(t));
+  const int nl = p.nlevels;
+  t.scale_factor[0] = 1.0f;
+  t.level_sigma2[0] = 1.0f;
+  for (int i = 1; i < nl; i++) {
+    t.scale_factor[i] = t.scale_factor[i - 1] * p.scale_factor;
+    t.level_sigma2[i] = t.scale_factor[i] * t.scale_factor[i];
+  }
+  for (int i = 0; i < nl; i++) {
+    t.inv_scale_factor[i] = 1.0f / t.scale_factor[i];
+    t.inv_level_sigma2[i] = 1.0f / t.level_sigma2[i];
+  }
+  float factor = 1.0f / p.scale_factor;
+  float nDesired = p.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nl));
+  int sum = 0;
+  for (int l = 0; l < nl - 1; l++) {
+    t.features_per_level[l] = fb_cvround(nDesired);
+    sum += t.features_per_level[l];
+    nDesired *= factor;
+  }
+  t.features_per_level[nl - 1] = std::max(p.nfeatures - sum, 0);
+  int umax[HALF_PATCH + 2] = {0};
+  int v, v0;
+  const int vmax = fb_cvfloor(HALF_PATCH * sqrtf(2.f) / 2 + 1);
+  const int vmin = fb_cvceil(HALF_PATCH * sqrtf(2.f) / 2);
+  const double hp2 = HALF_PATCH * HALF_PATCH;
+  for (v = 0; v <= vmax; ++v) umax[v] = fb_cvround_d(sqrt(hp2 - v * v));
+  for (v = HALF_PATCH, v0 = 0; v >= vmin; --v) {
+    while (umax[v0] == umax[v0 + 1]) ++v0;
+    umax[v] = v0;
+    ++v0;
+  }
+  for (int i = 0; i <= HALF_PATCH; i++) t.umax[i] = umax[i];
+}
+
+int capacity_of(const fb_orb_params &p) { return p.nfeatures + 8 * p.nlevels; }
+
+// (re)build the workspace for images of w x h, up to `batch` per call
+int prepare(fb_orb *o, int w, int h, int batch) {
+  if (o->w == w && o->h == h && batch <= o->batchCap) return FB_OK;
+  const fb_orb_params &p = o->p;
+  OrbK &K = o->K;
+  memset(&K, 0, sizeof(K));
+  K.nlevels = p.nlevels;
+  K.iniTh = p.ini_th_fast;
+  K.minTh = p.min_th_fast;
+  K.capOut = capacity_of(p);
+  for (int i = 0; i < 16; i++) K.umax[i] = o->t.umax[i];
+  long long pyrOff = 0, candOff = 0;
+  int cells = 0, outOff = 0, maxNodes = 0;
+  std::vector<int> xofs, yofs;
+  std::vector<short> ialpha, ibeta;
+  std::vector<size_t> tabOff(p.nlevels * 4, 0);
+  std::vector<uint8_t> tabBytes;
+  auto append = [&](const void *src, size_t n) {
+    size_t off = (tabBytes.size() + 15) & ~(size_t)15;
+    tabBytes.resize(off + n);
+    memcpy(tabBytes.data() + off, src, n);
+    return off;
+  };
+  int pw = w, ph = h;
+  for (int l = 0; l < p.nlevels; l++) {
+    LevelInfo &L = K.L[l];
+    const float scale = o->t.inv_scale_factor[l];
+    L.w = fb_cvround((float)w * scale);   // ORBextractor.cc:1112
+    L.h = fb_cvround((float)h * scale);
+    if (l == 0) { L.w = w; L.h = h; }
+    if (L.w >= 4096 || L.h >= 4096) { fb::set_error("image too large (level %d is %dx%d, limit 4095)", l, L.w, L.h); return FB_ERR_ARG; }
+    L.pitch = (L.w + 63) & ~63;
+    L.off = pyrOff;
+    if (l > 0) pyrOff += (long long)L.pitch * L.h;
+    const int maxBX = L.w - BORDER, maxBY = L.h - BORDER;
+    const float width = (float)(maxBX - BORDER), height = (float)(maxBY - BORDER);
+    L.nCols = (int)(width / 30.f);
+    L.nRows = (int)(height / 30.f);
+    if (L.nCols <= 0 || L.nRows <= 0) { L.nCols = L.nRows = 0; L.wCell = L.hCell = 1; }
+    else { L.wCell = (int)ceilf(width / L.nCols); L.hCell = (int)ceilf(height / L.nRows); }
+    if (L.wCell + 6 > FAST_MAX_TILE - 3 || L.hCell + 6 > FAST_MAX_TILE) { fb::set_error("FAST cell %dx%d exceeds the LDS tile", L.wCell, L.hCell); return FB_ERR_CAPACITY; }
+    L.cellBase = cells;
+    cells += L.nCols * L.nRows;
+    if (L.nCols * L.nRows > 4095) { fb::set_error("level %d has more than 4095 FAST cells", l); return FB_ERR_CAPACITY; }
+    L.N = o->t.features_per_level[l];
+    // NMS worst case: one survivor per 2x2 block of each cell's detection area
+    const int dw = std::max(L.w - 2 * EDGE_THRESHOLD, 0), dh = std::max(L.h - 2 * EDGE_THRESHOLD, 0);
+    L.candBase = candOff;
+    L.candCap = L.nCols * L.nRows * (((L.wCell + 1) / 2) * ((L.hCell + 1) / 2)) + 16;
+    (void)dw; (void)dh;
+    candOff += (L.candCap + 3) & ~3;
+    const int Wr = maxBX - BORDER, Hr = maxBY - BORDER;
+    L.nIni = (Hr > 0) ? (int)roundf((float)Wr / Hr) : 0;   // ORBextractor.cc:542
+    L.hX = L.nIni > 0 ? (float)Wr / L.nIni : 1.f;
+    L.outBase = outOff;
+    L.outCap = std::max(L.N + 3, 4 * L.nIni) + 4;
+    outOff += L.outCap;
+    maxNodes = std::max(maxNodes, L.outCap + 4);
+    L.scale = o->t.scale_factor[l];
+    L.patchSize = (int)(PATCH_SIZE * o->t.scale_factor[l]);
+    if (l > 0) {  // resize tables (oracle resize_linear_u8)
+      const int sw = pw, sh = ph, dwd = L.w, dhd = L.h;
+      const double inv_scale_x = (double)dwd / sw, inv_scale_y = (double)dhd / sh;
+      const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+      xofs.assign(dwd, 0); ialpha.assign(dwd * 2, 0); yofs.assign(dhd, 0); ibeta.assign(dhd * 2, 0);
+      for (int dx = 0; dx < dwd; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = fb_cvfloor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        ialpha[dx * 2] = (short)fb_cvround((1.f - fx) * 2048.f);
+        ialpha[dx * 2 + 1] = (short)fb_cvround(fx * 2048.f);
+      }
+      for (int dy = 0; dy < dhd; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = fb_cvfloor(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        ibeta[dy * 2] = (short)fb_cvround((1.f - fy) * 2048.f);
+        ibeta[dy * 2 + 1] = (short)fb_cvround(fy * 2048.f);
+      }
+      tabOff[l * 4 + 0] = append(xofs.data(), xofs.size() * 4);
+      tabOff[l * 4 + 1] = append(ialpha.data(), ialpha.size() * 2);
+      tabOff[l * 4 + 2] = append(yofs.data(), yofs.size() * 4);
+      tabOff[l * 4 + 3] = append(ibeta.data(), ibeta.size() * 2);
+    }
+    pw = L.w; ph = L.h;
+  }
+  K.totalCells = cells;
+  K.pyrStride = (pyrOff + 255) & ~255ll;
+  K.candStride = candOff;
+  K.outStride = outOff;
+  o->maxNodes = maxNodes;
+  // LDS of k_octree: 2 lists + ccnt + cpos + npos + order + split + best
+  const size_t M = maxNodes;
+  size_t lds = 2 * M * sizeof(ONode) + 4 * M * 4 + 4 * M * 2 + M * 2 + M * 2 + M;
+  lds = ((lds + 7) & ~(size_t)7) + M * 8 + 16;
+  if (lds > 160 * 1024) { fb::set_error("nfeatures too large for the LDS quadtree (%zu B)", lds); return FB_ERR_CAPACITY; }
+  o->octreeLds = lds;
+  FB_TRY(o->tabs.upload(tabBytes.data(), tabBytes.size()));
+  for (int l = 1; l < p.nlevels; l++) {
+    const uint8_t *base = o->tabs.as<uint8_t>();
+    o->rt[l].xofs = reinterpret_cast<const int *>(base + tabOff[l * 4 + 0]);
+    o->rt[l].ialpha = reinterpret_cast<const short *>(base + tabOff[l * 4 + 1]);
+    o->rt[l].yofs = reinterpret_cast<const int *>(base + tabOff[l * 4 + 2]);
+    o->rt[l].ibeta = reinterpret_cast<const short *>(base + tabOff[l * 4 + 3]);
+  }
+  const size_t B = batch;
+  FB_TRY(o->pyr.alloc(B * K.pyrStride + 256));
+  FB_TRY(o->cand.alloc(B * K.candStride * 4 + 16));
+  FB_TRY(o->nodeOf.alloc(B * K.candStride * 2 + 16));
+  FB_TRY(o->counts.alloc(B * p.nlevels * 4 * 2));  // candCount | lvlCount
+  FB_TRY(o->lvlOut.alloc(B * K.outStride * 4 + 16));
+  o->w = w; o->h = h; o->batchCap = batch;
+  return FB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fb_orb_capacity(const fb_orb_params *params) {
+  if (!params) return FB_ERR_ARG;
+  return capacity_of(*params);
+}
+
+int fb_orb_create(const fb_orb_params *params, fb_orb **out) {
+  FB_ARG(params && out);
+  FB_ARG(params->nlevels >= 1 && params->nlevels <= FB_MAX_LEVELS);
+  FB_ARG(params->nfeatures >= 1 && params->nfeatures <= 60000);
+  FB_ARG(params->scale_factor > 1.0f);
+  FB_ARG(params->min_th_fast >= 1 && params->ini_th_fast >= params->min_th_fast && params->ini_th_fast <= 254);
+  fb_orb *o = new fb_orb();
+  o->p = *params;
+  make_tables(o->p, o->t);
+  *out = o;
+  return FB_OK;
+}
+
+void fb_orb_destroy(fb_orb *h) { delete h; }
+
+int fb_orb_get_tables(const fb_orb *h, fb_orb_tables *out) {
+  FB_ARG(h && out);
+  *out = h->t;
+  return FB_OK;
+}
+
+int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int width, int height, int stride,
+                             size_t image_stride, fb_keypoint *d_keypoints, uint8_t *d_descriptors, int32_t *d_n,
+                             void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(o && d_images && d_keypoints && d_descriptors && d_n);
+  FB_ARG(batch >= 1 && width >= 2 * EDGE_THRESHOLD + 7 && height >= 2 * EDGE_THRESHOLD + 7 && stride >= width);
+  FB_TRY(prepare(o, width, height, batch));
+  hipStream_t s = fb::as_stream(stream);
+  const OrbK &K = o->K;
+  const int nl = K.nlevels;
+  int *candCount = o->counts.as<int>();
+  int *lvlCount = candCount + (size_t)o->batchCap * nl;
+  FB_HIP(hipMemsetAsync(candCount, 0, (size_t)batch * nl * 4, s));
+  // pyramid
+  for (int l = 1; l < nl; l++) {
+    const LevelInfo &D = K.L[l], &S = K.L[l - 1];
+    const uint8_t *src = (l == 1) ? d_images : o->pyr.as<uint8_t>() + S.off;
+    const long long sstr = (l == 1) ? (long long)image_stride : K.pyrStride;
+    const int spitch = (l == 1) ? stride : S.pitch;
+    dim3 blk(64, 4), grd((D.pitch / 4 + 63) / 64, (D.h + 3) / 4, batch);
+    k_resize<<<grd, blk, 0, s>>>(src, sstr, S.w, S.h, spitch, o->pyr.as<uint8_t>() + D.off, K.pyrStride, D.w, D.h, D.pitch, o->rt[l]);
+  }
+  if (K.totalCells > 0)
+    k_fast<<<dim3(K.totalCells, batch), 256, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
+                                                      o->cand.as<uint32_t>(), candCount);
+  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->octreeLds));
+  k_octree<<<dim3(nl, batch), 256, o->octreeLds, s>>>(K, o->cand.as<uint32_t>(), candCount, o->nodeOf.as<uint16_t>(),
+                                                       o->lvlOut.as<uint32_t>(), lvlCount, o->maxNodes);
+  k_describe<<<dim3(K.capOut, batch), 64, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
+                                                   o->lvlOut.as<uint32_t>(), lvlCount, d_keypoints, d_descriptors, d_n);
+  FB_HIP(hipGetLastError());
+  o->lastImg = d_images;
+  o->lastImgStride = (long long)image_stride;
+  o->lastPitch0 = stride;
+  return FB_OK;
+}
+
+int fb_orb_extract(fb_orb *o, const uint8_t *image, int width, int height, int stride, fb_keypoint *keypoints,
+                   uint8_t *descriptors, int32_t *n_out) {
+  FB_TRY(fb::check_device());
+  FB_ARG(o && n_out);
+  if (!image || width <= 0 || height <= 0) return FB_OK;  // _image.empty(): silent return, ORBextractor.cc:1046
+  FB_ARG(keypoints && descriptors && stride >= width);
+  const int cap = capacity_of(o->p);
+  fb::DevBuf dk, dd, dn;
+  FB_TRY(o->ownedImg.upload(image, (size_t)stride * height));
+  FB_TRY(dk.alloc((size_t)cap * sizeof(fb_keypoint)));
+  FB_TRY(dd.alloc((size_t)cap * 32));
+  FB_TRY(dn.alloc(4));
+  FB_TRY(fb_orb_extract_batch_dev(o, o->ownedImg.as<uint8_t>(), 1, width, height, stride, (size_t)stride * height,
+                                  dk.as<fb_keypoint>(), dd.as<uint8_t>(), dn.as<int32_t>(), nullptr));
+  FB_HIP(hipDeviceSynchronize());
+  FB_TRY(dn.download(n_out, 4));
+  if (*n_out > cap) { fb::set_error("keypoint capacity exceeded"); return FB_ERR_CAPACITY; }
+  FB_TRY(dk.download(keypoints, (size_t)*n_out * sizeof(fb_keypoint)));
+  return dd.download(descriptors, (size_t)*n_out * 32);
+}
+
+int fb_orb_debug_candidates(fb_orb *o, int b, int level, uint32_t *dst, int cap) {
+  FB_TRY(fb::check_device());
+  FB_ARG(o && o->lastImg && level >= 0 && level < o->p.nlevels && b >= 0 && b < o->batchCap);
+  FB_HIP(hipDeviceSynchronize());
+  int n = 0;
+  FB_HIP(hipMemcpy(&n, o->counts.as<int>() + (size_t)b * o->p.nlevels + level, 4, hipMemcpyDeviceToHost));
+  const LevelInfo &L = o->K.L[level];
+  const int m = n < cap ? n : cap;
+  if (dst && m > 0)
+    FB_HIP(hipMemcpy(dst, o->cand.as<uint32_t>() + (size_t)b * o->K.candStride + L.candBase, (size_t)m * 4, hipMemcpyDeviceToHost));
+  return n;
+}
+
+int fb_orb_get_level(fb_orb *o, int b, int level, uint8_t *dst, int *w, int *hgt) {
+  FB_TRY(fb::check_device());
+  FB_ARG(o && w && hgt && o->lastImg && level >= 0 && level < o->p.nlevels && b >= 0 && b < o->batchCap);
+  const LevelInfo &L = o->K.L[level];
+  *w = L.w;
+  *hgt = L.h;
+  if (!dst) return FB_OK;
+  FB_HIP(hipDeviceSynchronize());
+  const uint8_t *src = level == 0 ? o->lastImg + (long long)b * o->lastImgStride
+                                  : o->pyr.as<uint8_t>() + (long long)b * o->K.pyrStride + L.off;
+  const int pitch = level == 0 ? o->lastPitch0 : L.pitch;
+  FB_HIP(hipMemcpy2D(dst, L.w, src, pitch, L.w, L.h, hipMemcpyDeviceToHost));
+  return FB_OK;
+}
+
+}  // extern "C"

@@ -132,3 +132,54 @@ def pose_args(problems, mode=cabi.FB_POSE_FRONT_BIRD, wF=1.0, wB=1.0, front_vali
     fill(a, batch=B, mode=mode, front_stride=fs, bird_stride=bs, fx=p0["fx"], fy=p0["fy"], cx=p0["cx"], cy=p0["cy"],
          wF=wF, wB=wB, **keep, **out)
     return a, out, keep
+
+
+def proj_points_args(problems, cell_start, cell_items, th=1.0, nnratio=0.8):
+    B = len(problems)
+    p0 = problems[0]
+    cs_ = max(len(p["cur_kps"]) for p in problems)
+    ms_ = max(len(p["mp_desc"]) for p in problems)
+    keep = dict(
+        n_cur=np.array([len(p["cur_kps"]) for p in problems], np.int32),
+        cur_kps=_stack([p["cur_kps"] for p in problems], cs_, cabi.KP_DTYPE),
+        cur_desc=_stack([p["cur_desc"] for p in problems], cs_, np.uint8, (32,)),
+        cur_cell_start=_c(cell_start), cur_cell_items=_c(cell_items),
+        cur_blocked=_stack([p["cur_blocked"] for p in problems], cs_, np.uint8),
+        n_mp=np.array([len(p["mp_desc"]) for p in problems], np.int32),
+        mp_track=_stack([p["mp_track"] for p in problems], ms_, np.uint8),
+        mp_obs_pos=_stack([p["mp_obs_pos"] for p in problems], ms_, np.uint8),
+        mp_proj=_stack([p["mp_proj"] for p in problems], ms_, np.float32, (2,)),
+        mp_level=_stack([p["mp_level"] for p in problems], ms_, np.int32),
+        mp_view_cos=_stack([p["mp_view_cos"] for p in problems], ms_, np.float32),
+        mp_desc=_stack([p["mp_desc"] for p in problems], ms_, np.uint8, (32,)),
+    )
+    out = dict(match_cur_to_mp=np.full((B, cs_), -7, np.int32), nmatches=np.full(B, -7, np.int32))
+    a = cabi.ProjPointsArgs()
+    fill(a, batch=B, cur_stride=cs_, mp_stride=ms_, th=th, **keep, **out)
+    fill(a.grid, **synth.front_grid_geom(p0["w"], p0["h"]))
+    fill(a, scale_factors=[float(x) for x in synth.scale_tables()[0]])
+    fill(a.matcher, nnratio=nnratio, check_orientation=1)
+    return a, out, keep
+
+
+def birdview_args(problems, cell_start, cell_items, window=10, nnratio=0.9, check_ori=1):
+    B = len(problems)
+    p0 = problems[0]
+    cs_ = max(len(p["cur_kps"]) for p in problems)
+    rs_ = max(len(p["ref_kps"]) for p in problems)
+    keep = dict(
+        n_cur=np.array([len(p["cur_kps"]) for p in problems], np.int32),
+        cur_kps=_stack([p["cur_kps"] for p in problems], cs_, cabi.KP_DTYPE),
+        cur_desc=_stack([p["cur_desc"] for p in problems], cs_, np.uint8, (32,)),
+        cur_cell_start=_c(cell_start), cur_cell_items=_c(cell_items),
+        n_ref=np.array([len(p["ref_kps"]) for p in problems], np.int32),
+        ref_kps=_stack([p["ref_kps"] for p in problems], rs_, cabi.KP_DTYPE),
+        ref_desc=_stack([p["ref_desc"] for p in problems], rs_, np.uint8, (32,)),
+    )
+    out = dict(match_ref_to_cur=np.full((B, rs_), -7, np.int32), match_dist=np.full((B, rs_), -7, np.int32),
+               nmatches=np.full(B, -7, np.int32), n_dmatches=np.full(B, -7, np.int32))
+    a = cabi.BirdviewArgs()
+    fill(a, batch=B, cur_stride=cs_, ref_stride=rs_, window_size=window, **keep, **out)
+    fill(a.grid, **synth.bird_grid_geom(p0["cols"], p0["rows"]))
+    fill(a.matcher, nnratio=nnratio, check_orientation=check_ori)
+    return a, out, keep

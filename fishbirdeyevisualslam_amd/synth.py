@@ -266,3 +266,42 @@ def make_pose_problem(seed, n_front=2000, n_bird=1000, w=1280, h=720, fx=500.0, 
                bird_inv_sigma2=inv_sig2[boct].astype(np.float32), bird_is_outlier=badb)
     out["Tcw0"] = to12(perturb_pose(g, T))
     return out
+
+
+# ---- M2 problem: SearchByProjection(F, vpMapPoints, th) ---------------------------------
+def make_proj_points_problem(seed, n_cur=2000, n_mp=3000, w=1280, h=720):
+    g = rng(seed)
+    cur = random_keypoints(g, n_cur, w, h)
+    cur_desc = random_descriptors(g, n_cur)
+    tgt = g.integers(0, n_cur, n_mp)
+    is_copy = g.random(n_mp) < 0.7
+    mp_desc = random_descriptors(g, n_mp)
+    mp_desc[is_copy] = flip_bits(g, cur_desc[tgt[is_copy]])
+    proj = np.stack([cur["x"][tgt] + g.normal(0, 2.0, n_mp), cur["y"][tgt] + g.normal(0, 2.0, n_mp)], 1)
+    level = np.clip(cur["octave"][tgt] + g.integers(0, 2, n_mp), 0, 7).astype(np.int32)
+    return dict(w=w, h=h, cur_kps=cur, cur_desc=cur_desc,
+                cur_blocked=(g.random(n_cur) < 0.05).astype(np.uint8),
+                mp_track=(g.random(n_mp) < 0.9).astype(np.uint8),
+                mp_obs_pos=(g.random(n_mp) < 0.95).astype(np.uint8),
+                mp_proj=np.ascontiguousarray(proj.astype(np.float32)), mp_level=level,
+                mp_view_cos=g.uniform(0.99, 1.0, n_mp).astype(np.float32), mp_desc=mp_desc)
+
+
+# ---- M8 problem: BirdviewMatch(isProject=0) ---------------------------------------------
+def make_birdview_problem(seed, n_cur=1000, n_ref=1000, cols=512, rows=512):
+    g = rng(seed)
+    cur = random_keypoints(g, n_cur, cols, rows)
+    cur["octave"] = np.where(g.random(n_cur) < 0.6, 0, g.integers(0, 8, n_cur)).astype(np.int32)
+    cur_desc = random_descriptors(g, n_cur)
+    tgt = g.integers(0, n_cur, n_ref)
+    ref = np.zeros(n_ref, KP_DTYPE)
+    ref["x"] = (cur["x"][tgt] + g.normal(0, 2.0, n_ref)).astype(np.float32)
+    ref["y"] = (cur["y"][tgt] + g.normal(0, 2.0, n_ref)).astype(np.float32)
+    ref["octave"] = np.where(g.random(n_ref) < 0.8, 0, g.integers(1, 8, n_ref)).astype(np.int32)
+    ref["angle"] = np.mod(cur["angle"][tgt] + 20.0 + g.normal(0, 5.0, n_ref), 360.0).astype(np.float32)
+    wild = g.random(n_ref) < 0.1
+    ref["angle"][wild] = g.uniform(0, 360, int(wild.sum())).astype(np.float32)
+    is_copy = g.random(n_ref) < 0.7
+    ref_desc = random_descriptors(g, n_ref)
+    ref_desc[is_copy] = flip_bits(g, cur_desc[tgt[is_copy]], p=0.05)
+    return dict(cols=cols, rows=rows, cur_kps=cur, cur_desc=cur_desc, ref_kps=ref, ref_desc=ref_desc)

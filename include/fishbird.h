@@ -99,6 +99,10 @@ int fb_orb_extract_batch_dev(fb_orb *h, const uint8_t *d_images, int batch, int 
 /* debug/parity access to the pyramid level of image `b` of the last batch
  * (public member mvImagePyramid, ORBextractor.h:85). dst is host, w*h bytes.  */
 int fb_orb_get_level(fb_orb *h, int b, int level, uint8_t *dst, int *w, int *hgt);
+/* debug/parity: FAST candidates of (image b, level) of the last batch, the input of
+ * DistributeOctTree (vToDistributeKeys, ORBextractor.cc:822-824), packed
+ * x | y<<12 | response<<24 in level coordinates, unordered.  Returns the count (>=0). */
+int fb_orb_debug_candidates(fb_orb *h, int b, int level, uint32_t *dst, int cap);
 
 /* ======================================================================== */
 /* Frame grid (src/Frame.cc:381-411, 548-570; include/Frame.h:38-40)         */
