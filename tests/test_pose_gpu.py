@@ -1,0 +1,89 @@
+"""GPU parity: HIP pose optimisation (C-ABI) vs the CPU oracle.
+
+Tolerance (BASELINE.json north_star): pose within 1e-4 relative; inlier/outlier masks and the
+returned inlier count are integer results and must be identical.
+"""
+import numpy as np
+import pytest
+
+import hip_lib as H
+import oracle_lib as O
+from fishbirdeyevisualslam_amd import cabi, problems as P, synth
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-4
+
+
+def _run(probs, **kw):
+    a, out_o, keep = P.pose_args(probs, **kw)
+    O.call("orc_pose_opt", a)
+    a2, out_h, keep2 = P.pose_args(probs, **kw)
+    H.call("fb_pose_opt", a2)
+    return out_o, out_h
+
+
+def _compare(out_o, out_h, mode):
+    To, Th = out_o["Tcw"].reshape(-1, 3, 4), out_h["Tcw"].reshape(-1, 3, 4)
+    scale = np.maximum(1.0, np.abs(To).max(axis=(1, 2), keepdims=True))
+    rel = np.abs(Th - To) / scale
+    assert rel.max() <= REL_TOL, rel.max()
+    np.testing.assert_array_equal(out_h["ninliers"], out_o["ninliers"])
+    if mode != cabi.FB_POSE_BIRD:
+        np.testing.assert_array_equal(out_h["front_outlier"], out_o["front_outlier"])
+    if mode != cabi.FB_POSE_FRONT:
+        np.testing.assert_array_equal(out_h["bird_outlier"], out_o["bird_outlier"])
+    return rel.max()
+
+
+@pytest.mark.parametrize("mode", [cabi.FB_POSE_FRONT, cabi.FB_POSE_FRONT_BIRD, cabi.FB_POSE_BIRD])
+def test_pose_opt_config3(mode):
+    """BASELINE config 3: 2000 front + 1000 bird edges."""
+    probs = [synth.make_pose_problem(3000 + i) for i in range(4)]
+    out_o, out_h = _run(probs, mode=mode)
+    _compare(out_o, out_h, mode)
+    # the optimiser must actually have moved towards the generating pose
+    Tt = np.stack([p["T_true"][:3, :4] for p in probs])
+    e0 = np.abs(np.stack([p["Tcw0"].reshape(3, 4) for p in probs]) - Tt).max()
+    e1 = np.abs(out_h["Tcw"].reshape(-1, 3, 4) - Tt).max()
+    assert e1 < (0.2 if mode != cabi.FB_POSE_BIRD else 0.5) * e0
+
+
+def test_pose_opt_weights_and_masks():
+    g = synth.rng(5)
+    probs = [synth.make_pose_problem(3100 + i, n_front=700 + 50 * i, n_bird=300 + 20 * i) for i in range(3)]
+    fv = [(g.random(len(p["front_xw"])) < 0.7).astype(np.uint8) for p in probs]
+    bv = [(g.random(len(p["bird_xw"])) < 0.6).astype(np.uint8) for p in probs]
+    bo = [(g.random(len(p["bird_xw"])) < 0.2).astype(np.uint8) for p in probs]
+    out_o, out_h = _run(probs, mode=cabi.FB_POSE_FRONT_BIRD, wF=1.0, wB=3.0, front_valid=fv, bird_valid=bv,
+                        bird_outlier_in=bo)
+    _compare(out_o, out_h, cabi.FB_POSE_FRONT_BIRD)
+    # slots without an edge are left untouched (front buffer was pre-filled with 9)
+    for b in range(3):
+        assert np.all(out_h["front_outlier"][b, : len(fv[b])][fv[b] == 0] == 9)
+
+
+def test_pose_opt_degenerate_counts():
+    # < 3 correspondences -> returns 0 and leaves the pose alone (Optimizer.cc:379,607,776)
+    p = synth.make_pose_problem(3200, n_front=2, n_bird=2)
+    for mode in (cabi.FB_POSE_FRONT, cabi.FB_POSE_FRONT_BIRD, cabi.FB_POSE_BIRD):
+        out_o, out_h = _run([p], mode=mode)
+        assert out_h["ninliers"][0] == 0 and out_o["ninliers"][0] == 0
+        np.testing.assert_array_equal(out_h["Tcw"], np.stack([p["Tcw0"]]))
+    # fewer than 10 edges in total -> a single round (Optimizer.cc:462,688)
+    p = synth.make_pose_problem(3201, n_front=5, n_bird=3, outlier_frac=0.0)
+    out_o, out_h = _run([p], mode=cabi.FB_POSE_FRONT_BIRD)
+    _compare(out_o, out_h, cabi.FB_POSE_FRONT_BIRD)
+
+
+def test_pose_opt_noise_free_recovers_pose():
+    """Known answer: noise-free data -> generating pose, zero outliers."""
+    p = synth.make_pose_problem(3300, n_front=400, n_bird=0)
+    T = p["T_true"]
+    Xw = p["front_xw"].astype(np.float64)
+    Xc = (T[:3, :3] @ Xw.T).T + T[:3, 3]
+    p["front_obs"] = np.ascontiguousarray(
+        np.stack([Xc[:, 0] / Xc[:, 2] * p["fx"] + p["cx"], Xc[:, 1] / Xc[:, 2] * p["fy"] + p["cy"]], 1).astype(np.float32))
+    out_o, out_h = _run([p], mode=cabi.FB_POSE_FRONT)
+    _compare(out_o, out_h, cabi.FB_POSE_FRONT)
+    assert out_h["ninliers"][0] == 400 and out_h["front_outlier"][0, :400].sum() == 0
+    assert np.abs(out_h["Tcw"][0].reshape(3, 4) - T[:3, :4]).max() < 1e-3
