@@ -37,6 +37,10 @@ def ptr(x):
     raise TypeError(type(x))
 
 
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", _i32), ("total_ms", C.c_double)]
+
+
 class OrbParams(C.Structure):
     _fields_ = [("nfeatures", _i32), ("scale_factor", _f32), ("nlevels", _i32), ("ini_th_fast", _i32),
                 ("min_th_fast", _i32)]
@@ -138,6 +142,7 @@ def fill(struct, **kw):
 # every symbol include/fishbird.h declares (checked by tests/test_cabi_exports.py)
 EXPORTS = [
     "fb_abi_version", "fb_last_error", "fb_device_count", "fb_set_device",
+    "fb_prof_enable", "fb_prof_reset", "fb_prof_report",
     "fb_orb_create", "fb_orb_destroy", "fb_orb_get_tables", "fb_orb_capacity", "fb_orb_extract", "fb_orb_extract_batch_dev",
     "fb_orb_get_level", "fb_orb_debug_candidates", "fb_grid_build_batch_dev", "fb_bird_keys_to_cam_dev",
     "fb_descriptor_distance_dev", "fb_descriptor_distance",

@@ -36,18 +36,33 @@ __host__ __device__ inline Quat quat_from_R(const double R[9]) {  // Eigen Quate
     q.y = (R[2] - R[6]) * t;
     q.z = (R[3] - R[1]) * t;
   } else {
+    // i = index of the largest diagonal entry, (i,j,k) cyclic; written out per case so that no
+    // array is indexed at run time (keeps everything in registers on the GPU)
     int i = 0;
     if (R[4] > R[0]) i = 1;
-    if (R[8] > R[i * 3 + i]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
-    double v[3];
-    v[i] = 0.5 * t;
-    t = 0.5 / t;
-    q.w = (R[k * 3 + j] - R[j * 3 + k]) * t;
-    v[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
-    v[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
-    q.x = v[0]; q.y = v[1]; q.z = v[2];
+    if (R[8] > (i == 1 ? R[4] : R[0])) i = 2;
+    if (i == 0) {
+      t = sqrt(R[0] - R[4] - R[8] + 1.0);
+      q.x = 0.5 * t;
+      t = 0.5 / t;
+      q.w = (R[7] - R[5]) * t;
+      q.y = (R[3] + R[1]) * t;
+      q.z = (R[6] + R[2]) * t;
+    } else if (i == 1) {
+      t = sqrt(R[4] - R[8] - R[0] + 1.0);
+      q.y = 0.5 * t;
+      t = 0.5 / t;
+      q.w = (R[2] - R[6]) * t;
+      q.z = (R[7] + R[5]) * t;
+      q.x = (R[1] + R[3]) * t;
+    } else {
+      t = sqrt(R[8] - R[0] - R[4] + 1.0);
+      q.z = 0.5 * t;
+      t = 0.5 / t;
+      q.w = (R[3] - R[1]) * t;
+      q.x = (R[2] + R[6]) * t;
+      q.y = (R[5] + R[7]) * t;
+    }
   }
   return q;
 }
@@ -211,27 +226,40 @@ __host__ __device__ inline void huber(double e, double delta, double &rho0, doub
 // (LinearSolverDense, solvers/linear_solver_dense.h:65-113: Eigen LDLT::isPositive()).
 __host__ __device__ inline bool ldlt6(const double H[36], double lambda, const double b[6], double x[6]) {
   double A[36], d[6], y[6];
+#pragma unroll
   for (int i = 0; i < 36; i++) A[i] = H[i];
+#pragma unroll
   for (int j = 0; j < 6; j++) A[j * 6 + j] += lambda;
+  bool ok = true;
+#pragma unroll
   for (int j = 0; j < 6; j++) {
     double dj = A[j * 6 + j];
+#pragma unroll
     for (int k = 0; k < j; k++) dj -= A[j * 6 + k] * A[j * 6 + k] * d[k];
-    if (dj < 0) return false;
+    if (dj < 0) ok = false;
     d[j] = dj;
+#pragma unroll
     for (int i = j + 1; i < 6; i++) {
       double s = A[i * 6 + j];
+#pragma unroll
       for (int k = 0; k < j; k++) s -= A[i * 6 + k] * A[j * 6 + k] * d[k];
       A[i * 6 + j] = dj != 0 ? s / dj : 0;
     }
   }
+  if (!ok) return false;
+#pragma unroll
   for (int i = 0; i < 6; i++) {
     double s = b[i];
+#pragma unroll
     for (int k = 0; k < i; k++) s -= A[i * 6 + k] * y[k];
     y[i] = s;
   }
+#pragma unroll
   for (int i = 0; i < 6; i++) y[i] = d[i] != 0 ? y[i] / d[i] : 0;
+#pragma unroll
   for (int i = 5; i >= 0; i--) {
     double s = y[i];
+#pragma unroll
     for (int k = i + 1; k < 6; k++) s -= A[k * 6 + i] * x[k];
     x[i] = s;
   }

@@ -589,6 +589,7 @@ int fb_descriptor_distance_dev(const uint8_t *d_a, const uint8_t *d_b, int n, in
   FB_TRY(fb::check_device());
   FB_ARG(n >= 0 && (n == 0 || (d_a && d_b && d_out)));
   if (n == 0) return FB_OK;
+  fb::ProfScope prof_(fb::P_HAMMING, fb::as_stream(stream));
   k_descriptor_distance<<<(n + 255) / 256, 256, 0, fb::as_stream(stream)>>>(
       reinterpret_cast<const uint4 *>(d_a), reinterpret_cast<const uint4 *>(d_b), n, d_out);
   FB_HIP(hipGetLastError());
@@ -616,6 +617,7 @@ int fb_grid_build_batch_dev(const fb_keypoint *d_keypoints, const int32_t *d_n, 
   const size_t lds = (size_t)(2 * ncell + 1) * 4;
   FB_TRY(check_lds(lds, "fb_grid_build_batch_dev"));
   FB_TRY(set_max_lds(k_grid_build, lds));
+  fb::ProfScope prof_(fb::P_GRID, fb::as_stream(stream));
   k_grid_build<<<batch, 256, lds, fb::as_stream(stream)>>>(d_keypoints, d_n, kp_stride, *geom, d_cell_start, d_cell_items);
   FB_HIP(hipGetLastError());
   return FB_OK;
@@ -631,6 +633,7 @@ int fb_bird_keys_to_cam_dev(const fb_keypoint *d_kps, const int32_t *d_n, int ba
   K.cols = bird_cols; K.rows = bird_rows; K.pixel2meter = pixel2meter; K.rear = rear_axle_to_center;
   memcpy(K.Tcb, Tcb12, sizeof(K.Tcb));
   dim3 grid((kp_stride + 255) / 256, batch);
+  fb::ProfScope prof_(fb::P_BIRDCAM, fb::as_stream(stream));
   k_bird_keys_to_cam<<<grid, 256, 0, fb::as_stream(stream)>>>(d_kps, d_n, kp_stride, K, d_cam_xyz);
   FB_HIP(hipGetLastError());
   return FB_OK;
@@ -644,6 +647,7 @@ int fb_match_projection_frame_dev(const fb_proj_frame_args *A, void *stream) {
   const size_t lds = match_lds_bytes(A->cur_stride, ncell, 2 * A->cur_stride + 2 * A->last_stride);
   FB_TRY(check_lds(lds, "fb_match_projection_frame"));
   FB_TRY(set_max_lds(k_proj_frame, lds));
+  fb::ProfScope prof_(fb::P_PROJ_FRAME, fb::as_stream(stream));
   k_proj_frame<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A);
   FB_HIP(hipGetLastError());
   return FB_OK;
@@ -657,6 +661,7 @@ int fb_match_projection_points_dev(const fb_proj_points_args *A, void *stream) {
   const size_t lds = match_lds_bytes(A->cur_stride, ncell, 2 * A->cur_stride + 2 * A->mp_stride);
   FB_TRY(check_lds(lds, "fb_match_projection_points"));
   FB_TRY(set_max_lds(k_proj_points, lds));
+  fb::ProfScope prof_(fb::P_PROJ_POINTS, fb::as_stream(stream));
   k_proj_points<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A);
   FB_HIP(hipGetLastError());
   return FB_OK;
@@ -670,6 +675,7 @@ int fb_match_bird_mappoints_dev(const fb_bird_mp_args *A, void *stream) {
   const size_t lds = match_lds_bytes(A->cur_stride, ncell, A->cur_stride);
   FB_TRY(check_lds(lds, "fb_match_bird_mappoints"));
   FB_TRY(set_max_lds(k_bird_mappoints, lds));
+  fb::ProfScope prof_(fb::P_BIRD_MP, fb::as_stream(stream));
   k_bird_mappoints<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A);
   FB_HIP(hipGetLastError());
   return FB_OK;
@@ -683,6 +689,7 @@ int fb_match_birdview_dev(const fb_birdview_args *A, void *stream) {
   const size_t lds = match_lds_bytes(A->cur_stride, ncell, 2 * A->ref_stride);
   FB_TRY(check_lds(lds, "fb_match_birdview"));
   FB_TRY(set_max_lds(k_birdview, lds));
+  fb::ProfScope prof_(fb::P_BIRDVIEW, fb::as_stream(stream));
   k_birdview<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A);
   FB_HIP(hipGetLastError());
   return FB_OK;

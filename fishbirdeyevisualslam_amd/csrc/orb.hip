@@ -803,16 +803,25 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
     const long long sstr = (l == 1) ? (long long)image_stride : K.pyrStride;
     const int spitch = (l == 1) ? stride : S.pitch;
     dim3 blk(64, 4), grd((D.pitch / 4 + 63) / 64, (D.h + 3) / 4, batch);
+    fb::ProfScope prof_(fb::P_RESIZE, s);
     k_resize<<<grd, blk, 0, s>>>(src, sstr, S.w, S.h, spitch, o->pyr.as<uint8_t>() + D.off, K.pyrStride, D.w, D.h, D.pitch, o->rt[l]);
   }
-  if (K.totalCells > 0)
+  if (K.totalCells > 0) {
+    fb::ProfScope prof_(fb::P_FAST, s);
     k_fast<<<dim3(K.totalCells, batch), 256, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
                                                       o->cand.as<uint32_t>(), candCount);
+  }
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->octreeLds));
+  {
+  fb::ProfScope prof_(fb::P_OCTREE, s);
   k_octree<<<dim3(nl, batch), 256, o->octreeLds, s>>>(K, o->cand.as<uint32_t>(), candCount, o->nodeOf.as<uint16_t>(),
                                                        o->lvlOut.as<uint32_t>(), lvlCount, o->maxNodes);
+  }
+  {
+  fb::ProfScope prof_(fb::P_DESCRIBE, s);
   k_describe<<<dim3(K.capOut, batch), 64, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
                                                    o->lvlOut.as<uint32_t>(), lvlCount, d_keypoints, d_descriptors, d_n);
+  }
   FB_HIP(hipGetLastError());
   o->lastImg = d_images;
   o->lastImgStride = (long long)image_stride;

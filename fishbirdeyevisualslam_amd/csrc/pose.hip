@@ -49,6 +49,39 @@ struct EdgeView {  // staged (LDS) or global float arrays of one problem
   double wf, wb;  // information = (1.0*invSigma2)*w  (Optimizer.cc:303,542,588,756)
 };
 
+// accumulate one edge (base_unary_edge.hpp:43-72): b -= rho1 * J^T (info e), H += J^T (rho1 info) J.
+// DIM is a compile-time constant and every loop is unrolled so J/err/acc stay in registers.
+template <int DIM>
+__device__ __forceinline__ void accumulate_edge(const double (&J)[DIM][6], const double (&err)[DIM], double info,
+                                                bool robust, double delta, double (&acc)[NACC]) {
+  double chi2 = 0;
+#pragma unroll
+  for (int r = 0; r < DIM; r++) chi2 += err[r] * (info * err[r]);
+  double rho0 = chi2, rho1 = 1.;
+  if (robust) fb::huber(chi2, delta, rho0, rho1);
+  acc[0] += rho0;
+  const double w = rho1 * info;
+  double ie[DIM];
+#pragma unroll
+  for (int r = 0; r < DIM; r++) ie[r] = info * err[r];
+  int hidx = 1;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double s = 0;
+#pragma unroll
+    for (int r = 0; r < DIM; r++) s += J[r][i] * ie[r];
+    acc[22 + i] -= rho1 * s;
+#pragma unroll
+    for (int j = i; j < 6; j++) {
+      double h = 0;
+#pragma unroll
+      for (int r = 0; r < DIM; r++) h += J[r][i] * w * J[r][j];
+      acc[hidx] += h;
+      hidx++;
+    }
+  }
+}
+
 // one evaluation: robust chi2 + H + b at pose T over the active edges
 __device__ void eval_pass(const EdgeView &E, const fb::SE3 &T, bool robust, double delta, double fx, double fy,
                           double cx, double cy, PoseLds *S) {
@@ -56,68 +89,26 @@ __device__ void eval_pass(const EdgeView &E, const fb::SE3 &T, bool robust, doub
 #pragma unroll
   for (int i = 0; i < NACC; i++) acc[i] = 0;
   const int tid = threadIdx.x;
-  for (int e = tid; e < E.nfs + E.nbs; e += POSE_THREADS) {
-    double J[18], err[3], info;
-    int dim;
-    if (e < E.nfs) {
-      if (E.flevel[e] != 0) continue;
-      const double Xw[3] = {E.fxw[e * 3], E.fxw[e * 3 + 1], E.fxw[e * 3 + 2]};
-      double p[3];
-      fb::se3_map(T, Xw, p);
-      err[0] = (double)E.fobs[e * 2] - ((p[0] / p[2]) * fx + cx);
-      err[1] = (double)E.fobs[e * 2 + 1] - ((p[1] / p[2]) * fy + cy);
-      err[2] = 0;
-      const double X = p[0], Y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
-      J[0] = X * Y * invz_2 * fx;
-      J[1] = -(1 + (X * X * invz_2)) * fx;
-      J[2] = Y * invz * fx;
-      J[3] = -invz * fx;
-      J[4] = 0;
-      J[5] = X * invz_2 * fx;
-      J[6] = (1 + Y * Y * invz_2) * fy;
-      J[7] = -X * Y * invz_2 * fy;
-      J[8] = -X * invz * fy;
-      J[9] = 0;
-      J[10] = -invz * fy;
-      J[11] = Y * invz_2 * fy;
-#pragma unroll
-      for (int i = 12; i < 18; i++) J[i] = 0;
-      info = (double)E.finf[e] * E.wf;
-      dim = 2;
-    } else {
-      const int k = e - E.nfs;
-      if (E.blevel[k] != 0) continue;
-      const double Xw[3] = {E.bxw[k * 3], E.bxw[k * 3 + 1], E.bxw[k * 3 + 2]};
-      double p[3];
-      fb::se3_map(T, Xw, p);
-#pragma unroll
-      for (int i = 0; i < 3; i++) err[i] = (double)E.bxc[k * 3 + i] - p[i];
-      // -[-skew(p), I]
-      J[0] = 0;     J[1] = -p[2]; J[2] = p[1];  J[3] = -1; J[4] = 0;  J[5] = 0;
-      J[6] = p[2];  J[7] = 0;     J[8] = -p[0]; J[9] = 0;  J[10] = -1; J[11] = 0;
-      J[12] = -p[1]; J[13] = p[0]; J[14] = 0;   J[15] = 0; J[16] = 0; J[17] = -1;
-      info = (double)E.binf[k] * E.wb;
-      dim = 3;
-    }
-    double chi2 = 0;
-    for (int r = 0; r < dim; r++) chi2 += err[r] * (info * err[r]);
-    double rho0 = chi2, rho1 = 1.;
-    if (robust) fb::huber(chi2, delta, rho0, rho1);
-    acc[0] += rho0;
-    const double w = rho1 * info;
-    int hidx = 1;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      double s = 0;
-      for (int r = 0; r < dim; r++) s += J[r * 6 + i] * (info * err[r]);
-      acc[22 + i] -= rho1 * s;
-#pragma unroll
-      for (int j = i; j < 6; j++) {
-        double h = 0;
-        for (int r = 0; r < dim; r++) h += J[r * 6 + i] * w * J[r * 6 + j];
-        acc[hidx++] += h;
-      }
-    }
+  for (int e = tid; e < E.nfs; e += POSE_THREADS) {  // EdgeSE3ProjectXYZOnlyPose
+    if (E.flevel[e] != 0) continue;
+    const double Xw[3] = {E.fxw[e * 3], E.fxw[e * 3 + 1], E.fxw[e * 3 + 2]};
+    double p[3];
+    fb::se3_map(T, Xw, p);
+    const double err[2] = {(double)E.fobs[e * 2] - ((p[0] / p[2]) * fx + cx),
+                           (double)E.fobs[e * 2 + 1] - ((p[1] / p[2]) * fy + cy)};
+    const double X = p[0], Y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
+    const double J[2][6] = {{X * Y * invz_2 * fx, -(1 + (X * X * invz_2)) * fx, Y * invz * fx, -invz * fx, 0, X * invz_2 * fx},
+                            {(1 + Y * Y * invz_2) * fy, -X * Y * invz_2 * fy, -X * invz * fy, 0, -invz * fy, Y * invz_2 * fy}};
+    accumulate_edge<2>(J, err, (double)E.finf[e] * E.wf, robust, delta, acc);
+  }
+  for (int k = tid; k < E.nbs; k += POSE_THREADS) {  // EdgeSE3ProjectBirdPoint2CamXYZ
+    if (E.blevel[k] != 0) continue;
+    const double Xw[3] = {E.bxw[k * 3], E.bxw[k * 3 + 1], E.bxw[k * 3 + 2]};
+    double p[3];
+    fb::se3_map(T, Xw, p);
+    const double err[3] = {(double)E.bxc[k * 3] - p[0], (double)E.bxc[k * 3 + 1] - p[1], (double)E.bxc[k * 3 + 2] - p[2]};
+    const double J[3][6] = {{0, -p[2], p[1], -1, 0, 0}, {p[2], 0, -p[0], 0, -1, 0}, {-p[1], p[0], 0, 0, 0, -1}};  // -[-skew(p), I]
+    accumulate_edge<3>(J, err, (double)E.binf[k] * E.wb, robust, delta, acc);
   }
   const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
@@ -392,6 +383,7 @@ int fb_pose_opt_batch_dev(const fb_pose_opt_args *A, void *stream) {
   if (lds > 140 * 1024) { staged = 0; lds = flags; }
   if (lds > 140 * 1024) { fb::set_error("fb_pose_opt: too many edges per frame for LDS flags"); return FB_ERR_CAPACITY; }
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pose_opt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  fb::ProfScope prof_(fb::P_POSE, fb::as_stream(stream));
   k_pose_opt<<<A->batch, POSE_THREADS, lds, fb::as_stream(stream)>>>(*A, staged);
   FB_HIP(hipGetLastError());
   return FB_OK;
@@ -440,6 +432,7 @@ int fb_pose_gather_front_dev(int batch, int kp_stride, int mp_stride, const int3
   memset(&G, 0, sizeof(G));
   G.nlevels = nlevels;
   for (int i = 0; i < nlevels; i++) G.inv_sigma2[i] = inv_level_sigma2[i];
+  fb::ProfScope prof_(fb::P_GATHER, fb::as_stream(stream));
   k_gather_front<<<dim3((kp_stride + 255) / 256, batch), 256, 0, fb::as_stream(stream)>>>(
       kp_stride, mp_stride, d_n, d_kps, d_match, d_mp_xw, G, d_front_xw, d_front_obs, d_front_inv_sigma2, d_front_valid);
   FB_HIP(hipGetLastError());
@@ -457,6 +450,7 @@ int fb_pose_gather_bird_dev(int batch, int kp_stride, int mp_stride, const int32
   memset(&G, 0, sizeof(G));
   G.nlevels = nlevels;
   for (int i = 0; i < nlevels; i++) G.inv_sigma2[i] = inv_level_sigma2[i];
+  fb::ProfScope prof_(fb::P_GATHER, fb::as_stream(stream));
   k_gather_bird<<<dim3((kp_stride + 255) / 256, batch), 256, 0, fb::as_stream(stream)>>>(
       kp_stride, mp_stride, d_n, d_kps, d_cam_xyz, d_match, d_mpb_xw, G, d_bird_xw, d_bird_xc, d_bird_inv_sigma2, d_bird_valid);
   FB_HIP(hipGetLastError());

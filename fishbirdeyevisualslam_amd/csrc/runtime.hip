@@ -23,9 +23,63 @@ int check_device() {
   return FB_OK;
 }
 
+bool g_prof_on = false;
+namespace {
+const char *kProfNames[P_COUNT] = {"k_resize", "k_fast", "k_octree", "k_describe", "k_grid_build", "k_bird_keys_to_cam",
+                                   "k_descriptor_distance", "k_proj_frame", "k_proj_points", "k_bird_mappoints",
+                                   "k_birdview", "k_pose_opt", "k_pose_gather", "k_ba_linearize", "k_ba_schur",
+                                   "k_ba_solve", "k_ba_update", "k_ba_misc"};
+struct ProfRec { int id; hipEvent_t a, b; };
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t take_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+
+void prof_begin(int id, hipStream_t s) {
+  ProfRec r{id, take_event(), take_event()};
+  (void)hipEventRecord(r.a, s);
+  g_recs.push_back(r);
+}
+void prof_end(hipStream_t s) { (void)hipEventRecord(g_recs.back().b, s); }
+
 }  // namespace fb
 
 extern "C" {
+
+int fb_prof_enable(int on) { fb::g_prof_on = on != 0; return FB_OK; }
+
+int fb_prof_reset(void) {
+  for (auto &r : fb::g_recs) { fb::g_pool.push_back(r.a); fb::g_pool.push_back(r.b); }
+  fb::g_recs.clear();
+  return FB_OK;
+}
+
+int fb_prof_report(fb_prof_entry *out, int cap) {
+  double tot[fb::P_COUNT] = {0};
+  int cnt[fb::P_COUNT] = {0};
+  for (auto &r : fb::g_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    tot[r.id] += ms;
+    cnt[r.id]++;
+  }
+  int n = 0;
+  for (int i = 0; i < fb::P_COUNT && n < cap; i++) {
+    if (!cnt[i]) continue;
+    memset(&out[n], 0, sizeof(out[n]));
+    strncpy(out[n].name, fb::kProfNames[i], sizeof(out[n].name) - 1);
+    out[n].launches = cnt[i];
+    out[n].total_ms = tot[i];
+    n++;
+  }
+  return n;
+}
 
 int fb_abi_version(void) { return FB_ABI_VERSION; }
 

@@ -41,11 +41,11 @@ def build_grid_host(kps_list, geom, grid_fn, stride=None):
     return cs, ci
 
 
-def proj_frame_args(problems, cell_start, cell_items, th=15.0, nnratio=0.9, check_ori=1):
+def proj_frame_args(problems, cell_start, cell_items, th=15.0, nnratio=0.9, check_ori=1, cur_stride=None, scale_factors=None):
     """fb_proj_frame_args from a list of synth.make_proj_frame_problem dicts."""
     B = len(problems)
     p0 = problems[0]
-    cs_ = max(len(p["cur_kps"]) for p in problems)
+    cs_ = cur_stride or max(len(p["cur_kps"]) for p in problems)
     ls_ = max(len(p["last_xw"]) for p in problems)
     assert cell_items.shape == (B, cs_)
     keep = dict(
@@ -69,16 +69,16 @@ def proj_frame_args(problems, cell_start, cell_items, th=15.0, nnratio=0.9, chec
     fill(a.cam, fx=p0["fx"], fy=p0["fy"], cx=p0["cx"], cy=p0["cy"], min_x=0.0, min_y=0.0, max_x=float(p0["w"]),
          max_y=float(p0["h"]))
     fill(a.grid, **synth.front_grid_geom(p0["w"], p0["h"]))
-    sf = synth.scale_tables()[0]
+    sf = synth.scale_tables()[0] if scale_factors is None else scale_factors
     fill(a, scale_factors=[float(x) for x in sf])
     fill(a.matcher, nnratio=nnratio, check_orientation=check_ori)
     return a, out, keep
 
 
-def bird_mp_args(problems, cell_start, cell_items, window=10, filter_size=0.05, nnratio=0.9, prefill=-1):
+def bird_mp_args(problems, cell_start, cell_items, window=10, filter_size=0.05, nnratio=0.9, prefill=-1, cur_stride=None):
     B = len(problems)
     p0 = problems[0]
-    cs_ = max(len(p["cur_kps"]) for p in problems)
+    cs_ = cur_stride or max(len(p["cur_kps"]) for p in problems)
     rs_ = max(len(p["ref_xw"]) for p in problems)
     keep = dict(
         n_cur=np.array([len(p["cur_kps"]) for p in problems], np.int32),

@@ -44,6 +44,19 @@ const char *fb_last_error(void);
 int fb_device_count(void);
 int fb_set_device(int device);
 
+/* ---- per-kernel timing (HIP events on the launch stream) ------------------- */
+/* When enabled every kernel launch of this library is bracketed by two hipEvents
+ * recorded on the stream it is launched on; fb_prof_report synchronises and
+ * returns launches and total milliseconds per kernel since fb_prof_reset.      */
+typedef struct fb_prof_entry {
+  char name[32];
+  int32_t launches;
+  double total_ms;
+} fb_prof_entry;
+int fb_prof_enable(int on);
+int fb_prof_reset(void);
+int fb_prof_report(fb_prof_entry *out, int cap); /* returns the number of entries written */
+
 /* cv::KeyPoint as POD (ORBextractor.cc:837-847: pt, size, angle, response, octave) */
 typedef struct fb_keypoint {
   float x, y;

@@ -1,78 +1,3 @@
-"""Loader for the CPU oracle (oracle/_build/liboracle.so) -- test infrastructure only."""
-import ctypes as C
-import os
-import subprocess
-
-import numpy as np
-
-from fishbirdeyevisualslam_amd import cabi
-
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_LIB = None
-
-
-def lib():
-    global _LIB
-    if _LIB is None:
-        so = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
-        if not os.path.exists(so):
-            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
-        _LIB = C.CDLL(so)
-    return _LIB
-
-
-def orb_params(**kw):
-    from fishbirdeyevisualslam_amd import synth
-    d = dict(synth.ORB_DEFAULT)
-    d.update(kw)
-    return cabi.OrbParams(**d)
-
-
-def orb_tables(params):
-    t = cabi.OrbTables()
-    assert lib().orc_orb_tables(C.byref(params), C.byref(t)) == 0
-    return t
-
-
-def orb_extract(params, img):
-    img = np.ascontiguousarray(img)
-    h, w = img.shape
-    cap = params.nfeatures + 8 * params.nlevels
-    kps = np.zeros(cap, cabi.KP_DTYPE)
-    desc = np.zeros((cap, 32), np.uint8)
-    n = C.c_int32(0)
-    rc = lib().orc_orb_extract(C.byref(params), C.c_void_p(img.ctypes.data), w, h, w, C.c_void_p(kps.ctypes.data),
-                               C.c_void_p(desc.ctypes.data), C.byref(n))
-    assert rc == 0, rc
-    return kps[: n.value].copy(), desc[: n.value].copy()
-
-
-def orb_level(params, img, level):
-    img = np.ascontiguousarray(img)
-    h, w = img.shape
-    lw, lh = C.c_int(0), C.c_int(0)
-    buf = np.zeros(w * h, np.uint8)
-    lib().orc_orb_level(C.byref(params), C.c_void_p(img.ctypes.data), w, h, w, level, C.c_void_p(buf.ctypes.data),
-                        C.byref(lw), C.byref(lh))
-    return buf[: lw.value * lh.value].reshape(lh.value, lw.value).copy()
-
-
-def orb_candidates(params, img, level, cap=400000):
-    img = np.ascontiguousarray(img)
-    h, w = img.shape
-    xyr = np.zeros((cap, 3), np.int32)
-    n = lib().orc_orb_candidates(C.byref(params), C.c_void_p(img.ctypes.data), w, h, w, level,
-                                 C.c_void_p(xyr.ctypes.data), cap)
-    assert n <= cap
-    return xyr[:n].copy()
-
-
-def grid_build(kps, n, batch, stride, geom, cs, ci):
-    rc = lib().orc_grid_build(C.c_void_p(kps.ctypes.data), C.c_void_p(n.ctypes.data), batch, stride, C.byref(geom),
-                              C.c_void_p(cs.ctypes.data), C.c_void_p(ci.ctypes.data))
-    assert rc == 0
-
-
-def call(name, args):
-    rc = getattr(lib(), name)(C.byref(args))
-    assert rc == 0, (name, rc)
+"""Re-export of the oracle loader (oracle/pyoracle.py) for the tests."""
+from oracle.pyoracle import *  # noqa: F401,F403
+from oracle.pyoracle import lib, call, grid_build, orb_params, orb_tables, orb_extract, orb_level, orb_candidates, frame_pipeline  # noqa: F401
