@@ -1,9 +1,896 @@
-// ba.hip -- Optimizer::LocalBundleAdjustment / LocalBundleAdjustmentWithOdom (placeholder until the
-// Schur kernels land later in this round; fails loudly, never silently succeeds).
+// ba.hip -- Optimizer::LocalBundleAdjustment / LocalBundleAdjustmentWithOdom on gfx950.
+//
+// Replaces (reference file:line):
+//   Optimizer::LocalBundleAdjustment            src/Optimizer.cc:838-1165
+//   Optimizer::LocalBundleAdjustmentWithOdom    src/Optimizer.cc:2137-2670
+//   EdgeSE3ProjectXYZ                           Thirdparty/g2o/g2o/types/types_six_dof_expmap.cpp:103-147
+//   EdgeSE3ProjectXYZ2UVQuat / 2XYZQuat / EdgeSE3Quat   src/OdomG2oTypeQuat.cc:109-212
+//   BaseBinaryEdge::constructQuadraticForm      Thirdparty/g2o/g2o/core/base_binary_edge.hpp:55-120
+//   BlockSolver::solve (Schur complement)       core/block_solver.hpp:354-486
+//   OptimizationAlgorithmLevenberg::solve       core/optimization_algorithm_levenberg.cpp:61-164
+//
+// Kernels per LM evaluation (all fp64 like g2o):
+//   k_ba_linearize  one lane per landmark: residuals, Huber weights, Hll (3x3), bl, and the 6x3
+//                   pose-landmark blocks W_e of its edges; per-block partial chi2
+//   k_ba_pose       one workgroup per free keyframe: Hpp diagonal block + bp (wave-shuffle reduce)
+//   k_ba_odom       pose-pose EdgeSE3Quat blocks (few edges) added into the dense Hpp
+// and per LM trial (given lambda):
+//   k_ba_schur      THE MFMA KERNEL: S_part = sum_l (W_l D_l^-1) W_l^T and the reduced rhs, as dense
+//                   LDS panels (6n x 3c per chunk of c landmarks) multiplied with
+//                   v_mfma_f64_16x16x4_f64; upper-triangular 16x16 tiles only, like g2o
+//   k_ba_solve      S = Hpp + lambda I - sum S_part, dense LDL^T in LDS, triangular solves in one wave
+//   k_ba_update     landmark back-substitution, exp-map pose update, trial state, scale term
+// The accept/reject logic of Levenberg-Marquardt runs on the host between trials (a few scalars
+// are read back per trial); the abort flag (pbStopFlag) is polled there, between iterations.
 #include "fb_common.h"
+#include "fb_se3.h"
 
-extern "C" int fb_local_ba(const fb_local_ba_args *args) {
-  (void)args;
-  fb::set_error("fb_local_ba: not implemented yet in this build");
-  return FB_ERR_ARG;
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+
+using fb::SE3;
+
+constexpr int T_PROJ = 0, T_XYZ = 1;
+constexpr int LIN_THREADS = 128;
+constexpr int POSE_THREADS = 256;
+constexpr int SCHUR_THREADS = 256;
+constexpr int SOLVE_THREADS = 1024;
+constexpr int CHUNK = 16;  // landmarks per MFMA panel (K = 48)
+constexpr int KP = 3 * CHUNK;
+constexpr int KPAD = KP + 2;  // LDS row stride in doubles (breaks the 2-way bank conflict of stride 48)
+
+struct BADev {  // device pointers + sizes, passed by value
+  int n_kf, np, npt, nE, nO, quat;
+  double fx, fy, cx, cy, delta;
+  const int *poseIdx;          // [n_kf] free index or -1
+  const int *e_pt, *e_kf;      // [nE]
+  const uint8_t *e_type;       // [nE]
+  const double *e_meas;        // [nE][3]
+  const double *e_info;        // [nE]
+  uint8_t *e_level;            // [nE]
+  double *e_chi2;              // [nE] chi2 of the last evaluation that covered the edge
+  const int *lm_start, *lm_edges;  // CSR by landmark
+  const int *ps_start, *ps_edges;  // CSR by free pose
+  const int *o_i, *o_j;        // [nO]
+  const SE3 *o_Zinv;           // [nO]
+  const double *o_info;        // [nO]
+};
+
+struct LinBuf {  // linearisation at one state
+  double *Hll;   // [npt][9]
+  double *bl;    // [npt][3]
+  double *W;     // [nE][18]
+  double *Hpp;   // [P6][P6] dense
+  double *bp;    // [P6]
+  double *chiPart;  // [nLinBlocks + 1] (last = odom chi2)
+};
+
+struct State {
+  SE3 *pose;     // [n_kf]
+  double *pt;    // [npt][3]
+};
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// residual + Jacobians of one point-pose edge (vertex 0 = point, vertex 1 = pose)
+struct EdgeLin {
+  double err[3];
+  double Ji[3][3];  // d err / d point
+  double Jj[3][6];  // d err / d pose
+};
+
+__device__ __forceinline__ void edge_residual(const BADev &D, int type, const SE3 &T, const double *X, const double *meas,
+                                              double p[3], double err[3]) {
+  fb::se3_map(T, X, p);
+  if (type == T_PROJ) {
+    if (D.quat) {  // OdomG2oTypeQuat.cc:138-144
+      err[0] = meas[0] - (D.fx * p[0] / p[2] + D.cx);
+      err[1] = meas[1] - (D.fy * p[1] / p[2] + D.cy);
+    } else {       // types_six_dof_expmap.cpp:141-147
+      err[0] = meas[0] - ((p[0] / p[2]) * D.fx + D.cx);
+      err[1] = meas[1] - ((p[1] / p[2]) * D.fy + D.cy);
+    }
+    err[2] = 0;
+  } else {
+    err[0] = meas[0] - p[0]; err[1] = meas[1] - p[1]; err[2] = meas[2] - p[2];
+  }
+}
+
+__device__ __forceinline__ void edge_jacobians(const BADev &D, int type, const SE3 &T, const double p[3], EdgeLin &L) {
+  double R[9];
+  fb::quat_to_R(T.r, R);
+  const double X = p[0], Y = p[1], Z = p[2];
+  if (type == T_PROJ) {
+    if (D.quat) {  // EdgeSE3ProjectXYZ2UVQuat::linearizeOplus, OdomG2oTypeQuat.cc:109-129
+      const double z2 = Z * Z;
+      const double jep[2][3] = {{-(D.fx / Z), -0.0, -(-D.fx * X / z2)}, {-0.0, -(D.fy / Z), -(-D.fy * Y / z2)}};
+      const double jpk[3][6] = {{-0.0, Z, -Y, 1, 0, 0}, {-Z, -0.0, X, 0, 1, 0}, {Y, -X, -0.0, 0, 0, 1}};  // [-skew(p), I]
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) L.Jj[r][c] = jep[r][0] * jpk[0][c] + jep[r][1] * jpk[1][c] + jep[r][2] * jpk[2][c];
+#pragma unroll
+        for (int c = 0; c < 3; c++) L.Ji[r][c] = jep[r][0] * R[c] + jep[r][1] * R[3 + c] + jep[r][2] * R[6 + c];
+      }
+    } else {  // EdgeSE3ProjectXYZ::linearizeOplus, types_six_dof_expmap.cpp:103-139
+      const double z_2 = Z * Z;
+      const double tmp[2][3] = {{D.fx, 0, -X / Z * D.fx}, {0, D.fy, -Y / Z * D.fy}};
+      const double s = -1. / Z;
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) L.Ji[r][c] = (s * tmp[r][0]) * R[c] + (s * tmp[r][1]) * R[3 + c] + (s * tmp[r][2]) * R[6 + c];
+      L.Jj[0][0] = X * Y / z_2 * D.fx; L.Jj[0][1] = -(1 + (X * X / z_2)) * D.fx; L.Jj[0][2] = Y / Z * D.fx;
+      L.Jj[0][3] = -1. / Z * D.fx;     L.Jj[0][4] = 0;                            L.Jj[0][5] = X / z_2 * D.fx;
+      L.Jj[1][0] = (1 + Y * Y / z_2) * D.fy; L.Jj[1][1] = -X * Y / z_2 * D.fy;   L.Jj[1][2] = -X / Z * D.fy;
+      L.Jj[1][3] = 0;                  L.Jj[1][4] = -1. / Z * D.fy;               L.Jj[1][5] = Y / z_2 * D.fy;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++) L.Jj[2][c] = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) L.Ji[2][c] = 0;
+  } else {  // EdgeSE3ProjectXYZ2XYZQuat::linearizeOplus, OdomG2oTypeQuat.cc:157-169
+    const double jj[3][6] = {{0, -Z, Y, -1, -0.0, -0.0}, {Z, 0, -X, -0.0, -1, -0.0}, {-Y, X, 0, -0.0, -0.0, -1}};
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) L.Jj[r][c] = jj[r][c];
+#pragma unroll
+      for (int c = 0; c < 3; c++) L.Ji[r][c] = -R[r * 3 + c];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ba_linearize: one lane per landmark
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BADev D, State S, LinBuf B, int robust) {
+  __shared__ double s_part[LIN_THREADS / 64];
+  const int l = blockIdx.x * LIN_THREADS + threadIdx.x;
+  double chi = 0;
+  if (l < D.npt) {
+    const double X[3] = {S.pt[3 * l], S.pt[3 * l + 1], S.pt[3 * l + 2]};
+    double H[9], b3[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 9; i++) H[i] = 0;
+    for (int c = D.lm_start[l]; c < D.lm_start[l + 1]; c++) {
+      const int e = D.lm_edges[c];
+      double *W = B.W + (size_t)e * 18;
+      const int kf = D.e_kf[e];
+      const int pj = D.poseIdx[kf];
+      if (D.e_level[e] != 0) {
+#pragma unroll
+        for (int i = 0; i < 18; i++) W[i] = 0;
+        continue;
+      }
+      const int type = D.e_type[e];
+      const SE3 T = S.pose[kf];
+      const double meas[3] = {D.e_meas[3 * e], D.e_meas[3 * e + 1], D.e_meas[3 * e + 2]};
+      double p[3];
+      EdgeLin L;
+      edge_residual(D, type, T, X, meas, p, L.err);
+      edge_jacobians(D, type, T, p, L);
+      const double info = D.e_info[e];
+      double chi2 = 0;
+#pragma unroll
+      for (int r = 0; r < 3; r++) chi2 += L.err[r] * (info * L.err[r]);
+      D.e_chi2[e] = chi2;
+      double rho0 = chi2, rho1 = 1.;
+      if (robust) fb::huber(chi2, D.delta, rho0, rho1);
+      chi += rho0;
+      const double w = rho1 * info;
+      double orr[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) orr[r] = -(info * L.err[r]) * rho1;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        double s = 0;
+#pragma unroll
+        for (int r = 0; r < 3; r++) s += L.Ji[r][i] * orr[r];
+        b3[i] += s;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          double h = 0;
+#pragma unroll
+          for (int r = 0; r < 3; r++) h += L.Ji[r][i] * w * L.Ji[r][j];
+          H[3 * i + j] += h;
+        }
+      }
+      if (pj >= 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            double h = 0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) h += L.Jj[r][i] * w * L.Ji[r][j];
+            W[i * 3 + j] = h;
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 18; i++) W[i] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) B.Hll[(size_t)9 * l + i] = H[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) B.bl[(size_t)3 * l + i] = b3[i];
+  }
+  const double ws = wave_sum_d(chi);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (int i = 0; i < LIN_THREADS / 64; i++) s += s_part[i];
+    B.chiPart[blockIdx.x] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ba_pose: one workgroup per free keyframe -> Hpp(k,k) and bp(k)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(POSE_THREADS) void k_ba_pose(BADev D, State S, LinBuf B, int robust, int P6) {
+  __shared__ double s_part[POSE_THREADS / 64][27];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  double acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; i++) acc[i] = 0;
+  for (int c = D.ps_start[k] + tid; c < D.ps_start[k + 1]; c += POSE_THREADS) {
+    const int e = D.ps_edges[c];
+    if (D.e_level[e] != 0) continue;
+    const int type = D.e_type[e], l = D.e_pt[e];
+    const SE3 T = S.pose[D.e_kf[e]];
+    const double X[3] = {S.pt[3 * l], S.pt[3 * l + 1], S.pt[3 * l + 2]};
+    const double meas[3] = {D.e_meas[3 * e], D.e_meas[3 * e + 1], D.e_meas[3 * e + 2]};
+    double p[3];
+    EdgeLin L;
+    edge_residual(D, type, T, X, meas, p, L.err);
+    edge_jacobians(D, type, T, p, L);
+    const double info = D.e_info[e];
+    double chi2 = 0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) chi2 += L.err[r] * (info * L.err[r]);
+    double rho0 = chi2, rho1 = 1.;
+    if (robust) fb::huber(chi2, D.delta, rho0, rho1);
+    const double w = rho1 * info;
+    int h = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double s = 0;
+#pragma unroll
+      for (int r = 0; r < 3; r++) s += L.Jj[r][i] * (-(info * L.err[r]) * rho1);
+      acc[21 + i] += s;
+#pragma unroll
+      for (int j = i; j < 6; j++) {
+        double v = 0;
+#pragma unroll
+        for (int r = 0; r < 3; r++) v += L.Jj[r][i] * w * L.Jj[r][j];
+        acc[h] += v;
+        h++;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 27; i++) {
+    const double s = wave_sum_d(acc[i]);
+    if ((tid & 63) == 0) s_part[tid >> 6][i] = s;
+  }
+  __syncthreads();
+  if (tid < 27) {
+    double s = 0;
+    for (int w2 = 0; w2 < POSE_THREADS / 64; w2++) s += s_part[w2][tid];
+    s_part[0][tid] = s;
+  }
+  __syncthreads();
+  if (tid < 36) {
+    const int i = tid / 6, j = tid % 6;
+    const int a = i < j ? i : j, b2 = i < j ? j : i;
+    const int idx = a * 6 - a * (a - 1) / 2 + (b2 - a);  // upper-triangular packing
+    B.Hpp[(size_t)(6 * k + i) * P6 + 6 * k + j] = s_part[0][idx];
+  }
+  if (tid < 6) B.bp[6 * k + tid] = s_part[0][21 + tid];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ba_odom: EdgeSE3Quat (OdomG2oTypeQuat.cc:180-204). Phase a: one lane per edge computes the
+// residual and Jacobians into LDS; phase b: one lane per (free pose, row) adds the blocks into Hpp
+// in edge order (deterministic).
+// ------------------------------------------------------------------------------------------
+struct OdomLin { double A[36], Bm[36], err[6]; };
+
+__global__ __launch_bounds__(256) void k_ba_odom(BADev D, State S, LinBuf B, int P6, int chiSlot) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  OdomLin *ol = reinterpret_cast<OdomLin *>(smem);
+  __shared__ double s_chi[256];
+  const int tid = threadIdx.x;
+  double chi = 0;
+  for (int e = tid; e < D.nO; e += 256) {
+    const SE3 T1 = S.pose[D.o_i[e]], T2 = S.pose[D.o_j[e]];
+    const SE3 d = fb::se3_mul(fb::se3_mul(D.o_Zinv[e], T1), fb::se3_inverse(T2));
+    double er[6];
+    fb::se3_log(d, er);
+    double J[36], a2[36], a1[36], t1[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) J[i] = 0;
+    const double w0 = er[0], w1 = er[1], w2 = er[2], u0 = er[3], u1 = er[4], u2 = er[5];
+    // JRInv: 0.5*[[skew(w),0],[skew(u),skew(w)]] + I
+    J[1] = -w2; J[2] = w1; J[6] = w2; J[8] = -w0; J[12] = -w1; J[13] = w0;
+    J[21 + 1] = -w2; J[21 + 2] = w1; J[27] = w2; J[27 + 2] = -w0; J[33] = -w1; J[33 + 1] = w0;
+    J[18 + 1] = -u2; J[18 + 2] = u1; J[24] = u2; J[24 + 2] = -u0; J[30] = -u1; J[30 + 1] = u0;
+#pragma unroll
+    for (int i = 0; i < 36; i++) J[i] = 0.5 * J[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) J[i * 6 + i] += 1.0;
+    fb::se3_adj(T2, a2);
+    fb::se3_adj(fb::se3_inverse(T1), a1);
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) {
+        double s = 0;
+        for (int k = 0; k < 6; k++) s += J[i * 6 + k] * a2[k * 6 + j];
+        t1[i * 6 + j] = s;
+      }
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) {
+        double s = 0;
+        for (int k = 0; k < 6; k++) s += t1[i * 6 + k] * a1[k * 6 + j];
+        ol[e].A[i * 6 + j] = s;
+      }
+    for (int i = 0; i < 36; i++) ol[e].Bm[i] = -J[i];
+    const double info = D.o_info[e];
+    const bool act = !(D.poseIdx[D.o_i[e]] < 0 && D.poseIdx[D.o_j[e]] < 0);  // allVerticesFixed edges are not active
+    for (int i = 0; i < 6; i++) { ol[e].err[i] = er[i]; if (act) chi += er[i] * (info * er[i]); }
+  }
+  s_chi[tid] = chi;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0;
+    for (int i = 0; i < 256; i++) s += s_chi[i];
+    B.chiPart[chiSlot] = s;
+  }
+  // phase b: lane (k, i) = row i of free pose k
+  for (int row = tid; row < P6; row += 256) {
+    const int k = row / 6, i = row % 6;
+    for (int e = 0; e < D.nO; e++) {
+      const int pi = D.poseIdx[D.o_i[e]], pj = D.poseIdx[D.o_j[e]];
+      if (pi != k && pj != k) continue;
+      const double info = D.o_info[e];
+      const OdomLin &o = ol[e];
+      // this row belongs to vertex i (Jacobian A) or vertex j (Jacobian Bm)
+      const double *Mine = (pi == k) ? o.A : o.Bm;
+      double bsum = 0;
+      for (int r = 0; r < 6; r++) bsum += Mine[r * 6 + i] * (-(info * o.err[r]));
+      B.bp[row] += bsum;
+      for (int side = 0; side < 2; side++) {
+        const int pc = side == 0 ? pi : pj;
+        if (pc < 0) continue;
+        const double *Oth = side == 0 ? o.A : o.Bm;
+        for (int j = 0; j < 6; j++) {
+          double s = 0;
+          for (int r = 0; r < 6; r++) s += Mine[r * 6 + i] * info * Oth[r * 6 + j];
+          B.Hpp[(size_t)row * P6 + 6 * pc + j] += s;
+        }
+      }
+      if (pi == k && pj == k) {  // degenerate self edge: also the Bm rows
+        double b2 = 0;
+        for (int r = 0; r < 6; r++) b2 += o.Bm[r * 6 + i] * (-(info * o.err[r]));
+        B.bp[row] += b2;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ba_schur: MFMA fp64 accumulation of the Schur complement.
+//   C[NT*16][NT*16] (upper tiles) += Yp[rows][K] * Wp[rows][K]^T over chunks of CHUNK landmarks,
+//   Yp = W_e * Dinv_l scattered at rows 6*pose.., columns 3*li..; Wp likewise with W_e;
+//   Wp row P6 carries bl so that column P6 of C is the reduced right-hand side (coefficients).
+// v_mfma_f64_16x16x4_f64 operand layout (lane L): a = A[L%16][L/16], b = B[L/16][L%16],
+// c[r] = C[(L/16)+4*r][L%16]  (measured on gfx950, scratch probe; not the f32 16x16x4 layout).
+// ------------------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+template <int MAXT>  // accumulator tiles per wave (compile-time so the C tiles stay in registers)
+__global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BADev D, LinBuf B, double lambda, double *Dinv, double *Spart,
+                                                            int P6, int NT, int lmPerWg) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int rows = NT * 16;
+  double *Yp = reinterpret_cast<double *>(smem);  // [rows][KPAD]
+  double *Wp = Yp + (size_t)rows * KPAD;           // [rows][KPAD]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l0 = blockIdx.x * lmPerWg, l1 = min(l0 + lmPerWg, D.npt);
+  // upper-triangular tiles, dealt round-robin to the 4 waves
+  const int nTiles = NT * (NT + 1) / 2;
+  double4_t acc[MAXT];
+#pragma unroll
+  for (int t = 0; t < MAXT; t++) acc[t] = (double4_t){0, 0, 0, 0};
+  for (int c0 = l0; c0 < l1; c0 += CHUNK) {
+    for (int i = tid; i < 2 * rows * KPAD; i += SCHUR_THREADS) Yp[i] = 0;
+    __syncthreads();
+    // one lane per landmark of the chunk: Dinv, then scatter its edges' blocks
+    if (tid < CHUNK && c0 + tid < l1) {
+      const int l = c0 + tid;
+      double M[9];
+#pragma unroll
+      for (int i = 0; i < 9; i++) M[i] = B.Hll[(size_t)9 * l + i];
+      M[0] += lambda; M[4] += lambda; M[8] += lambda;
+      const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+      const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+      const double id = 1.0 / det;
+      double Di[9];
+      Di[0] = c00 * id; Di[1] = (M[2] * M[7] - M[1] * M[8]) * id; Di[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+      Di[3] = c01 * id; Di[4] = (M[0] * M[8] - M[2] * M[6]) * id; Di[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+      Di[6] = c02 * id; Di[7] = (M[1] * M[6] - M[0] * M[7]) * id; Di[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+#pragma unroll
+      for (int i = 0; i < 9; i++) Dinv[(size_t)9 * l + i] = Di[i];
+#pragma unroll
+      for (int c = 0; c < 3; c++) Wp[(size_t)P6 * KPAD + 3 * tid + c] = B.bl[(size_t)3 * l + c];
+      for (int cc = D.lm_start[l]; cc < D.lm_start[l + 1]; cc++) {
+        const int e = D.lm_edges[cc];
+        const int pj = D.poseIdx[D.e_kf[e]];
+        if (pj < 0 || D.e_level[e] != 0) continue;
+        const double *W = B.W + (size_t)e * 18;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          const double w0 = W[i * 3], w1 = W[i * 3 + 1], w2 = W[i * 3 + 2];
+          double *yr = Yp + (size_t)(6 * pj + i) * KPAD + 3 * tid;
+          double *wr = Wp + (size_t)(6 * pj + i) * KPAD + 3 * tid;
+          wr[0] = w0; wr[1] = w1; wr[2] = w2;
+          yr[0] = w0 * Di[0] + w1 * Di[3] + w2 * Di[6];
+          yr[1] = w0 * Di[1] + w1 * Di[4] + w2 * Di[7];
+          yr[2] = w0 * Di[2] + w1 * Di[5] + w2 * Di[8];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+      const int tile = wv + 4 * t;
+      if (tile < nTiles) {
+        // tile -> (ti, tj), ti <= tj
+        int ti = 0, rem = tile;
+        while (rem >= NT - ti) { rem -= NT - ti; ti++; }
+        const int tj = ti + rem;
+        const double *ya = Yp + (size_t)(ti * 16 + (lane & 15)) * KPAD + (lane >> 4);
+        const double *wb = Wp + (size_t)(tj * 16 + (lane & 15)) * KPAD + (lane >> 4);
+        double4_t c = acc[t];
+#pragma unroll
+        for (int k0 = 0; k0 < KP; k0 += 4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[k0], wb[k0], c, 0, 0, 0);
+        acc[t] = c;
+      }
+    }
+    __syncthreads();
+  }
+  // write this workgroup's partial (upper tiles) : Spart[wg][rows][rows]
+  double *out = Spart + (size_t)blockIdx.x * rows * rows;
+#pragma unroll
+  for (int t = 0; t < MAXT; t++) {
+    const int tile = wv + 4 * t;
+    if (tile < nTiles) {
+      int ti = 0, rem = tile;
+      while (rem >= NT - ti) { rem -= NT - ti; ti++; }
+      const int tj = ti + rem;
+#pragma unroll
+      for (int r = 0; r < 4; r++) out[(size_t)(ti * 16 + (lane >> 4) + 4 * r) * rows + tj * 16 + (lane & 15)] = acc[t][r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ba_solve: reduce partials, S = Hpp + lambda I - sum, LDL^T (no pivoting) and solves.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lambda, const double *Spart, int nWg, int P6,
+                                                            int NT, double *xp, int *okFlag) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  double *A = reinterpret_cast<double *>(smem);  // [P6][P6+1] lower triangle used
+  const int ld = P6 + 1;
+  double *rhs = A + (size_t)P6 * ld;             // [P6]
+  __shared__ int s_ok;
+  const int tid = threadIdx.x, rows = NT * 16;
+  if (tid == 0) s_ok = 1;
+  for (int idx = tid; idx < P6 * P6; idx += SOLVE_THREADS) {
+    const int i = idx / P6, j = idx % P6;
+    if (j > i) continue;  // lower triangle: A[i][j] = S[j][i] (upper, as g2o's solver reads it)
+    double s = 0;
+    for (int w = 0; w < nWg; w++) s += Spart[(size_t)w * rows * rows + (size_t)j * rows + i];
+    double h = B.Hpp[(size_t)j * P6 + i];
+    if (i == j) h += lambda;
+    A[(size_t)i * ld + j] = h - s;
+  }
+  for (int i = tid; i < P6; i += SOLVE_THREADS) {
+    double s = 0;
+    for (int w = 0; w < nWg; w++) s += Spart[(size_t)w * rows * rows + (size_t)i * rows + P6];
+    rhs[i] = B.bp[i] - s;
+  }
+  __syncthreads();
+  // right-looking LDL^T: column j is final after step j-1; the scaled L is never stored
+  // (L[i][j] = A[i][j] / A[j][j]).  One barrier per column.
+  for (int j = 0; j < P6; j++) {
+    const double dj = A[(size_t)j * ld + j];
+    if (dj < 0 && tid == 0) s_ok = 0;
+    const double inv = dj != 0 ? 1.0 / dj : 0.0;
+    const int m = P6 - 1 - j;  // trailing size
+    for (int idx = tid; idx < m * (m + 1) / 2; idx += SOLVE_THREADS) {
+      // idx -> (r >= c) in the trailing lower triangle
+      int r = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+      while ((r + 1) * (r + 2) / 2 <= idx) r++;
+      while (r * (r + 1) / 2 > idx) r--;
+      const int c = idx - r * (r + 1) / 2;
+      const int i = j + 1 + r, k = j + 1 + c;
+      A[(size_t)i * ld + k] -= A[(size_t)i * ld + j] * inv * A[(size_t)k * ld + j];
+    }
+    __syncthreads();
+  }
+  // triangular solves by wave 0: lane owns rows lane, lane+64, ...
+  if (tid < 64) {
+    constexpr int RPL = 4;  // rows per lane, P6 <= 256
+    double y[RPL];
+#pragma unroll
+    for (int q = 0; q < RPL; q++) y[q] = (tid + 64 * q < P6) ? rhs[tid + 64 * q] : 0.0;
+    for (int i = 0; i < P6; i++) {  // forward: L y = b
+      const double yi = __shfl(y[i >> 6], i & 63, 64);
+      const double di = A[(size_t)i * ld + i];
+      const double inv = di != 0 ? 1.0 / di : 0.0;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        const int r = tid + 64 * q;
+        if (r > i && r < P6) y[q] -= A[(size_t)r * ld + i] * inv * yi;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {  // D^-1
+      const int r = tid + 64 * q;
+      if (r < P6) { const double d = A[(size_t)r * ld + r]; y[q] = d != 0 ? y[q] / d : 0.0; }
+    }
+    for (int i = P6 - 1; i >= 0; i--) {  // backward: L^T x = y
+      const double xi = __shfl(y[i >> 6], i & 63, 64);
+      const double di = A[(size_t)i * ld + i];
+      (void)di;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        const int r = tid + 64 * q;
+        if (r < i) {
+          const double dr = A[(size_t)r * ld + r];
+          const double inv = dr != 0 ? 1.0 / dr : 0.0;
+          y[q] -= A[(size_t)i * ld + r] * inv * xi;  // L[i][r] = A[i][r]/d_r
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+      const int r = tid + 64 * q;
+      if (r < P6) xp[r] = y[q];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) *okFlag = s_ok;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ba_update: back-substitution, trial state, scale term sum x (lambda x + b)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LIN_THREADS) void k_ba_update(BADev D, LinBuf B, State cur, State trial, const double *Dinv,
+                                                           const double *xp, double lambda, double *scalePart) {
+  __shared__ double s_part[LIN_THREADS / 64];
+  const int g = blockIdx.x * LIN_THREADS + threadIdx.x;
+  double sc = 0;
+  if (g < D.npt) {
+    const int l = g;
+    double cl[3] = {B.bl[(size_t)3 * l], B.bl[(size_t)3 * l + 1], B.bl[(size_t)3 * l + 2]};
+    for (int cc = D.lm_start[l]; cc < D.lm_start[l + 1]; cc++) {
+      const int e = D.lm_edges[cc];
+      const int pj = D.poseIdx[D.e_kf[e]];
+      if (pj < 0 || D.e_level[e] != 0) continue;
+      const double *W = B.W + (size_t)e * 18;
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 6; i++) cl[j] -= W[i * 3 + j] * xp[6 * pj + i];
+    }
+    const double *Di = Dinv + (size_t)9 * l;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const double xl = Di[i * 3] * cl[0] + Di[i * 3 + 1] * cl[1] + Di[i * 3 + 2] * cl[2];
+      trial.pt[3 * l + i] = cur.pt[3 * l + i] + xl;
+      sc += xl * (lambda * xl + B.bl[(size_t)3 * l + i]);
+    }
+  } else if (g < D.npt + D.n_kf) {
+    const int k = g - D.npt;
+    const int pi = D.poseIdx[k];
+    if (pi < 0) trial.pose[k] = cur.pose[k];
+    else {
+      double u[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) { u[i] = xp[6 * pi + i]; sc += u[i] * (lambda * u[i] + B.bp[6 * pi + i]); }
+      trial.pose[k] = fb::se3_mul(fb::se3_exp(u), cur.pose[k]);
+    }
+  }
+  const double ws = wave_sum_d(sc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (int i = 0; i < LIN_THREADS / 64; i++) s += s_part[i];
+    scalePart[blockIdx.x] = s;
+  }
+}
+
+// sum of partials in index order + max |diag| (computeLambdaInit)
+__global__ void k_ba_scalars(const double *part, int n, const double *Hpp, int P6, const double *Hll, int npt, double *out,
+                             int wantDiag) {
+  __shared__ double s_m[256];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    double s = 0;
+    for (int i = 0; i < n; i++) s += part[i];
+    out[0] = s;
+  }
+  if (wantDiag) {
+    double m = 0;
+    for (int i = tid; i < P6; i += 256) m = fmax(m, fabs(Hpp[(size_t)i * P6 + i]));
+    for (int i = tid; i < npt * 3; i += 256) m = fmax(m, fabs(Hll[(size_t)9 * (i / 3) + 4 * (i % 3)]));
+    s_m[tid] = m;
+    __syncthreads();
+    if (tid == 0) {
+      double mm = 0;
+      for (int i = 0; i < 256; i++) mm = fmax(mm, s_m[i]);
+      out[1] = mm;
+    }
+  }
+}
+
+// gating between the two optimisation rounds and the final outlier flags
+// (Optimizer.cc:1059-1073,1102-1115 / 2534-2565,2573-2607)
+__global__ void k_ba_gate(BADev D, State S, int setLevel, uint8_t *outFlag) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= D.nE) return;
+  const int type = D.e_type[e], l = D.e_pt[e];
+  const SE3 T = S.pose[D.e_kf[e]];
+  const double X[3] = {S.pt[3 * l], S.pt[3 * l + 1], S.pt[3 * l + 2]};
+  bool bad;
+  if (type == T_PROJ) {
+    double p[3];
+    fb::se3_map(T, X, p);
+    bad = D.e_chi2[e] > 5.991 || !(p[2] > 0.0);
+  } else {
+    if (setLevel) {  // e->computeError() first
+      const double meas[3] = {D.e_meas[3 * e], D.e_meas[3 * e + 1], D.e_meas[3 * e + 2]};
+      double p[3], err[3];
+      edge_residual(D, type, T, X, meas, p, err);
+      const double info = D.e_info[e];
+      D.e_chi2[e] = err[0] * (info * err[0]) + err[1] * (info * err[1]) + err[2] * (info * err[2]);
+    }
+    bad = D.e_chi2[e] > 5.991;
+  }
+  if (setLevel) { if (bad) D.e_level[e] = 1; }
+  else outFlag[e] = bad ? 1 : 0;
+}
+
+__global__ void k_ba_export(int n_kf, int npt, const SE3 *pose, const double *pt, const uint8_t *fixed, float *kfT, float *ptOut) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n_kf) {
+    if (!fixed[g]) fb::se3_to_float12(pose[g], kfT + 12 * g);
+  } else if (g < n_kf + npt * 3) ptOut[g - n_kf] = (float)pt[g - n_kf];
+}
+
+}  // namespace
+
+#define BA_UP(buf, vec) FB_TRY(buf.upload((vec).data(), (vec).size() * sizeof((vec)[0])))
+
+extern "C" int fb_local_ba(const fb_local_ba_args *A) {
+  FB_TRY(fb::check_device());
+  FB_ARG(A && A->n_kf > 0 && A->n_mp >= 0 && A->n_mpb >= 0 && A->n_obs >= 0 && A->kf_Tcw && A->kf_fixed);
+  if (A->stop_flag && *A->stop_flag) return FB_OK;  // Optimizer.cc:902-906 / 2498-2500
+  const bool odom = A->with_odom != 0;
+  const int n_kf = A->n_kf, n_mp = A->n_mp, n_mpb = odom ? A->n_mpb : 0;
+  const int npt = A->n_mp + A->n_mpb;  // bird points keep their slots even when unused
+  const int nF = A->n_obs, nB = odom ? A->n_bobs : 0, nE = nF + nB, nO = odom ? A->n_odom : 0;
+  (void)n_mpb;
+  // ---- host preprocessing: indices, CSR by landmark / pose
+  std::vector<int> poseIdx(n_kf, -1);
+  int np = 0;
+  for (int k = 0; k < n_kf; k++) if (!A->kf_fixed[k]) poseIdx[k] = np++;
+  const int P6 = 6 * np;
+  if (P6 + 1 > 256) { fb::set_error("fb_local_ba: more than 42 free keyframes"); return FB_ERR_CAPACITY; }
+  std::vector<int> e_pt(nE), e_kf(nE);
+  std::vector<uint8_t> e_type(nE), e_level(nE, 0);
+  std::vector<double> e_meas((size_t)nE * 3, 0.0), e_info(nE);
+  for (int i = 0; i < nF; i++) {
+    FB_ARG(A->obs_mp[i] >= 0 && A->obs_mp[i] < n_mp && A->obs_kf[i] >= 0 && A->obs_kf[i] < n_kf);
+    e_pt[i] = A->obs_mp[i]; e_kf[i] = A->obs_kf[i]; e_type[i] = T_PROJ;
+    e_meas[3 * i] = A->obs_uv[2 * i]; e_meas[3 * i + 1] = A->obs_uv[2 * i + 1];
+    e_info[i] = odom ? (1.0 * (double)A->obs_inv_sigma2[i]) * (double)A->wF : (double)A->obs_inv_sigma2[i];
+  }
+  for (int i = 0; i < nB; i++) {
+    FB_ARG(A->bobs_mpb[i] >= 0 && A->bobs_mpb[i] < A->n_mpb && A->bobs_kf[i] >= 0 && A->bobs_kf[i] < n_kf);
+    const int e = nF + i;
+    e_pt[e] = n_mp + A->bobs_mpb[i]; e_kf[e] = A->bobs_kf[i]; e_type[e] = T_XYZ;
+    for (int k = 0; k < 3; k++) e_meas[3 * e + k] = A->bobs_xc[3 * i + k];
+    e_info[e] = (1.0 * (double)A->bobs_inv_sigma2[i]) * (double)A->wB;
+  }
+  std::vector<int> lm_start(npt + 1, 0), lm_edges(nE), ps_start(np + 1, 0), ps_edges;
+  for (int e = 0; e < nE; e++) lm_start[e_pt[e] + 1]++;
+  for (int l = 0; l < npt; l++) lm_start[l + 1] += lm_start[l];
+  {
+    std::vector<int> fill(lm_start.begin(), lm_start.end() - 1);
+    for (int e = 0; e < nE; e++) lm_edges[fill[e_pt[e]]++] = e;
+  }
+  for (int l = 0; l < npt; l++) {  // a keyframe observes a point at most once (map<KeyFrame*,size_t>)
+    std::vector<int> kfs;
+    for (int c = lm_start[l]; c < lm_start[l + 1]; c++) kfs.push_back(e_kf[lm_edges[c]]);
+    std::sort(kfs.begin(), kfs.end());
+    if (std::adjacent_find(kfs.begin(), kfs.end()) != kfs.end()) { fb::set_error("fb_local_ba: duplicate (keyframe, point) observation"); return FB_ERR_ARG; }
+  }
+  for (int e = 0; e < nE; e++) if (poseIdx[e_kf[e]] >= 0) ps_start[poseIdx[e_kf[e]] + 1]++;
+  for (int k = 0; k < np; k++) ps_start[k + 1] += ps_start[k];
+  ps_edges.resize(ps_start[np]);
+  {
+    std::vector<int> fill(ps_start.begin(), ps_start.end() - 1);
+    for (int e = 0; e < nE; e++) if (poseIdx[e_kf[e]] >= 0) ps_edges[fill[poseIdx[e_kf[e]]]++] = e;
+  }
+  std::vector<SE3> poses(n_kf), oZinv(nO);
+  for (int k = 0; k < n_kf; k++) poses[k] = fb::se3_from_float12(A->kf_Tcw + 12 * k);
+  std::vector<double> pts((size_t)npt * 3);
+  for (int i = 0; i < 3 * n_mp; i++) pts[i] = A->mp_xw[i];
+  for (int i = 0; i < 3 * A->n_mpb; i++) pts[3 * n_mp + i] = A->mpb_xw[i];
+  std::vector<int> o_i(nO), o_j(nO);
+  std::vector<double> o_info(nO);
+  for (int i = 0; i < nO; i++) {
+    FB_ARG(A->odom_kf_i[i] >= 0 && A->odom_kf_i[i] < n_kf && A->odom_kf_j[i] >= 0 && A->odom_kf_j[i] < n_kf);
+    o_i[i] = A->odom_kf_i[i]; o_j[i] = A->odom_kf_j[i]; o_info[i] = A->odom_info[i];
+    oZinv[i] = fb::se3_inverse(fb::se3_from_float12(A->odom_Tij + 12 * i));
+  }
+  // ---- device buffers
+  const int NT = (P6 + 1 + 15) / 16;
+  const int rows = NT * 16;
+  const int nLinBlocks = (npt + LIN_THREADS - 1) / LIN_THREADS;
+  const int nUpdBlocks = (npt + n_kf + LIN_THREADS - 1) / LIN_THREADS;
+  int nWg = std::min(128, std::max(1, (npt + CHUNK - 1) / CHUNK));
+  const int lmPerWg = ((npt + nWg - 1) / nWg + CHUNK - 1) / CHUNK * CHUNK;
+  nWg = std::max(1, (npt + lmPerWg - 1) / std::max(lmPerWg, 1));
+  fb::DevBuf d_poseIdx, d_ept, d_ekf, d_etype, d_emeas, d_einfo, d_elevel, d_echi2, d_lms, d_lme, d_pss, d_pse, d_oi, d_oj,
+      d_oz, d_oinfo, d_fixed;
+  BA_UP(d_poseIdx, poseIdx); BA_UP(d_ept, e_pt); BA_UP(d_ekf, e_kf); BA_UP(d_etype, e_type); BA_UP(d_emeas, e_meas);
+  BA_UP(d_einfo, e_info); BA_UP(d_elevel, e_level); BA_UP(d_lms, lm_start); BA_UP(d_lme, lm_edges); BA_UP(d_pss, ps_start);
+  BA_UP(d_pse, ps_edges); BA_UP(d_oi, o_i); BA_UP(d_oj, o_j); BA_UP(d_oz, oZinv); BA_UP(d_oinfo, o_info);
+  FB_TRY(d_fixed.upload(A->kf_fixed, n_kf));
+  FB_TRY(d_echi2.alloc((size_t)std::max(nE, 1) * 8));
+  FB_HIP(hipMemset(d_echi2.p, 0, (size_t)std::max(nE, 1) * 8));
+  BADev D;
+  D.n_kf = n_kf; D.np = np; D.npt = npt; D.nE = nE; D.nO = nO; D.quat = odom ? 1 : 0;
+  D.fx = A->fx; D.fy = A->fy; D.cx = A->cx; D.cy = A->cy; D.delta = (double)(float)sqrt(5.991);
+  D.poseIdx = d_poseIdx.as<int>(); D.e_pt = d_ept.as<int>(); D.e_kf = d_ekf.as<int>(); D.e_type = d_etype.as<uint8_t>();
+  D.e_meas = d_emeas.as<double>(); D.e_info = d_einfo.as<double>(); D.e_level = d_elevel.as<uint8_t>();
+  D.e_chi2 = d_echi2.as<double>(); D.lm_start = d_lms.as<int>(); D.lm_edges = d_lme.as<int>(); D.ps_start = d_pss.as<int>();
+  D.ps_edges = d_pse.as<int>(); D.o_i = d_oi.as<int>(); D.o_j = d_oj.as<int>(); D.o_Zinv = d_oz.as<SE3>();
+  D.o_info = d_oinfo.as<double>();
+  fb::DevBuf d_pose[2], d_pt[2], d_Hll[2], d_bl[2], d_W[2], d_Hpp[2], d_bp[2], d_chi[2];
+  State st[2];
+  LinBuf lb[2];
+  for (int s = 0; s < 2; s++) {
+    FB_TRY(d_pose[s].upload(poses.data(), poses.size() * sizeof(SE3)));
+    FB_TRY(d_pt[s].upload(pts.data(), pts.size() * 8));
+    FB_TRY(d_Hll[s].alloc((size_t)npt * 9 * 8)); FB_TRY(d_bl[s].alloc((size_t)npt * 3 * 8));
+    FB_TRY(d_W[s].alloc((size_t)std::max(nE, 1) * 18 * 8)); FB_TRY(d_Hpp[s].alloc((size_t)std::max(P6 * P6, 1) * 8));
+    FB_TRY(d_bp[s].alloc((size_t)std::max(P6, 1) * 8)); FB_TRY(d_chi[s].alloc((size_t)(nLinBlocks + 1) * 8));
+    st[s].pose = d_pose[s].as<SE3>(); st[s].pt = d_pt[s].as<double>();
+    lb[s].Hll = d_Hll[s].as<double>(); lb[s].bl = d_bl[s].as<double>(); lb[s].W = d_W[s].as<double>();
+    lb[s].Hpp = d_Hpp[s].as<double>(); lb[s].bp = d_bp[s].as<double>(); lb[s].chiPart = d_chi[s].as<double>();
+  }
+  fb::DevBuf d_Dinv, d_Spart, d_xp, d_ok, d_scale, d_scal;
+  FB_TRY(d_Dinv.alloc((size_t)npt * 9 * 8)); FB_TRY(d_Spart.alloc((size_t)nWg * rows * rows * 8));
+  FB_TRY(d_xp.alloc((size_t)std::max(P6, 1) * 8)); FB_TRY(d_ok.alloc(4)); FB_TRY(d_scale.alloc((size_t)nUpdBlocks * 8));
+  FB_TRY(d_scal.alloc(4 * 8));
+  const size_t schurLds = (size_t)2 * rows * KPAD * 8;
+  const size_t solveLds = ((size_t)P6 * (P6 + 1) + P6 + 2) * 8;
+  if (schurLds > 160 * 1024 || solveLds > 160 * 1024) { fb::set_error("fb_local_ba: %d free keyframes exceed the LDS-resident reduced system", np); return FB_ERR_CAPACITY; }
+  // accumulator tiles per wave: NT<=8 -> 9, NT<=12 -> 20, NT<=16 -> 34
+  auto schurKernel = NT <= 8 ? k_ba_schur<9> : (NT <= 12 ? k_ba_schur<20> : k_ba_schur<34>);
+  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(schurKernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
+  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
+  const size_t odomLds = (size_t)std::max(nO, 1) * sizeof(OdomLin);
+  if (odomLds > 150 * 1024) { fb::set_error("fb_local_ba: too many odometry edges"); return FB_ERR_CAPACITY; }
+  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_odom), hipFuncAttributeMaxDynamicSharedMemorySize, (int)odomLds));
+  hipStream_t s0 = nullptr;
+
+  // one linearisation at state `si` into buffer `bi`; returns chi2 (and max diagonal when wanted)
+  auto linearize = [&](int si, int bi, int robust, bool wantDiag, double *chi, double *maxDiag) -> int {
+    if (P6 > 0) FB_HIP(hipMemsetAsync(lb[bi].Hpp, 0, (size_t)P6 * P6 * 8, s0));
+    { fb::ProfScope pr(fb::P_BA_LINEARIZE, s0);
+      if (nLinBlocks > 0) k_ba_linearize<<<nLinBlocks, LIN_THREADS, 0, s0>>>(D, st[si], lb[bi], robust);
+      if (np > 0) k_ba_pose<<<np, POSE_THREADS, 0, s0>>>(D, st[si], lb[bi], robust, P6);
+      k_ba_odom<<<1, 256, odomLds, s0>>>(D, st[si], lb[bi], P6, nLinBlocks); }
+    { fb::ProfScope pr(fb::P_BA_MISC, s0);
+      k_ba_scalars<<<1, 256, 0, s0>>>(lb[bi].chiPart, nLinBlocks + 1, lb[bi].Hpp, P6, lb[bi].Hll, npt, d_scal.as<double>(), wantDiag ? 1 : 0); }
+    double h[2];
+    FB_HIP(hipMemcpy(h, d_scal.p, 16, hipMemcpyDeviceToHost));
+    *chi = h[0];
+    if (wantDiag) *maxDiag = h[1];
+    return FB_OK;
+  };
+  // SparseOptimizer::optimize + OptimizationAlgorithmLevenberg::solve, host-driven
+  int cur = 0;  // index of the accepted state / its linearisation
+  const bool trace = getenv("FB_BA_TRACE") != nullptr;
+  auto optimize = [&](int iterations, int robust) -> int {
+    double currentChi = 0, maxDiag = 0;
+    FB_TRY(linearize(cur, cur, robust, true, &currentChi, &maxDiag));
+    if (trace) fprintf(stderr, "[hip] optimize(%d) chi0=%.17g maxDiag=%.17g\n", iterations, currentChi, maxDiag);
+    double lambda = 0, ni = 2;
+    int nBad = 0;
+    for (int it = 0; it < iterations; it++) {
+      if (A->stop_flag && *A->stop_flag) break;  // terminate()
+      const double iniChi = currentChi;
+      if (it == 0) { lambda = 1e-5 * maxDiag; ni = 2; nBad = 0; }
+      double rho = 0;
+      int qmax = 0;
+      do {
+        const int tr = 1 - cur;
+        { fb::ProfScope pr(fb::P_BA_SCHUR, s0);
+          schurKernel<<<nWg, SCHUR_THREADS, schurLds, s0>>>(D, lb[cur], lambda, d_Dinv.as<double>(), d_Spart.as<double>(), P6, NT, lmPerWg); }
+        { fb::ProfScope pr(fb::P_BA_SOLVE, s0);
+          k_ba_solve<<<1, SOLVE_THREADS, solveLds, s0>>>(lb[cur], lambda, d_Spart.as<double>(), nWg, P6, NT, d_xp.as<double>(), d_ok.as<int>()); }
+        { fb::ProfScope pr(fb::P_BA_UPDATE, s0);
+          k_ba_update<<<nUpdBlocks, LIN_THREADS, 0, s0>>>(D, lb[cur], st[cur], st[tr], d_Dinv.as<double>(), d_xp.as<double>(), lambda, d_scale.as<double>());
+          k_ba_scalars<<<1, 256, 0, s0>>>(d_scale.as<double>(), nUpdBlocks, nullptr, 0, nullptr, 0, d_scal.as<double>() + 2, 0); }
+        double tempChi = 0, dummy = 0;
+        FB_TRY(linearize(tr, tr, robust, false, &tempChi, &dummy));
+        double hs[1];
+        int ok2 = 1;
+        FB_HIP(hipMemcpy(hs, d_scal.as<double>() + 2, 8, hipMemcpyDeviceToHost));
+        FB_HIP(hipMemcpy(&ok2, d_ok.p, 4, hipMemcpyDeviceToHost));
+        if (!ok2) tempChi = 1.7976931348623157e308;
+        rho = currentChi - tempChi;
+        const double scale = hs[0] + 1e-3;
+        rho /= scale;
+        if (trace) fprintf(stderr, "[hip]  it=%d q=%d lambda=%.17g tempChi=%.17g scale=%.17g rho=%.17g ok=%d\n", it, qmax, lambda, tempChi, scale, rho, ok2);
+        if (rho > 0 && std::isfinite(tempChi)) {
+          double alpha = 1. - pow((2 * rho - 1), 3);
+          alpha = std::min(alpha, 2. / 3.);
+          lambda *= std::max(1. / 3., alpha);
+          ni = 2;
+          currentChi = tempChi;
+          cur = tr;  // discardTop: the trial state and its linearisation become current
+        } else {
+          lambda *= ni;
+          ni *= 2;  // pop: keep `cur`
+        }
+        qmax++;
+      } while (rho < 0 && qmax < 10 && !(A->stop_flag && *A->stop_flag));
+      if (qmax == 10 || rho == 0) break;
+      if ((iniChi - currentChi) * 1e3 < iniChi) nBad++;
+      else nBad = 0;
+      if (nBad >= 3) break;
+    }
+    return FB_OK;
+  };
+  if (nE + nO > 0 && (np > 0 || npt > 0)) FB_TRY(optimize(5, 1));
+  const bool more = !(A->stop_flag && *A->stop_flag);
+  if (more && nE > 0) {
+    k_ba_gate<<<(nE + 255) / 256, 256, 0, s0>>>(D, st[cur], 1, nullptr);
+    if (nE + nO > 0) FB_TRY(optimize(10, 0));
+  }
+  fb::DevBuf d_flags, d_kfT, d_ptOut;
+  FB_TRY(d_flags.alloc(std::max(nE, 1)));
+  if (nE > 0) k_ba_gate<<<(nE + 255) / 256, 256, 0, s0>>>(D, st[cur], 0, d_flags.as<uint8_t>());
+  FB_TRY(d_kfT.upload(A->kf_Tcw, (size_t)n_kf * 48));
+  FB_TRY(d_ptOut.alloc((size_t)std::max(npt, 1) * 12));
+  k_ba_export<<<(n_kf + npt * 3 + 255) / 256, 256, 0, s0>>>(n_kf, npt, st[cur].pose, st[cur].pt, d_fixed.as<uint8_t>(),
+                                                            d_kfT.as<float>(), d_ptOut.as<float>());
+  FB_HIP(hipGetLastError());
+  FB_HIP(hipDeviceSynchronize());
+  std::vector<uint8_t> flags(std::max(nE, 1));
+  FB_TRY(d_flags.download(flags.data(), std::max(nE, 1)));
+  for (int i = 0; i < nF; i++) A->obs_outlier[i] = flags[i];
+  for (int i = 0; i < nB; i++) A->bobs_outlier[i] = flags[nF + i];
+  FB_TRY(d_kfT.download(A->kf_Tcw, (size_t)n_kf * 48));
+  std::vector<float> po((size_t)std::max(npt, 1) * 3);
+  FB_TRY(d_ptOut.download(po.data(), (size_t)npt * 12));
+  for (int i = 0; i < 3 * n_mp; i++) A->mp_xw[i] = po[i];
+  for (int i = 0; i < 3 * A->n_mpb; i++) A->mpb_xw[i] = po[3 * n_mp + i];
+  return FB_OK;
 }

@@ -305,3 +305,109 @@ def make_birdview_problem(seed, n_cur=1000, n_ref=1000, cols=512, rows=512):
     ref_desc = random_descriptors(g, n_ref)
     ref_desc[is_copy] = flip_bits(g, cur_desc[tgt[is_copy]], p=0.05)
     return dict(cols=cols, rows=rows, cur_kps=cur, cur_desc=cur_desc, ref_kps=ref, ref_desc=ref_desc)
+
+
+# ---- local bundle adjustment problem (seed 4000) ------------------------------
+def odom_transform(p1, p2, Tbc, Tcb):
+    """Frame::GetTransformFromOdometer (Frame.cc:1049-1067): planar odometer poses (x,y,theta) -> float 4x4 Tcb*T12b*Tbc."""
+    x1, y1, t1 = p1
+    x2, y2, t2 = p2
+    t12 = t2 - t1
+    x12 = (x2 - x1) * math.cos(t1) + (y2 - y1) * math.sin(t1)
+    y12 = (y2 - y1) * math.cos(t1) - (x2 - x1) * math.sin(t1)
+    T12b = np.array([[math.cos(t12), -math.sin(t12), 0, x12], [math.sin(t12), math.cos(t12), 0, y12], [0, 0, 1, 0],
+                     [0, 0, 0, 1]], np.float32)
+    return (Tcb @ T12b @ Tbc).astype(np.float32)
+
+
+def make_ba_problem(seed=4000, n_kf=20, n_fixed=2, n_mp=8000, n_mpb=2000, w=1280, h=720, fx=500.0, fy=500.0,
+                    outlier_frac=0.03, wP=3.0):
+    """n_kf keyframes on a planar arc (0.5 m spacing, the n_fixed oldest fixed), n_mp points each observed by
+    2..8 keyframes that see it, n_mpb bird points observed by 2..5 consecutive keyframes, odometry chain
+    (i,i+1),(i,i+2),(i,i+3) as Optimizer.cc:2419-2495, every estimate perturbed."""
+    g = rng(seed)
+    cx, cy = w / 2.0, h / 2.0
+    _, _, sig2, inv_sig2 = scale_tables()
+    per = np.array(features_per_level(), np.float64)
+    Tbc, Tcb = extrinsics()
+    Tbc64, Tcb64 = Tbc.astype(np.float64), Tcb.astype(np.float64)
+    # base (vehicle) poses on an arc of radius 30 m, planar
+    odo = []
+    for k in range(n_kf):
+        s = 0.5 * k
+        th = s / 30.0
+        odo.append((30.0 * math.sin(th), 30.0 * (1 - math.cos(th)), th))
+    Twb = []
+    for (x, y, th) in odo:
+        T = np.eye(4)
+        T[:3, :3] = rot_xyz(0, 0, th)
+        T[:3, 3] = [x, y, 0]
+        Twb.append(T)
+    # camera pose Tcw = Tcb * Tbw
+    Tcw_true = [Tcb64 @ np.linalg.inv(T) for T in Twb]
+    # map points: sample in the frustum of a random keyframe, observe from 2..8 keyframes that see them
+    obs_kf, obs_mp, obs_uv, obs_inf = [], [], [], []
+    mp = np.zeros((n_mp, 3))
+    j = 0
+    while j < n_mp:
+        k0 = g.integers(0, n_kf)
+        u, v, z = g.uniform(0, w), g.uniform(0, h), g.uniform(4.0, 40.0)
+        Xc = np.array([(u - cx) / fx * z, (v - cy) / fy * z, z])
+        Xw = np.linalg.inv(Tcw_true[k0])[:3, :3] @ Xc + np.linalg.inv(Tcw_true[k0])[:3, 3]
+        vis = []
+        for k in range(n_kf):
+            pc = Tcw_true[k][:3, :3] @ Xw + Tcw_true[k][:3, 3]
+            if pc[2] > 1.0:
+                uu, vv = pc[0] / pc[2] * fx + cx, pc[1] / pc[2] * fy + cy
+                if 0 <= uu < w and 0 <= vv < h:
+                    vis.append((k, uu, vv))
+        if len(vis) < 2:
+            continue
+        nobs = min(len(vis), int(g.integers(2, 9)))
+        pick = sorted(g.choice(len(vis), nobs, replace=False))
+        mp[j] = Xw
+        for i in pick:
+            k, uu, vv = vis[i]
+            o = int(g.choice(8, p=per / per.sum()))
+            n2 = g.normal(0, 1.0, 2) * math.sqrt(sig2[o])
+            if g.random() < outlier_frac:
+                n2 += g.uniform(-15, 15, 2)
+            obs_kf.append(k); obs_mp.append(j); obs_uv.append((uu + n2[0], vv + n2[1])); obs_inf.append(inv_sig2[o])
+        j += 1
+    # bird points: on the ground plane near the vehicle, observed by 2..5 consecutive keyframes
+    bobs_kf, bobs_mpb, bobs_xc, bobs_inf = [], [], [], []
+    mpb = np.zeros((n_mpb, 3))
+    for j in range(n_mpb):
+        k0 = int(g.integers(0, n_kf - 1))
+        pb = np.array([g.uniform(-8, 8) + REAR_AXLE_TO_CENTER, g.uniform(-8, 8), 0.0, 1.0])
+        Xw = (Twb[k0] @ pb)[:3]
+        mpb[j] = Xw
+        nobs = int(g.integers(2, 6))
+        for k in range(k0, min(k0 + nobs, n_kf)):
+            pc = Tcw_true[k][:3, :3] @ Xw + Tcw_true[k][:3, 3]
+            n3 = g.normal(0, 0.01, 3)
+            if g.random() < outlier_frac:
+                n3 += g.uniform(-3, 3, 3)
+            bobs_kf.append(k); bobs_mpb.append(j); bobs_xc.append(pc + n3); bobs_inf.append(inv_sig2[int(g.choice(8, p=per / per.sum()))])
+    # odometry edges from noisy planar poses
+    odo_n = [(x + g.normal(0, 0.01), y + g.normal(0, 0.01), th + g.normal(0, 0.002)) for (x, y, th) in odo]
+    oi, oj, oT, oinfo = [], [], [], []
+    for i in range(n_kf - 1):
+        oi.append(i); oj.append(i + 1); oT.append(odom_transform(odo_n[i], odo_n[i + 1], Tbc, Tcb)); oinfo.append(1e4 * wP)
+        if i + 2 < n_kf:
+            oi.append(i); oj.append(i + 2); oT.append(odom_transform(odo_n[i], odo_n[i + 2], Tbc, Tcb)); oinfo.append(2e3)
+            if i + 3 < n_kf:
+                oi.append(i); oj.append(i + 3); oT.append(odom_transform(odo_n[i], odo_n[i + 3], Tbc, Tcb)); oinfo.append(1e3 * wP)
+    kf_T = np.stack([to12(T if k < n_fixed else perturb_pose(g, T, 0.005, 0.03)) for k, T in enumerate(Tcw_true)])
+    fixed = np.zeros(n_kf, np.uint8)
+    fixed[:n_fixed] = 1
+    return dict(fx=fx, fy=fy, cx=cx, cy=cy, wP=wP, kf_Tcw=kf_T, kf_fixed=fixed, kf_true=np.stack([to12(T) for T in Tcw_true]),
+                mp_xw=(mp + g.normal(0, 0.05, mp.shape)).astype(np.float32), mp_true=mp.astype(np.float32),
+                mpb_xw=(mpb + g.normal(0, 0.02, mpb.shape)).astype(np.float32),
+                obs_kf=np.array(obs_kf, np.int32), obs_mp=np.array(obs_mp, np.int32),
+                obs_uv=np.array(obs_uv, np.float32).reshape(-1, 2), obs_inv_sigma2=np.array(obs_inf, np.float32),
+                bobs_kf=np.array(bobs_kf, np.int32), bobs_mpb=np.array(bobs_mpb, np.int32),
+                bobs_xc=np.array(bobs_xc, np.float32).reshape(-1, 3), bobs_inv_sigma2=np.array(bobs_inf, np.float32),
+                odom_kf_i=np.array(oi, np.int32), odom_kf_j=np.array(oj, np.int32),
+                odom_Tij=np.stack([to12(T) for T in oT]) if oT else np.zeros((0, 12), np.float32),
+                odom_info=np.array(oinfo, np.float64))

@@ -13,6 +13,8 @@
 #define SE3_ORACLE_H_
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <vector>
 
@@ -285,10 +287,12 @@ inline int lm_solve(LMProblem &P, LMState &S, int iteration) {
   double tempChi = currentChi;
   const double iniChi = currentChi;
   P.buildSystem();
+  static const bool trace = std::getenv("FB_BA_TRACE") != nullptr;
   if (iteration == 0) {
     S.lambda = 1e-5 * P.maxDiagonal();
     S.ni = 2;
     S.nBad = 0;
+    if (trace) std::fprintf(stderr, "[orc] optimize chi0=%.17g maxDiag=%.17g\n", currentChi, P.maxDiagonal());
   }
   double rho = 0;
   int qmax = 0;
@@ -303,6 +307,7 @@ inline int lm_solve(LMProblem &P, LMState &S, int iteration) {
     double scale = P.scaleTerm(S.lambda);
     scale += 1e-3;
     rho /= scale;
+    if (trace) std::fprintf(stderr, "[orc]  it=%d q=%d lambda=%.17g tempChi=%.17g scale=%.17g rho=%.17g ok=%d\n", iteration, qmax, S.lambda, tempChi, scale, rho, (int)ok2);
     if (rho > 0 && std::isfinite(tempChi)) {
       double alpha = 1. - std::pow((2 * rho - 1), 3);
       alpha = std::min(alpha, 2. / 3.);
