@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures of tests/golden/ with the CPU oracle (oracle/), i.e. by the build's own
+restatement: the reference cannot be built or run here (no OpenCV/Eigen) and ships no fixtures of its own.
+
+    python tests/golden/make_golden.py
+
+Inputs are regenerated from seeds by fishbirdeyevisualslam_amd.synth; only small inputs (one 160x120 image)
+and the expected OUTPUTS are stored."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle_lib as O  # noqa: E402
+from fishbirdeyevisualslam_amd import ba_problem, cabi, problems as P, synth  # noqa: E402
+
+
+def golden_cases():
+    out = {}
+    # 1. ORB extraction of a 160x120 synthetic image, 300 features, 4 levels
+    img = synth.synth_image(1234, 160, 120, n_rect=14, n_disc=8)
+    params = O.orb_params(nfeatures=300, nlevels=4)
+    k, d = O.orb_extract(params, img)
+    out["orb"] = dict(image=img, kps=k.view(np.uint8).reshape(len(k), 24), desc=d)
+    # 2. matchers on seeded problems
+    probs = [synth.make_proj_frame_problem(2000, 400, 400, dup_frac=0.2, obs0_frac=0.2)]
+    geom = P.grid_geom(synth.front_grid_geom(1280, 720))
+    cs, ci = P.build_grid_host([p["cur_kps"] for p in probs], geom, O.grid_build, 400)
+    a, o, keep = P.proj_frame_args(probs, cs, ci)
+    O.call("orc_match_projection_frame", a)
+    out["m3"] = dict(match=o["match_cur_to_last"], n=o["nmatches"])
+    probs = [synth.make_bird_mp_problem(2100, 300, 300)]
+    geom = P.grid_geom(synth.bird_grid_geom(512, 512))
+    cs, ci = P.build_grid_host([p["cur_kps"] for p in probs], geom, O.grid_build, 300)
+    a, o, keep = P.bird_mp_args(probs, cs, ci)
+    O.call("orc_match_bird_mappoints", a)
+    out["m9"] = dict(match=o["match_cur_to_ref"], n=o["ninliers"])
+    probs = [synth.make_proj_points_problem(2200, 400, 600)]
+    geom = P.grid_geom(synth.front_grid_geom(1280, 720))
+    cs, ci = P.build_grid_host([p["cur_kps"] for p in probs], geom, O.grid_build, 400)
+    a, o, keep = P.proj_points_args(probs, cs, ci, th=5.0)
+    O.call("orc_match_projection_points", a)
+    out["m2"] = dict(match=o["match_cur_to_mp"], n=o["nmatches"])
+    probs = [synth.make_birdview_problem(2300, 300, 300)]
+    geom = P.grid_geom(synth.bird_grid_geom(512, 512))
+    cs, ci = P.build_grid_host([p["cur_kps"] for p in probs], geom, O.grid_build, 300)
+    a, o, keep = P.birdview_args(probs, cs, ci)
+    O.call("orc_match_birdview", a)
+    out["m8"] = dict(match=o["match_ref_to_cur"], dist=o["match_dist"], n=o["nmatches"], nd=o["n_dmatches"])
+    # 3. pose optimisation, the three modes
+    pp = [synth.make_pose_problem(3000, 300, 120)]
+    for mode in (0, 1, 2):
+        a, o, keep = P.pose_args(pp, mode=mode)
+        O.call("orc_pose_opt", a)
+        out["pose%d" % mode] = dict(Tcw=o["Tcw"], front_outlier=o["front_outlier"], bird_outlier=o["bird_outlier"], n=o["ninliers"])
+    # 4. local BA (reduced: 6 keyframes x 500 points)
+    bp = synth.make_ba_problem(4000, n_kf=6, n_mp=500, n_mpb=120)
+    for wo in (1, 0):
+        a, o, keep = ba_problem.local_ba_args(bp, with_odom=wo)
+        O.call("orc_local_ba", a)
+        out["ba%d" % wo] = dict(kf_Tcw=o["kf_Tcw"], mp_xw=o["mp_xw"], mpb_xw=o["mpb_xw"], obs_outlier=o["obs_outlier"],
+                                bobs_outlier=o["bobs_outlier"])
+    return out
+
+
+if __name__ == "__main__":
+    for name, d in golden_cases().items():
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        print(name, {k: v.shape for k, v in d.items()})
