@@ -1,0 +1,262 @@
+// fishbird_host.hpp -- C++ host side above the C-ABI (include/fishbird.h), mirroring the reference's
+// operator interface for the hot path: same class names, argument meaning and return values as
+//   ORBextractor  (include/ORBextractor.h:51-85)
+//   ORBmatcher    (include/ORBmatcher.h:41-88)      SearchByProjection x2, BirdMapPointMatch, BirdviewMatch
+//   Optimizer     (include/Optimizer.h:40-68)       PoseOptimization, PoseOptimizationWithBird, BirdOptimization,
+//                                                   LocalBundleAdjustment[WithOdom]
+// on plain-old-data frames (the reference's Frame/KeyFrame/MapPoint own OpenCV and graph state that stays in the
+// host application).  Header only; link with -lfishbird_hip.  Errors throw std::runtime_error(fb_last_error()).
+#ifndef FISHBIRD_HOST_HPP_
+#define FISHBIRD_HOST_HPP_
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "../../include/fishbird.h"
+
+namespace fishbird {
+
+inline void check(int rc) {
+  if (rc != FB_OK) throw std::runtime_error(fb_last_error());
+}
+
+// ---- the part of Frame (include/Frame.h) the hot path reads and writes -------------------------------------------
+struct MapPointRef {            // what the path needs from a MapPoint / MapPointBird
+  bool valid = false;           // pointer != NULL (&& !isBad())
+  bool hasObservations = true;  // Observations() > 0
+  float Xw[3] = {0, 0, 0};      // GetWorldPos()
+  uint8_t descriptor[32] = {0}; // GetDescriptor()
+};
+
+struct Frame {
+  // intrinsics and static grid data (Frame.h statics)
+  float fx = 0, fy = 0, cx = 0, cy = 0;
+  float mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;
+  int birdviewCols = 0, birdviewRows = 0;
+  std::vector<float> mvScaleFactors, mvInvLevelSigma2;
+  float mTcw[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};  // rows 0..2 of the 4x4
+  // front
+  std::vector<fb_keypoint> mvKeysUn;
+  std::vector<uint8_t> mDescriptors;          // N x 32
+  std::vector<int32_t> mvpMapPoints;          // index into the caller's map-point table, -1 = NULL
+  std::vector<uint8_t> mvpMapPointHasObs;     // Observations()>0 of the point currently in slot i
+  std::vector<uint8_t> mvbOutlier;
+  // bird
+  std::vector<fb_keypoint> mvKeysBird;
+  std::vector<uint8_t> mDescriptorsBird;
+  std::vector<float> mvKeysBirdCamXYZ;        // NB x 3
+  std::vector<int32_t> mvpMapPointsBird;
+  std::vector<uint8_t> mvBirdOutlier;
+  // grids (Frame::AssignFeaturesToGrid), CSR with cell id = ix*rows+iy
+  std::vector<int32_t> gridStart, gridItems, gridBirdStart, gridBirdItems;
+
+  int N() const { return (int)mvKeysUn.size(); }
+  int Nbird() const { return (int)mvKeysBird.size(); }
+  fb_grid_geom frontGrid() const { return {mnMinX, mnMinY, 64.f / (mnMaxX - mnMinX), 48.f / (mnMaxY - mnMinY), 64, 48}; }
+  fb_grid_geom birdGrid() const { return {0.f, 0.f, 32.f / (float)birdviewCols, 32.f / (float)birdviewRows, 32, 32}; }
+
+  // Frame::AssignFeaturesToGrid (Frame.cc:381-411) on the host (tiny); PosInGrid rounding as Frame.cc:548-570
+  static void assignToGrid(const std::vector<fb_keypoint> &k, const fb_grid_geom &g, std::vector<int32_t> &start,
+                           std::vector<int32_t> &items) {
+    const int ncell = g.cols * g.rows;
+    std::vector<std::vector<int32_t>> cells(ncell);
+    for (size_t i = 0; i < k.size(); i++) {
+      const int px = (int)std::round((k[i].x - g.min_x) * g.inv_w), py = (int)std::round((k[i].y - g.min_y) * g.inv_h);
+      if (px < 0 || px >= g.cols || py < 0 || py >= g.rows) continue;
+      cells[px * g.rows + py].push_back((int32_t)i);
+    }
+    start.assign(ncell + 1, 0);
+    items.assign(k.size() ? k.size() : 1, 0);
+    int off = 0;
+    for (int c = 0; c < ncell; c++) { start[c] = off; for (int32_t i : cells[c]) items[off++] = i; }
+    start[ncell] = off;
+  }
+  void AssignFeaturesToGrid() {
+    assignToGrid(mvKeysUn, frontGrid(), gridStart, gridItems);
+    if (birdviewCols > 0) assignToGrid(mvKeysBird, birdGrid(), gridBirdStart, gridBirdItems);
+  }
+};
+
+// ---- ORBextractor ------------------------------------------------------------------------------------------------
+class ORBextractor {
+ public:
+  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+      : p_{nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST} {
+    check(fb_orb_create(&p_, &h_));
+    check(fb_orb_get_tables(h_, &t_));
+  }
+  ~ORBextractor() { fb_orb_destroy(h_); }
+  ORBextractor(const ORBextractor &) = delete;
+  ORBextractor &operator=(const ORBextractor &) = delete;
+
+  // operator()(image, mask, keypoints, descriptors); the mask is ignored like in the reference (ORBextractor.h:58)
+  void operator()(const uint8_t *image, int width, int height, int stride, std::vector<fb_keypoint> &keypoints,
+                  std::vector<uint8_t> &descriptors) {
+    keypoints.clear();
+    descriptors.clear();
+    if (!image || width <= 0 || height <= 0) return;  // _image.empty()
+    const int cap = fb_orb_capacity(&p_);
+    keypoints.resize(cap);
+    descriptors.resize((size_t)cap * 32);
+    int32_t n = 0;
+    check(fb_orb_extract(h_, image, width, height, stride, keypoints.data(), descriptors.data(), &n));
+    keypoints.resize(n);
+    descriptors.resize((size_t)n * 32);
+  }
+  int GetLevels() const { return p_.nlevels; }
+  float GetScaleFactor() const { return p_.scale_factor; }
+  std::vector<float> GetScaleFactors() const { return {t_.scale_factor, t_.scale_factor + p_.nlevels}; }
+  std::vector<float> GetInverseScaleFactors() const { return {t_.inv_scale_factor, t_.inv_scale_factor + p_.nlevels}; }
+  std::vector<float> GetScaleSigmaSquares() const { return {t_.level_sigma2, t_.level_sigma2 + p_.nlevels}; }
+  std::vector<float> GetInverseScaleSigmaSquares() const { return {t_.inv_level_sigma2, t_.inv_level_sigma2 + p_.nlevels}; }
+
+ private:
+  fb_orb_params p_;
+  fb_orb *h_ = nullptr;
+  fb_orb_tables t_;
+};
+
+// ---- ORBmatcher --------------------------------------------------------------------------------------------------
+class ORBmatcher {
+ public:
+  explicit ORBmatcher(float nnratio = 0.6f, bool checkOri = true) : m_{nnratio, checkOri ? 1 : 0} {}
+
+  static int DescriptorDistance(const uint8_t *a, const uint8_t *b) {
+    int32_t d = 0;
+    check(fb_descriptor_distance(a, b, 1, &d));
+    return d;
+  }
+
+  // SearchByProjection(CurrentFrame, LastFrame, th, bMono=true), ORBmatcher.cc:1329-1471.
+  // lastPoints[i] describes LastFrame.mvpMapPoints[i] (valid = pointer && !mvbOutlier[i]).
+  int SearchByProjection(Frame &cur, const Frame &last, const std::vector<MapPointRef> &lastPoints, float th) const {
+    const int32_t N = cur.N(), NL = last.N();
+    std::vector<uint8_t> valid(NL), obs(NL), desc((size_t)NL * 32), blocked(N, 0);
+    std::vector<float> xw((size_t)NL * 3), angle(NL);
+    std::vector<int32_t> oct(NL), match(N > 0 ? N : 1);
+    for (int i = 0; i < NL; i++) {
+      valid[i] = lastPoints[i].valid && !(i < (int)last.mvbOutlier.size() && last.mvbOutlier[i]);
+      obs[i] = lastPoints[i].hasObservations;
+      std::memcpy(&xw[3 * i], lastPoints[i].Xw, 12);
+      std::memcpy(&desc[32 * (size_t)i], lastPoints[i].descriptor, 32);
+      oct[i] = last.mvKeysUn[i].octave;
+      angle[i] = last.mvKeysUn[i].angle;
+    }
+    for (int i = 0; i < N; i++) blocked[i] = cur.mvpMapPoints[i] >= 0 && cur.mvpMapPointHasObs[i];
+    fb_proj_frame_args a{};
+    a.batch = 1; a.cur_stride = N; a.last_stride = NL;
+    a.n_cur = &N; a.cur_kps = cur.mvKeysUn.data(); a.cur_desc = cur.mDescriptors.data();
+    a.cur_cell_start = cur.gridStart.data(); a.cur_cell_items = cur.gridItems.data(); a.cur_blocked = blocked.data();
+    a.cur_Tcw = cur.mTcw; a.n_last = &NL; a.last_valid = valid.data(); a.last_obs_pos = obs.data(); a.last_xw = xw.data();
+    a.last_desc = desc.data(); a.last_octave = oct.data(); a.last_angle = angle.data();
+    a.cam = {cur.fx, cur.fy, cur.cx, cur.cy, cur.mnMinX, cur.mnMinY, cur.mnMaxX, cur.mnMaxY};
+    a.grid = cur.frontGrid();
+    for (size_t i = 0; i < cur.mvScaleFactors.size() && i < FB_MAX_LEVELS; i++) a.scale_factors[i] = cur.mvScaleFactors[i];
+    a.th = th; a.matcher = m_;
+    int32_t nmatches = 0;
+    a.match_cur_to_last = match.data(); a.nmatches = &nmatches;
+    check(fb_match_projection_frame(&a));
+    for (int i = 0; i < N; i++)
+      if (match[i] >= 0) { cur.mvpMapPoints[i] = last.mvpMapPoints[match[i]]; cur.mvpMapPointHasObs[i] = obs[match[i]]; }
+    // culled assignments (rotation histogram) are already -1 in match[]; reproduce the NULL writes
+    return nmatches;
+  }
+
+  // BirdMapPointMatch(CurF, vRefMapPointsBird, windowSize, filterSize), ORBmatcher.cc:1763-1902
+  int BirdMapPointMatch(Frame &cur, const std::vector<MapPointRef> &ref, const float Tbc[12], int windowSize,
+                        float filterSize, double meter2pixel = 25.1, double rearAxleToCenter = 1.393) const {
+    const int32_t NB = cur.Nbird(), NR = (int32_t)ref.size();
+    std::vector<uint8_t> valid(NR), desc((size_t)NR * 32);
+    std::vector<float> xw((size_t)NR * 3);
+    for (int i = 0; i < NR; i++) {
+      valid[i] = ref[i].valid;
+      std::memcpy(&xw[3 * i], ref[i].Xw, 12);
+      std::memcpy(&desc[32 * (size_t)i], ref[i].descriptor, 32);
+    }
+    fb_bird_mp_args a{};
+    a.batch = 1; a.cur_stride = NB; a.ref_stride = NR;
+    a.n_cur = &NB; a.cur_kps = cur.mvKeysBird.data(); a.cur_desc = cur.mDescriptorsBird.data();
+    a.cur_cam_xyz = cur.mvKeysBirdCamXYZ.data(); a.cur_cell_start = cur.gridBirdStart.data();
+    a.cur_cell_items = cur.gridBirdItems.data(); a.cur_Tcw = cur.mTcw;
+    a.n_ref = &NR; a.ref_valid = valid.data(); a.ref_xw = xw.data(); a.ref_desc = desc.data();
+    std::memcpy(a.Tbc, Tbc, sizeof(a.Tbc));
+    a.bird_cols = cur.birdviewCols; a.bird_rows = cur.birdviewRows; a.meter2pixel = meter2pixel;
+    a.rear_axle_to_center = rearAxleToCenter; a.grid = cur.birdGrid(); a.window_size = windowSize;
+    a.filter_size = filterSize; a.matcher = m_;
+    int32_t ninl = 0;
+    a.match_cur_to_ref = cur.mvpMapPointsBird.data(); a.ninliers = &ninl;
+    check(fb_match_bird_mappoints(&a));
+    return ninl;
+  }
+
+ private:
+  fb_matcher_params m_;
+};
+
+// ---- Optimizer ---------------------------------------------------------------------------------------------------
+class Optimizer {
+ public:
+  // points[i] / birdPoints[i] describe pFrame->mvpMapPoints[i] / mvpMapPointsBird[i]
+  static int PoseOptimization(Frame *f, const std::vector<MapPointRef> &points) {
+    return run(f, FB_POSE_FRONT, points, {}, 1.f, 1.f);
+  }
+  static int PoseOptimizationWithBird(Frame *f, const std::vector<MapPointRef> &points,
+                                      const std::vector<MapPointRef> &birdPoints, float wB = 1.f, float wF = 1.f) {
+    return run(f, FB_POSE_FRONT_BIRD, points, birdPoints, wB, wF);
+  }
+  static int BirdOptimization(Frame *f, const std::vector<MapPointRef> &birdPoints, float wB = 1.f) {
+    return run(f, FB_POSE_BIRD, {}, birdPoints, wB, 1.f);
+  }
+  // LocalBundleAdjustment / LocalBundleAdjustmentWithOdom on an already flattened graph
+  static void LocalBundleAdjustment(fb_local_ba_args &graph, bool *pbStopFlag) {
+    graph.with_odom = 0;
+    graph.stop_flag = reinterpret_cast<volatile uint8_t *>(pbStopFlag);
+    check(fb_local_ba(&graph));
+  }
+  static void LocalBundleAdjustmentWithOdom(fb_local_ba_args &graph, bool *pbStopFlag, float wF = 1.f, float wB = 1.f,
+                                            float wP = 3.f) {
+    graph.with_odom = 1;
+    graph.wF = wF; graph.wB = wB; graph.wP = wP;
+    graph.stop_flag = reinterpret_cast<volatile uint8_t *>(pbStopFlag);
+    check(fb_local_ba(&graph));
+  }
+
+ private:
+  static int run(Frame *f, int mode, const std::vector<MapPointRef> &points, const std::vector<MapPointRef> &birdPoints,
+                 float wB, float wF) {
+    const int32_t N = mode == FB_POSE_BIRD ? 0 : f->N(), NB = mode == FB_POSE_FRONT ? 0 : f->Nbird();
+    std::vector<float> fxw((size_t)N * 3 + 3), fobs((size_t)N * 2 + 2), finf(N + 1), bxw((size_t)NB * 3 + 3), binf(NB + 1);
+    std::vector<uint8_t> fvalid(N + 1), bvalid(NB + 1);
+    for (int i = 0; i < N; i++) {
+      fvalid[i] = points[i].valid;
+      std::memcpy(&fxw[3 * i], points[i].Xw, 12);
+      fobs[2 * i] = f->mvKeysUn[i].x; fobs[2 * i + 1] = f->mvKeysUn[i].y;
+      finf[i] = f->mvInvLevelSigma2[f->mvKeysUn[i].octave];
+    }
+    for (int i = 0; i < NB; i++) {
+      bvalid[i] = birdPoints[i].valid;
+      std::memcpy(&bxw[3 * i], birdPoints[i].Xw, 12);
+      binf[i] = f->mvInvLevelSigma2[f->mvKeysBird[i].octave];
+    }
+    f->mvbOutlier.resize(N + (N == 0), 0);
+    f->mvBirdOutlier.resize(NB + (NB == 0), 0);
+    fb_pose_opt_args a{};
+    a.batch = 1; a.mode = mode; a.front_stride = N; a.bird_stride = NB;
+    a.fx = f->fx; a.fy = f->fy; a.cx = f->cx; a.cy = f->cy; a.wF = wF; a.wB = wB;
+    a.n_front = &N; a.front_xw = fxw.data(); a.front_obs = fobs.data(); a.front_inv_sigma2 = finf.data();
+    a.front_valid = fvalid.data();
+    a.n_bird = &NB; a.bird_xw = bxw.data(); a.bird_xc = f->mvKeysBirdCamXYZ.empty() ? bxw.data() : f->mvKeysBirdCamXYZ.data();
+    a.bird_inv_sigma2 = binf.data(); a.bird_valid = bvalid.data(); a.bird_outlier = f->mvBirdOutlier.data();
+    a.Tcw = f->mTcw; a.front_outlier = f->mvbOutlier.data();
+    int32_t ninl = 0;
+    a.ninliers = &ninl;
+    check(fb_pose_opt(&a));
+    return ninl;
+  }
+};
+
+}  // namespace fishbird
+#endif

@@ -1,0 +1,63 @@
+// Exercises the C++ host mirror (fishbird_host.hpp) the way Tracking would: extract -> grid -> self
+// SearchByProjection -> PoseOptimization.  Reads a raw u8 image, writes keypoints + descriptors for the Python
+// test to compare against the oracle, prints the integer results.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../fishbirdeyevisualslam_amd/host/fishbird_host.hpp"
+
+int main(int argc, char **argv) {
+  if (argc < 5) { std::fprintf(stderr, "usage: host_test img.raw w h out.bin\n"); return 2; }
+  const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
+  std::vector<uint8_t> img((size_t)w * h);
+  FILE *f = std::fopen(argv[1], "rb");
+  if (!f || std::fread(img.data(), 1, img.size(), f) != img.size()) return 3;
+  std::fclose(f);
+  try {
+    fishbird::ORBextractor orb(1000, 1.2f, 8, 15, 5);
+    fishbird::Frame F;
+    F.fx = F.fy = 400.f; F.cx = w / 2.f; F.cy = h / 2.f;
+    F.mnMinX = 0; F.mnMinY = 0; F.mnMaxX = (float)w; F.mnMaxY = (float)h;
+    F.mvScaleFactors = orb.GetScaleFactors();
+    F.mvInvLevelSigma2 = orb.GetInverseScaleSigmaSquares();
+    orb(img.data(), w, h, w, F.mvKeysUn, F.mDescriptors);
+    const int N = F.N();
+    F.mvpMapPoints.assign(N, -1);
+    F.mvpMapPointHasObs.assign(N, 0);
+    F.AssignFeaturesToGrid();
+    // "last frame" = the same keypoints back-projected at depth 5 m with the identity pose
+    fishbird::Frame L = F;
+    std::vector<fishbird::MapPointRef> pts(N);
+    for (int i = 0; i < N; i++) {
+      pts[i].valid = true;
+      const float z = 5.f;
+      pts[i].Xw[0] = (F.mvKeysUn[i].x - F.cx) / F.fx * z;
+      pts[i].Xw[1] = (F.mvKeysUn[i].y - F.cy) / F.fy * z;
+      pts[i].Xw[2] = z;
+      for (int k = 0; k < 32; k++) pts[i].descriptor[k] = F.mDescriptors[(size_t)i * 32 + k];
+      L.mvpMapPoints[i] = i;
+    }
+    fishbird::ORBmatcher matcher(0.9f, true);
+    const int nmatches = matcher.SearchByProjection(F, L, pts, 7.f);
+    int self = 0;
+    std::vector<fishbird::MapPointRef> framePts(N);
+    for (int i = 0; i < N; i++) {
+      if (F.mvpMapPoints[i] == i) self++;
+      if (F.mvpMapPoints[i] >= 0) framePts[i] = pts[F.mvpMapPoints[i]];
+    }
+    F.mTcw[3] = 0.02f;  // perturb tx; the optimiser must bring it back
+    const int ninl = fishbird::Optimizer::PoseOptimization(&F, framePts);
+    std::printf("N=%d nmatches=%d self=%d inliers=%d tx=%.6f dist00=%d\n", N, nmatches, self, ninl, F.mTcw[3],
+                fishbird::ORBmatcher::DescriptorDistance(F.mDescriptors.data(), F.mDescriptors.data()));
+    FILE *o = std::fopen(argv[4], "wb");
+    std::fwrite(&N, 4, 1, o);
+    std::fwrite(F.mvKeysUn.data(), sizeof(fb_keypoint), N, o);
+    std::fwrite(F.mDescriptors.data(), 32, N, o);
+    std::fclose(o);
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
