@@ -47,6 +47,9 @@ struct LevelInfo {
 
 struct OrbK {
   int nlevels, iniTh, minTh, totalCells, outStride, capOut;
+  int fastTileBytes, fastMaxOut, fastMaxPix;  // LDS carve of k_fast
+  int dbg;  // FB_FAST_DBG ablation switch (0 = normal)
+  int cellBase[FB_MAX_LEVELS + 1];  // first FAST cell of each level (contiguous copy for one scalar load)
   long long pyrStride;   // bytes per image of levels >= 1
   long long candStride;  // candidates per image
   int umax[16];
@@ -63,6 +66,12 @@ struct ResizeTabs {  // per level >= 1, device pointers
 // ------------------------------------------------------------------------------------------
 // cv::resize INTER_LINEAR, 8U, 11-bit fixed point (oracle: resize_linear_u8). 4 px per lane.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int win_byte(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int k) {  // byte k of a 16-byte window
+  const uint32_t lo = k & 8 ? w2 : w0, hi = k & 8 ? w3 : w1;
+  const uint32_t w = k & 4 ? hi : lo;
+  return (w >> (8 * (k & 3))) & 0xFF;
+}
+
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src0, long long srcImgStride, int sw,
                                                 int sh, int spitch, uint8_t *__restrict__ dst0, long long dstImgStride,
                                                 int dw, int dh, int dpitch, ResizeTabs tb) {
@@ -78,20 +87,46 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src0
   const int b0 = tb.ibeta[dy * 2], b1 = tb.ibeta[dy * 2 + 1];
   const uint8_t *r0p = src + (long long)sy0 * spitch, *r1p = src + (long long)sy1 * spitch;
   uint32_t packed = 0;
+  // the 4 destination pixels of this lane read source columns [sxa, sxb+1]; when that span fits a 16-byte
+  // window that is 4-byte aligned and inside the row, fetch it with 4 dword loads per row instead of 16 byte loads
+  const int dxl = min(dx4 + 3, dw - 1);
+  const int sxa = dx4 < dw ? tb.xofs[dx4] : 0, sxb = dx4 < dw ? min(tb.xofs[dxl] + 1, sw - 1) : 0;
+  const int a = sxa & ~3;
+  const bool wide = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)spitch) & 3) == 0 && (sxb - a) < 16 && a + 16 <= spitch;
+  if (wide) {
+    const uint32_t *p0 = reinterpret_cast<const uint32_t *>(r0p + a), *p1 = reinterpret_cast<const uint32_t *>(r1p + a);
+    const uint32_t u0 = p0[0], u1 = p0[1], u2 = p0[2], u3 = p0[3], v0 = p1[0], v1 = p1[1], v2 = p1[2], v3 = p1[3];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int dx = dx4 + k;
-    int v = 0;
-    if (dx < dw) {
-      const int sx = tb.xofs[dx];
-      const int sx1 = min(sx + 1, sw - 1);
-      const int a0 = tb.ialpha[dx * 2], a1 = tb.ialpha[dx * 2 + 1];
-      const int r0 = r0p[sx] * a0 + r0p[sx1] * a1;
-      const int r1 = r1p[sx] * a0 + r1p[sx1] * a1;
-      v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-      v = min(max(v, 0), 255);
+    for (int k = 0; k < 4; k++) {
+      const int dx = dx4 + k;
+      int v = 0;
+      if (dx < dw) {
+        const int sx = tb.xofs[dx];
+        const int sx1 = min(sx + 1, sw - 1);
+        const int a0 = tb.ialpha[dx * 2], a1 = tb.ialpha[dx * 2 + 1];
+        const int r0 = win_byte(u0, u1, u2, u3, sx - a) * a0 + win_byte(u0, u1, u2, u3, sx1 - a) * a1;
+        const int r1 = win_byte(v0, v1, v2, v3, sx - a) * a0 + win_byte(v0, v1, v2, v3, sx1 - a) * a1;
+        v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v = min(max(v, 0), 255);
+      }
+      packed |= (uint32_t)v << (8 * k);
     }
-    packed |= (uint32_t)v << (8 * k);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int dx = dx4 + k;
+      int v = 0;
+      if (dx < dw) {
+        const int sx = tb.xofs[dx];
+        const int sx1 = min(sx + 1, sw - 1);
+        const int a0 = tb.ialpha[dx * 2], a1 = tb.ialpha[dx * 2 + 1];
+        const int r0 = r0p[sx] * a0 + r0p[sx1] * a1;
+        const int r1 = r1p[sx] * a0 + r1p[sx1] * a1;
+        v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v = min(max(v, 0), 255);
+      }
+      packed |= (uint32_t)v << (8 * k);
+    }
   }
   *reinterpret_cast<uint32_t *>(dst + (long long)dy * dpitch + dx4) = packed;
 }
@@ -147,15 +182,27 @@ __device__ __forceinline__ int block_excl_scan256(int v, int *s_w /*[4]*/, int *
 
 constexpr int FAST_MAX_TILE = 72;  // cell window <= wCell+6 <= 65 px, +3 alignment slack
 
-__global__ __launch_bounds__(256) void k_fast(OrbK K, const uint8_t *__restrict__ img0, long long imgStride, int pitch0,
-                                              const uint8_t *__restrict__ pyr, uint32_t *__restrict__ cand,
-                                              int *__restrict__ candCount) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[FAST_MAX_TILE * FAST_MAX_TILE];
-  __shared__ uint8_t sc[FAST_MAX_TILE * FAST_MAX_TILE];
-  __shared__ int s_w[4], s_base;
-  const int b = blockIdx.y, tid = threadIdx.x;
+// One WAVE per cell (64-thread workgroups): no cross-wave barriers, ~11 cells resident per CU.
+//  1. the cell window is staged in LDS with 4-byte loads;
+//  2. per 64 pixels: a necessary corner test on the 4 compass pixels (any 9-arc holds two consecutive compass
+//     points), ballot-compaction of the survivors, full score only for those;
+//  3. 3x3 strict NMS over the score tile, survivors staged in LDS;
+//  4. if none survived at iniThFAST the cell is redone at minThFAST (ORBextractor.cc:809-816);
+//  5. ONE global atomic per cell reserves the output slots; candidate order is irrelevant downstream
+//     (the quadtree breaks response ties with an order key derived from x,y).
+__global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__ img0, long long imgStride, int pitch0,
+                                             const uint8_t *__restrict__ pyr, uint32_t *__restrict__ cand,
+                                             int *__restrict__ candCount) {
+  // LDS carve (sized on the host for the largest cell of this image size): tile | sc | out | slot
+  extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
+  uint8_t *tile = fsm;
+  uint8_t *sc = fsm + K.fastTileBytes;
+  uint32_t *s_out = reinterpret_cast<uint32_t *>(fsm + 2 * K.fastTileBytes);
+  unsigned short *s_list = reinterpret_cast<unsigned short *>(fsm + 2 * K.fastTileBytes + 4 * K.fastMaxOut);  // [fastMaxPix]
+  const int b = blockIdx.y, lane = threadIdx.x;
   int cell = blockIdx.x, l = 0;
-  while (l + 1 < K.nlevels && cell >= K.L[l + 1].cellBase) l++;
+#pragma unroll
+  for (int i = 1; i < FB_MAX_LEVELS; i++) l += (i < K.nlevels && cell >= K.cellBase[i]) ? 1 : 0;
   const LevelInfo &Lv = K.L[l];
   cell -= Lv.cellBase;
   const int ci = cell / Lv.nCols, cj = cell % Lv.nCols;
@@ -176,56 +223,108 @@ __global__ __launch_bounds__(256) void k_fast(OrbK K, const uint8_t *__restrict_
   const int ox = x0 - xa;
   if (aligned) {
     const int wpr = tp >> 2;
-    for (int i = tid; i < wpr * ch; i += 256) {
-      const int yy = i / wpr, xw = i - yy * wpr;
+    const float inv_wpr = 1.0f / (float)wpr;
+    for (int i = lane; i < wpr * ch; i += 64) {
+      const int yy = (int)(((float)i + 0.5f) * inv_wpr), xw = i - yy * wpr;
       *reinterpret_cast<uint32_t *>(&tile[yy * tp + xw * 4]) =
           *reinterpret_cast<const uint32_t *>(img + (long long)(y0 + yy) * pitch + xa + xw * 4);
     }
   } else {
-    for (int i = tid; i < cw * ch; i += 256) {
+    for (int i = lane; i < cw * ch; i += 64) {
       const int yy = i / cw, xx = i - yy * cw;
       tile[yy * tp + xx] = img[(long long)(y0 + yy) * pitch + x0 + xx];
     }
   }
-  for (int i = tid; i < tp * ch; i += 256) sc[i] = 0;
+  for (int i = lane; i < (tp * ch + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(sc)[i] = 0;
   __syncthreads();
+  if (K.dbg == 1) { if (tile[lane] == 255 && sc[lane] == 7) cand[0] = 1; return; }
   const int dwid = cw - 6, dhei = ch - 6, npix = dwid * dhei;
-  for (int p = tid; p < npix; p += 256) {
-    const int yy = p / dwid + 3, xx = p - (yy - 3) * dwid + 3;
-    const int s = fast_score16(&tile[yy * tp + ox + xx], tp);
-    sc[yy * tp + ox + xx] = (uint8_t)max(s, 0);
+  const unsigned long long lt = (1ull << lane) - 1;
+  const float inv_dwid = 1.0f / (float)dwid;  // p / dwid == (int)((p + 0.5f) * inv_dwid) for p < 4096, dwid < 64
+  // ---- ONE sweep over the cell: compact every pixel that can be a corner (necessary compass test) into two lists
+  //      sharing one array: from the front the pixels that pass at iniThFAST, from the back those that only pass
+  //      at minThFAST (needed only when the cell has to be redone at the lower threshold)
+  int nlA = 0, nlB = 0;
+  const int cap = K.fastMaxPix;
+  for (int base = 0; base < npix; base += 64) {
+    const int p = base + lane;
+    bool c9 = false, c9i = false;
+    int off = 0;
+    if (p < npix) {
+      const int yq = (int)(((float)p + 0.5f) * inv_dwid);
+      const int yy = yq + 3, xx = p - yq * dwid + 3;
+      off = yy * tp + ox + xx;
+      const uint8_t *c = &tile[off];
+      const int v = c[0];
+      const int d0 = v - c[3 * tp], d4 = v - c[3], d8 = v - c[-3 * tp], d12 = v - c[-3];
+      {
+        const int T = K.minTh;
+        const bool b0 = d0 > T, b4 = d4 > T, b8 = d8 > T, b12 = d12 > T;
+        const bool n0 = d0 < -T, n4 = d4 < -T, n8 = d8 < -T, n12 = d12 < -T;
+        c9 = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0) | (n0 & n4) | (n4 & n8) | (n8 & n12) | (n12 & n0);
+      }
+      if (c9) {
+        const int T = K.iniTh;
+        const bool b0 = d0 > T, b4 = d4 > T, b8 = d8 > T, b12 = d12 > T;
+        const bool n0 = d0 < -T, n4 = d4 < -T, n8 = d8 < -T, n12 = d12 < -T;
+        c9i = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0) | (n0 & n4) | (n4 & n8) | (n8 & n12) | (n12 & n0);
+      }
+    }
+    const unsigned long long mA = __ballot(c9i), mB = __ballot(c9 && !c9i);
+    if (c9i) s_list[nlA + __popcll(mA & lt)] = (unsigned short)off;
+    else if (c9) s_list[cap - 1 - (nlB + __popcll(mB & lt))] = (unsigned short)off;
+    nlA += __popcll(mA);
+    nlB += __popcll(mB);
   }
   __syncthreads();
-  // raster-ordered emission: thread t owns raster positions [t*chunk, (t+1)*chunk)
-  const int chunk = (npix + 255) / 256;
-  const int p0 = min(tid * chunk, npix), p1 = min(p0 + chunk, npix);
   for (int pass = 0; pass < 2; pass++) {
     const int T = pass == 0 ? K.iniTh : K.minTh;
-    unsigned long long keep = 0;  // chunk <= 64 always (npix <= 60*60, 256 threads -> <= 15)
-    int cnt = 0;
-    for (int p = p0; p < p1; p++) {
-      const int yy = p / dwid + 3, xx = p - (yy - 3) * dwid + 3;
-      const uint8_t *q = &sc[yy * tp + ox + xx];
-      const int s = q[0];
-      if (s < T) continue;
-      // neighbours below T count as 0 (not corners in this cv::FAST call); the rim holds 0
-      int m = 0;
-#define NB(o) { const int n_ = q[o]; m = max(m, n_ >= T ? n_ : 0); }
-      NB(-1) NB(1) NB(-tp - 1) NB(-tp) NB(-tp + 1) NB(tp - 1) NB(tp) NB(tp + 1)
-#undef NB
-      if (s > m) { keep |= 1ull << (p - p0); cnt++; }
+    // ---- scores: pass 0 scores list A, pass 1 list B
+    {
+      const int n = pass == 0 ? nlA : nlB;
+      const unsigned short *lst = pass == 0 ? s_list : s_list + cap - nlB;
+      for (int i = lane; i < n; i += 64) {
+        const int o = lst[i];
+        sc[o] = (uint8_t)max(fast_score16(&tile[o], tp), 0);
+      }
     }
-    int total;
-    const int ex = block_excl_scan256(cnt, s_w, &total);
-    if (total == 0) continue;  // uniform: retry with minThFAST (ORBextractor.cc:811-816)
-    if (tid == 0) s_base = atomicAdd(&candCount[b * K.nlevels + l], total);
     __syncthreads();
-    uint32_t *out = cand + (long long)b * K.candStride + Lv.candBase + s_base + ex;
-    for (int p = p0; p < p1; p++) {
-      if (!((keep >> (p - p0)) & 1)) continue;
-      const int yy = p / dwid + 3, xx = p - (yy - 3) * dwid + 3;
-      *out++ = (uint32_t)(x0 + xx) | ((uint32_t)(y0 + yy) << 12) | ((uint32_t)sc[yy * tp + ox + xx] << 24);
+    if (K.dbg == 2) { if (sc[lane] == 255) cand[0] = 1; return; }
+    // ---- 3x3 strict non-max suppression over the candidate list (only listed pixels can hold a score >= T);
+    //      neighbours below T count as 0, the rim holds 0
+    int total = 0;
+    const float inv_tp = 1.0f / (float)tp;
+    const int nl = pass == 0 ? nlA : nlA + nlB;  // pass 1 visits A then B
+    for (int base = 0; base < nl; base += 64) {
+      const int i = base + lane;
+      bool keep = false;
+      uint32_t rec = 0;
+      if (i < nl) {
+        const int o = i < nlA ? s_list[i] : s_list[cap - nlB + (i - nlA)];
+        const uint8_t *q = &sc[o];
+        const int sv = q[0];
+        if (sv >= T) {
+          int mx = 0;
+#define NB(o_) { const int n_ = q[o_]; mx = max(mx, n_ >= T ? n_ : 0); }
+          NB(-1) NB(1) NB(-tp - 1) NB(-tp) NB(-tp + 1) NB(tp - 1) NB(tp) NB(tp + 1)
+#undef NB
+          keep = sv > mx;
+          const int yy = (int)(((float)o + 0.5f) * inv_tp), xx = o - yy * tp - ox;
+          rec = (uint32_t)(x0 + xx) | ((uint32_t)(y0 + yy) << 12) | ((uint32_t)sv << 24);
+        }
+      }
+      const unsigned long long m = __ballot(keep);
+      if (keep) s_out[total + __popcll(m & lt)] = rec;
+      total += __popcll(m);
     }
+    if (K.dbg == 3) { if (total == 12345) cand[0] = 1; return; }
+    if (total == 0) continue;  // wave-uniform: retry with minThFAST
+    __syncthreads();
+    int gbase = 0;
+    if (lane == 0) gbase = atomicAdd(&candCount[b * K.nlevels + l], total);
+    gbase = __shfl(gbase, 0, 64);
+    uint32_t *out = cand + (long long)b * K.candStride + Lv.candBase + gbase;
+    for (int i = lane; i < total; i += 64) out[i] = s_out[i];
     break;
   }
 }
@@ -472,7 +571,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
 // One wave per keypoint: orientation (IC_Angle), 7x7 Gaussian blur of the 37x37 footprint,
 // 256 steered BRIEF tests, and the final cv::KeyPoint record.
 // ------------------------------------------------------------------------------------------
-constexpr int RP = 43, RPITCH = 44;  // raw patch 43x43 (radius 21)
+constexpr int RP = 43, RPITCH = 48;  // raw patch 43x43 (radius 21), rows staged as 12 dwords
 constexpr int BP = 37;               // blurred footprint (radius 18)
 
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -486,7 +585,7 @@ __global__ __launch_bounds__(64) void k_describe(OrbK K, const uint8_t *__restri
                                                  const uint32_t *__restrict__ lvlOut, const int *__restrict__ lvlCount,
                                                  fb_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                  int32_t *__restrict__ nOut) {
-  __shared__ uint8_t raw[RP * RPITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t raw[RP * RPITCH];
   __shared__ unsigned short hb[RP * BP];
   __shared__ uint8_t bl[BP * BP + 3];
   __shared__ __attribute__((aligned(16))) uint8_t dbytes[32];
@@ -508,17 +607,32 @@ __global__ __launch_bounds__(64) void k_describe(OrbK K, const uint8_t *__restri
   int pitch;
   if (myl == 0) { img = img0 + (long long)b * imgStride; pitch = pitch0; }
   else { img = pyr + (long long)b * K.pyrStride + Lv.off; pitch = Lv.pitch; }
-  for (int i = lane; i < RP * RP; i += 64) {
-    const int yy = i / RP, xx = i - yy * RP;
-    const int sx = reflect101(cx - 21 + xx, Lv.w), sy = reflect101(cy - 21 + yy, Lv.h);
-    raw[yy * RPITCH + xx] = img[(long long)sy * pitch + sx];
+  // patch rows as aligned dwords when the 43x43 window is inside the level (the common case); keypoints closer
+  // than 21 px to the border (they are >= 19 px inside) take the byte path with BORDER_REFLECT_101
+  const bool inside = cx - 21 >= 0 && cy - 21 >= 0 && cx + 25 < Lv.w && cy + 21 < Lv.h &&
+                      ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch) & 3) == 0;
+  int ox = 0;
+  if (inside) {
+    const int xa = (cx - 21) & ~3;
+    ox = (cx - 21) - xa;
+    const uint8_t *base = img + (long long)(cy - 21) * pitch + xa;
+    for (int i = lane; i < RP * 12; i += 64) {
+      const int yy = i / 12, xw = i - yy * 12;
+      reinterpret_cast<uint32_t *>(raw)[i] = *reinterpret_cast<const uint32_t *>(base + (long long)yy * pitch + xw * 4);
+    }
+  } else {
+    for (int i = lane; i < RP * RP; i += 64) {
+      const int yy = i / RP, xx = i - yy * RP;
+      const int sx = reflect101(cx - 21 + xx, Lv.w), sy = reflect101(cy - 21 + yy, Lv.h);
+      raw[yy * RPITCH + xx] = img[(long long)sy * pitch + sx];
+    }
   }
   __syncthreads();
   // IC_Angle (ORBextractor.cc:77-104): lane v+15 sums row v of the circular patch
   int m10 = 0, m01 = 0;
   if (lane < 31) {
     const int v = lane - 15, dmax = K.umax[v < 0 ? -v : v];
-    const uint8_t *row = &raw[(21 + v) * RPITCH + 21];
+    const uint8_t *row = &raw[(21 + v) * RPITCH + ox + 21];
     int rs = 0;
     for (int u = -dmax; u <= dmax; u++) { const int val = row[u]; m10 += u * val; rs += val; }
     m01 = v * rs;
@@ -529,7 +643,7 @@ __global__ __launch_bounds__(64) void k_describe(OrbK K, const uint8_t *__restri
   // separable blur, integer kernel {18,34,49,55,49,34,18}, (sum + 2^15) >> 16 (oracle gaussian_blur7)
   for (int i = lane; i < RP * BP; i += 64) {
     const int yy = i / BP, xx = i - yy * BP;
-    const uint8_t *r = &raw[yy * RPITCH + xx];
+    const uint8_t *r = &raw[yy * RPITCH + ox + xx];
     hb[i] = (unsigned short)(18 * (r[0] + r[6]) + 34 * (r[1] + r[5]) + 49 * (r[2] + r[4]) + 55 * r[3]);
   }
   __syncthreads();
@@ -725,6 +839,22 @@ int prepare(fb_orb *o, int w, int h, int batch) {
     pw = L.w; ph = L.h;
   }
   K.totalCells = cells;
+  for (int l = 0; l <= FB_MAX_LEVELS; l++) K.cellBase[l] = l < p.nlevels ? K.L[l].cellBase : cells;
+  K.dbg = getenv("FB_FAST_DBG") ? atoi(getenv("FB_FAST_DBG")) : 0;
+  {
+    int tileB = 0, maxOut = 0, maxPix = 0;
+    for (int l = 0; l < p.nlevels; l++) {
+      const LevelInfo &L = K.L[l];
+      if (L.nCols * L.nRows == 0) continue;
+      const int tpMax = (L.wCell + 6 + 3 + 3) & ~3, chMax = L.hCell + 6;
+      tileB = std::max(tileB, tpMax * chMax);
+      maxOut = std::max(maxOut, ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2));
+      maxPix = std::max(maxPix, L.wCell * L.hCell);
+    }
+    K.fastTileBytes = (tileB + 15) & ~15;
+    K.fastMaxOut = (maxOut + 3) & ~3;
+    K.fastMaxPix = (maxPix + 7) & ~7;
+  }
   K.pyrStride = (pyrOff + 255) & ~255ll;
   K.candStride = candOff;
   K.outStride = outOff;
@@ -808,7 +938,7 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
   }
   if (K.totalCells > 0) {
     fb::ProfScope prof_(fb::P_FAST, s);
-    k_fast<<<dim3(K.totalCells, batch), 256, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
+    k_fast<<<dim3(K.totalCells, batch), 64, (size_t)2 * K.fastTileBytes + 4 * K.fastMaxOut + 2 * K.fastMaxPix, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
                                                       o->cand.as<uint32_t>(), candCount);
   }
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->octreeLds));

@@ -62,6 +62,11 @@ class FramePipeline:
         self.e_bxw, self.e_bxc = z(B, cap, 3, dt=torch.float32), z(B, cap, 3, dt=torch.float32)
         self.e_binf, self.e_bvalid, self.e_bout = z(B, cap, dt=torch.float32), z(B, cap), z(B, cap)
         self.ninl = z(B, dt=torch.int32)
+        self.e_nf, self.e_nb = z(B, dt=torch.int32), z(B, dt=torch.int32)  # slot counts seen by the pose stage
+        # three streams: front chain, bird chain, pose optimisation (latency-bound, overlaps the next extraction)
+        self.sF, self.sB, self.sP = (torch.cuda.Stream(device=d) for _ in range(3))
+        self.evF, self.evB, self.evP = (torch.cuda.Event() for _ in range(3))
+        self._pose_pending = False
         self._inv_sigma2 = (C.c_float * cabi.FB_MAX_LEVELS)(*self.tables.inv_level_sigma2)
         self._Tcb12 = (C.c_float * 12)(*[float(x) for x in self.Tcb[:3, :4].reshape(12)])
         self._build_args()
@@ -98,49 +103,96 @@ class FramePipeline:
         self.a_m9 = m
         p = cabi.PoseOptArgs()
         fill(p, batch=B, mode=cabi.FB_POSE_FRONT_BIRD, front_stride=cap, bird_stride=cap, fx=self.fx, fy=self.fy,
-             cx=self.cx, cy=self.cy, wF=1.0, wB=1.0, n_front=self.f_n, front_xw=self.e_fxw, front_obs=self.e_fobs,
-             front_inv_sigma2=self.e_finf, front_valid=self.e_fvalid, n_bird=self.b_n, bird_xw=self.e_bxw,
+             cx=self.cx, cy=self.cy, wF=1.0, wB=1.0, n_front=self.e_nf, front_xw=self.e_fxw, front_obs=self.e_fobs,
+             front_inv_sigma2=self.e_finf, front_valid=self.e_fvalid, n_bird=self.e_nb, bird_xw=self.e_bxw,
              bird_xc=self.e_bxc, bird_inv_sigma2=self.e_binf, bird_valid=self.e_bvalid, bird_outlier=self.e_bout,
              Tcw=self.Tcw, front_outlier=self.e_fout, ninliers=self.ninl)
         self.a_pose = p
 
     # ---- stages ----
-    def extract(self, s):
+    def extract(self, s, which="both"):
         L, B = self.L, self.B
-        check(L.fb_orb_extract_batch_dev(self.orb_f, _vp(self.f_img), B, self.fw, self.fh, self.fw, C.c_size_t(self.fw * self.fh),
-                                         _vp(self.f_kps), _vp(self.f_desc), _vp(self.f_n), s), "extract front")
-        check(L.fb_orb_extract_batch_dev(self.orb_b, _vp(self.b_img), B, self.bw, self.bh, self.bw, C.c_size_t(self.bw * self.bh),
-                                         _vp(self.b_kps), _vp(self.b_desc), _vp(self.b_n), s), "extract bird")
+        if which in ("both", "front"):
+            check(L.fb_orb_extract_batch_dev(self.orb_f, _vp(self.f_img), B, self.fw, self.fh, self.fw, C.c_size_t(self.fw * self.fh),
+                                             _vp(self.f_kps), _vp(self.f_desc), _vp(self.f_n), s), "extract front")
+        if which in ("both", "bird"):
+            check(L.fb_orb_extract_batch_dev(self.orb_b, _vp(self.b_img), B, self.bw, self.bh, self.bw, C.c_size_t(self.bw * self.bh),
+                                             _vp(self.b_kps), _vp(self.b_desc), _vp(self.b_n), s), "extract bird")
 
-    def grids(self, s):
+    def grids(self, s, which="both"):
         L, B, cap = self.L, self.B, self.cap
-        check(L.fb_grid_build_batch_dev(_vp(self.f_kps), _vp(self.f_n), B, cap, C.byref(self.geom_f), _vp(self.f_cs), _vp(self.f_ci), s), "grid front")
-        check(L.fb_grid_build_batch_dev(_vp(self.b_kps), _vp(self.b_n), B, cap, C.byref(self.geom_b), _vp(self.b_cs), _vp(self.b_ci), s), "grid bird")
-        check(L.fb_bird_keys_to_cam_dev(_vp(self.b_kps), _vp(self.b_n), B, cap, self.bw, self.bh, C.c_double(synth.PIXEL2METER),
-                                        C.c_double(synth.REAR_AXLE_TO_CENTER), self._Tcb12, _vp(self.b_cam), s), "bird cam")
+        if which in ("both", "front"):
+            check(L.fb_grid_build_batch_dev(_vp(self.f_kps), _vp(self.f_n), B, cap, C.byref(self.geom_f), _vp(self.f_cs), _vp(self.f_ci), s), "grid front")
+        if which in ("both", "bird"):
+            check(L.fb_grid_build_batch_dev(_vp(self.b_kps), _vp(self.b_n), B, cap, C.byref(self.geom_b), _vp(self.b_cs), _vp(self.b_ci), s), "grid bird")
+            check(L.fb_bird_keys_to_cam_dev(_vp(self.b_kps), _vp(self.b_n), B, cap, self.bw, self.bh, C.c_double(synth.PIXEL2METER),
+                                            C.c_double(synth.REAR_AXLE_TO_CENTER), self._Tcb12, _vp(self.b_cam), s), "bird cam")
 
-    def match(self, s):
-        self.m_bird.fill_(-1)  # mvpMapPointsBird starts empty for a new frame
+    def match_front(self, s):
         check(self.L.fb_match_projection_frame_dev(C.byref(self.a_m3), s), "M3")
+
+    def match_bird(self, s):
+        self.m_bird.fill_(-1)  # mvpMapPointsBird starts empty for a new frame
         check(self.L.fb_match_bird_mappoints_dev(C.byref(self.a_m9), s), "M9")
 
-    def pose(self, s):
-        L, B, cap = self.L, self.B, self.cap
-        nl = self.params.nlevels
+    def gather_front(self, s):
+        L, B, cap, nl = self.L, self.B, self.cap, self.params.nlevels
+        self.e_nf.copy_(self.f_n)
         check(L.fb_pose_gather_front_dev(B, cap, self.nl, _vp(self.f_n), _vp(self.f_kps), _vp(self.m_front), _vp(self.last["xw"]),
                                          self._inv_sigma2, nl, _vp(self.e_fxw), _vp(self.e_fobs), _vp(self.e_finf), _vp(self.e_fvalid), s), "gather front")
+
+    def gather_bird(self, s):
+        L, B, cap, nl = self.L, self.B, self.cap, self.params.nlevels
+        self.e_nb.copy_(self.b_n)
         check(L.fb_pose_gather_bird_dev(B, cap, self.nr, _vp(self.b_n), _vp(self.b_kps), _vp(self.b_cam), _vp(self.m_bird), _vp(self.ref["xw"]),
                                         self._inv_sigma2, nl, _vp(self.e_bxw), _vp(self.e_bxc), _vp(self.e_binf), _vp(self.e_bvalid), s), "gather bird")
+
+    def pose(self, s):
         self.Tcw.copy_(self.Tcw0)   # SetPose(prediction), Tracking.cc:1314-1320
         self.e_bout.zero_()         # mvBirdOutlier of a fresh Frame
-        check(L.fb_pose_opt_batch_dev(C.byref(self.a_pose), s), "pose opt")
+        check(self.L.fb_pose_opt_batch_dev(C.byref(self.a_pose), s), "pose opt")
 
     def step(self):
-        """One pass of the hot path over the batch (enqueued on torch's current stream)."""
+        """One pass of the hot path over the batch.  The front chain and the bird chain run on their own streams;
+        the pose optimisation (one workgroup per frame, latency bound) runs on a third one so that it overlaps the
+        next step's extraction.  Callers synchronise with torch.cuda.synchronize() / results_host()."""
+        cur = torch.cuda.current_stream(self.dev)
+        self.sF.wait_stream(cur)
+        self.sB.wait_stream(cur)
+        with torch.cuda.stream(self.sF):
+            s = C.c_void_p(self.sF.cuda_stream)
+            self.extract(s, "front")
+            self.grids(s, "front")
+            self.match_front(s)
+            if self._pose_pending:
+                self.sF.wait_event(self.evP)  # the previous step's pose kernel still reads the edge arrays
+            self.gather_front(s)
+            self.evF.record(self.sF)
+        with torch.cuda.stream(self.sB):
+            s = C.c_void_p(self.sB.cuda_stream)
+            self.extract(s, "bird")
+            self.grids(s, "bird")
+            self.match_bird(s)
+            if self._pose_pending:
+                self.sB.wait_event(self.evP)
+            self.gather_bird(s)
+            self.evB.record(self.sB)
+        with torch.cuda.stream(self.sP):
+            self.sP.wait_event(self.evF)
+            self.sP.wait_event(self.evB)
+            self.pose(C.c_void_p(self.sP.cuda_stream))
+            self.evP.record(self.sP)
+            self._pose_pending = True
+
+    def step_serial(self):
+        """The same pass on torch's current stream only (used by tests and for single-stream timing)."""
         s = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         self.extract(s)
         self.grids(s)
-        self.match(s)
+        self.match_front(s)
+        self.match_bird(s)
+        self.gather_front(s)
+        self.gather_bird(s)
         self.pose(s)
 
     # ---- synthetic world (untimed setup) ----
