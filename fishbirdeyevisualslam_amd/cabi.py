@@ -103,6 +103,28 @@ class BirdviewArgs(C.Structure):
                 ("match_ref_to_cur", _vp), ("match_dist", _vp), ("nmatches", _vp), ("n_dmatches", _vp)]
 
 
+class FeatureVector(C.Structure):
+    _fields_ = [("node_stride", _i32), ("item_stride", _i32), ("n_nodes", _vp), ("node_ids", _vp), ("node_start", _vp),
+                ("items", _vp)]
+
+
+class BowArgs(C.Structure):
+    _fields_ = [("batch", _i32), ("kf_stride", _i32), ("f_stride", _i32),
+                ("n_kf", _vp), ("kf_kps", _vp), ("kf_desc", _vp), ("kf_has_mp", _vp), ("kf_fv", FeatureVector),
+                ("n_f", _vp), ("f_kps", _vp), ("f_desc", _vp), ("f_fv", FeatureVector),
+                ("matcher", MatcherParams), ("match_f_to_kf", _vp), ("nmatches", _vp)]
+
+
+class TriangulationArgs(C.Structure):
+    _fields_ = [("batch", _i32), ("kf1_stride", _i32), ("kf2_stride", _i32),
+                ("n1", _vp), ("kps1", _vp), ("desc1", _vp), ("has_mp1", _vp), ("fv1", FeatureVector),
+                ("n2", _vp), ("kps2", _vp), ("desc2", _vp), ("has_mp2", _vp), ("fv2", FeatureVector),
+                ("F12", _vp), ("Cw1", _vp), ("R2w", _vp), ("t2w", _vp),
+                ("fx", _f32), ("fy", _f32), ("cx", _f32), ("cy", _f32),
+                ("scale_factors", _f32 * FB_MAX_LEVELS), ("level_sigma2", _f32 * FB_MAX_LEVELS),
+                ("matcher", MatcherParams), ("matches12", _vp), ("nmatches", _vp)]
+
+
 class PoseOptArgs(C.Structure):
     _fields_ = [("batch", _i32), ("mode", _i32), ("front_stride", _i32), ("bird_stride", _i32),
                 ("fx", _f32), ("fy", _f32), ("cx", _f32), ("cy", _f32), ("wF", _f32), ("wB", _f32),
@@ -150,6 +172,7 @@ EXPORTS = [
     "fb_match_bird_mappoints_dev", "fb_match_bird_mappoints",
     "fb_match_projection_points_dev", "fb_match_projection_points",
     "fb_match_birdview_dev", "fb_match_birdview",
+    "fb_match_bow_dev", "fb_match_bow", "fb_match_triangulation_dev", "fb_match_triangulation",
     "fb_pose_opt_batch_dev", "fb_pose_opt", "fb_pose_gather_front_dev", "fb_pose_gather_bird_dev",
     "fb_local_ba",
 ]

@@ -279,6 +279,65 @@ typedef struct fb_birdview_args {
 int fb_match_birdview_dev(const fb_birdview_args *args, void *stream);
 int fb_match_birdview(const fb_birdview_args *args);
 
+/* DBoW2::FeatureVector (Thirdparty/DBoW2/DBoW2/FeatureVector.h:23) = map<NodeId, vector<unsigned>> as CSR:
+ * node ids ascending, node n owns items[node_start[n] .. node_start[n+1]) in addFeature order.          */
+typedef struct fb_feature_vector {
+  int32_t node_stride;        /* entries per problem in node_ids (node_start has node_stride+1)   */
+  int32_t item_stride;        /* entries per problem in items                                      */
+  const int32_t *n_nodes;     /* [batch]                                                            */
+  const uint32_t *node_ids;   /* [batch][node_stride]                                               */
+  const int32_t *node_start;  /* [batch][node_stride+1]                                             */
+  const int32_t *items;       /* [batch][item_stride] feature indices                               */
+} fb_feature_vector;
+
+/* --- M5: SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*>&) (ORBmatcher.cc:160-289) */
+typedef struct fb_bow_args {
+  int32_t batch;
+  int32_t kf_stride, f_stride;
+  const int32_t *n_kf;          /* pKF->N                                                            */
+  const fb_keypoint *kf_kps;    /* pKF->mvKeysUn (angle)                                             */
+  const uint8_t *kf_desc;
+  const uint8_t *kf_has_mp;     /* vpMapPointsKF[i] && !isBad()                                      */
+  fb_feature_vector kf_fv;      /* pKF->mFeatVec                                                     */
+  const int32_t *n_f;           /* F.N                                                               */
+  const fb_keypoint *f_kps;     /* F.mvKeys (angle)                                                  */
+  const uint8_t *f_desc;
+  fb_feature_vector f_fv;       /* F.mFeatVec                                                        */
+  fb_matcher_params matcher;    /* ORBmatcher(0.7,true) at Tracking.cc:1207                          */
+  int32_t *match_f_to_kf;       /* [batch][f_stride]: KF feature whose MapPoint lands in slot i, -1  */
+  int32_t *nmatches;            /* [batch]                                                           */
+} fb_bow_args;
+int fb_match_bow_dev(const fb_bow_args *args, void *stream);
+int fb_match_bow(const fb_bow_args *args);
+
+/* --- M7: SearchForTriangulation(pKF1, pKF2, F12, pairs, bOnlyStereo=false) (ORBmatcher.cc:658-824) */
+typedef struct fb_triangulation_args {
+  int32_t batch;
+  int32_t kf1_stride, kf2_stride;
+  const int32_t *n1;
+  const fb_keypoint *kps1;      /* pKF1->mvKeysUn                                                    */
+  const uint8_t *desc1;
+  const uint8_t *has_mp1;       /* pKF1->GetMapPoint(i) != NULL                                      */
+  fb_feature_vector fv1;
+  const int32_t *n2;
+  const fb_keypoint *kps2;
+  const uint8_t *desc2;
+  const uint8_t *has_mp2;
+  fb_feature_vector fv2;
+  const float *F12;             /* [batch][9] row-major                                              */
+  const float *Cw1;             /* [batch][3] pKF1->GetCameraCenter()                                */
+  const float *R2w;             /* [batch][9] pKF2->GetRotation()                                    */
+  const float *t2w;             /* [batch][3]                                                        */
+  float fx, fy, cx, cy;         /* pKF2 intrinsics                                                   */
+  float scale_factors[FB_MAX_LEVELS]; /* pKF2->mvScaleFactors                                        */
+  float level_sigma2[FB_MAX_LEVELS];  /* pKF2->mvLevelSigma2                                         */
+  fb_matcher_params matcher;    /* ORBmatcher(0.6,false) at LocalMapping.cc:239                      */
+  int32_t *matches12;           /* [batch][kf1_stride] vMatches12                                    */
+  int32_t *nmatches;            /* [batch]                                                           */
+} fb_triangulation_args;
+int fb_match_triangulation_dev(const fb_triangulation_args *args, void *stream);
+int fb_match_triangulation(const fb_triangulation_args *args);
+
 /* ======================================================================== */
 /* Optimizer::PoseOptimization / PoseOptimizationWithBird / BirdOptimization */
 /* (include/Optimizer.h:40-68, src/Optimizer.cc:246-835)                     */

@@ -403,3 +403,150 @@ int orc_match_birdview(const fb_birdview_args *A) {
 }
 
 }  // extern "C"
+
+// ---- BoW-gated matchers -------------------------------------------------------------------------------------
+namespace {
+struct FV {  // one problem's DBoW2::FeatureVector view
+  int n;
+  const uint32_t *ids;
+  const int32_t *start;
+  const int32_t *items;
+};
+FV fv_of(const fb_feature_vector &v, int b) {
+  return FV{v.n_nodes[b], v.node_ids + (size_t)b * v.node_stride, v.node_start + (size_t)b * (v.node_stride + 1),
+            v.items + (size_t)b * v.item_stride};
+}
+int lower_bound_node(const FV &v, uint32_t id) {  // std::map::lower_bound
+  int lo = 0, hi = v.n;
+  while (lo < hi) { int m = (lo + hi) / 2; if (v.ids[m] < id) lo = m + 1; else hi = m; }
+  return lo;
+}
+}  // namespace
+
+extern "C" {
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&), ORBmatcher.cc:160-289
+int orc_match_bow(const fb_bow_args *A) {
+  for (int b = 0; b < A->batch; b++) {
+    const size_t ko = (size_t)b * A->kf_stride, fo = (size_t)b * A->f_stride;
+    const int nF = A->n_f[b];
+    const FV K = fv_of(A->kf_fv, b), F = fv_of(A->f_fv, b);
+    int32_t *match = A->match_f_to_kf + fo;
+    for (int i = 0; i < nF; i++) match[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int nmatches = 0;
+    int ki = 0, fi = 0;
+    while (ki < K.n && fi < F.n) {
+      if (K.ids[ki] == F.ids[fi]) {
+        for (int a = K.start[ki]; a < K.start[ki + 1]; a++) {
+          const int realIdxKF = K.items[a];
+          if (!A->kf_has_mp[ko + realIdxKF]) continue;
+          const uint8_t *dKF = A->kf_desc + (ko + realIdxKF) * 32;
+          int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+          for (int c = F.start[fi]; c < F.start[fi + 1]; c++) {
+            const int realIdxF = F.items[c];
+            if (match[realIdxF] >= 0) continue;
+            const int dist = descriptor_distance(dKF, A->f_desc + (fo + realIdxF) * 32);
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+            else if (dist < bestDist2) bestDist2 = dist;
+          }
+          if (bestDist1 <= TH_LOW) {
+            if ((float)bestDist1 < A->matcher.nnratio * (float)bestDist2) {
+              match[bestIdxF] = realIdxKF;
+              if (A->matcher.check_orientation) {
+                float rot = A->kf_kps[ko + realIdxKF].angle - A->f_kps[fo + bestIdxF].angle;
+                rotHist[rot_bin(rot)].push_back(bestIdxF);
+              }
+              nmatches++;
+            }
+          }
+        }
+        ki++; fi++;
+      } else if (K.ids[ki] < F.ids[fi]) ki = lower_bound_node(K, F.ids[fi]);
+      else fi = lower_bound_node(F, K.ids[ki]);
+    }
+    if (A->matcher.check_orientation) {
+      int sz[HISTO_LENGTH], ind1, ind2, ind3;
+      for (int i = 0; i < HISTO_LENGTH; i++) sz[i] = (int)rotHist[i].size();
+      three_maxima(sz, HISTO_LENGTH, ind1, ind2, ind3);
+      for (int i = 0; i < HISTO_LENGTH; i++) {
+        if (i == ind1 || i == ind2 || i == ind3) continue;
+        for (int idx : rotHist[i]) { match[idx] = -1; nmatches--; }
+      }
+    }
+    A->nmatches[b] = nmatches;
+  }
+  return FB_OK;
+}
+
+// ORBmatcher::SearchForTriangulation (bOnlyStereo=false, mono keyframes), ORBmatcher.cc:658-824,
+// CheckDistEpipolarLine :141-158
+int orc_match_triangulation(const fb_triangulation_args *A) {
+  for (int b = 0; b < A->batch; b++) {
+    const size_t o1 = (size_t)b * A->kf1_stride, o2 = (size_t)b * A->kf2_stride;
+    const int n1 = A->n1[b];
+    const FV V1 = fv_of(A->fv1, b), V2 = fv_of(A->fv2, b);
+    const float *F12 = A->F12 + (size_t)b * 9, *Cw = A->Cw1 + (size_t)b * 3, *R = A->R2w + (size_t)b * 9, *t = A->t2w + (size_t)b * 3;
+    float C2[3];
+    for (int r = 0; r < 3; r++) C2[r] = ((R[r * 3] * Cw[0] + R[r * 3 + 1] * Cw[1]) + R[r * 3 + 2] * Cw[2]) + t[r];
+    const float invz = 1.0f / C2[2];
+    const float ex = A->fx * C2[0] * invz + A->cx, ey = A->fy * C2[1] * invz + A->cy;
+    int32_t *m12 = A->matches12 + o1;
+    for (int i = 0; i < n1; i++) m12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int nmatches = 0;
+    int i1n = 0, i2n = 0;
+    while (i1n < V1.n && i2n < V2.n) {
+      if (V1.ids[i1n] == V2.ids[i2n]) {
+        for (int a = V1.start[i1n]; a < V1.start[i1n + 1]; a++) {
+          const int idx1 = V1.items[a];
+          if (A->has_mp1[o1 + idx1]) continue;
+          const fb_keypoint &kp1 = A->kps1[o1 + idx1];
+          const uint8_t *d1 = A->desc1 + (o1 + idx1) * 32;
+          int bestDist = TH_LOW, bestIdx2 = -1;
+          for (int c = V2.start[i2n]; c < V2.start[i2n + 1]; c++) {
+            const int idx2 = V2.items[c];
+            if (A->has_mp2[o2 + idx2]) continue;  // vbMatched2 is never set in the reference
+            const int dist = descriptor_distance(d1, A->desc2 + (o2 + idx2) * 32);
+            if (dist > TH_LOW || dist > bestDist) continue;
+            const fb_keypoint &kp2 = A->kps2[o2 + idx2];
+            const float distex = ex - kp2.x, distey = ey - kp2.y;
+            if (distex * distex + distey * distey < 100 * A->scale_factors[kp2.octave]) continue;
+            // CheckDistEpipolarLine
+            const float la = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+            const float lb = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+            const float lc = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+            const float num = la * kp2.x + lb * kp2.y + lc;
+            const float den = la * la + lb * lb;
+            if (den == 0) continue;
+            const float dsqr = num * num / den;
+            if (dsqr < 3.84 * A->level_sigma2[kp2.octave]) { bestIdx2 = idx2; bestDist = dist; }
+          }
+          if (bestIdx2 >= 0) {
+            m12[idx1] = bestIdx2;
+            nmatches++;
+            if (A->matcher.check_orientation) {
+              float rot = kp1.angle - A->kps2[o2 + bestIdx2].angle;
+              rotHist[rot_bin(rot)].push_back(idx1);
+            }
+          }
+        }
+        i1n++; i2n++;
+      } else if (V1.ids[i1n] < V2.ids[i2n]) i1n = lower_bound_node(V1, V2.ids[i2n]);
+      else i2n = lower_bound_node(V2, V1.ids[i1n]);
+    }
+    if (A->matcher.check_orientation) {
+      int sz[HISTO_LENGTH], ind1, ind2, ind3;
+      for (int i = 0; i < HISTO_LENGTH; i++) sz[i] = (int)rotHist[i].size();
+      three_maxima(sz, HISTO_LENGTH, ind1, ind2, ind3);
+      for (int i = 0; i < HISTO_LENGTH; i++) {
+        if (i == ind1 || i == ind2 || i == ind3) continue;
+        for (int idx : rotHist[i]) { m12[idx] = -1; nmatches--; }
+      }
+    }
+    A->nmatches[b] = nmatches;
+  }
+  return FB_OK;
+}
+
+}  // extern "C"
