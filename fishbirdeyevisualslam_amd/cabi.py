@@ -146,6 +146,9 @@ class LocalBAArgs(C.Structure):
                 ("stop_flag", _vp), ("obs_outlier", _vp), ("bobs_outlier", _vp)]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), _i32, _i32)
+
+
 def fill(struct, **kw):
     """Set fields of a Structure; array-likes become pointers, lists fill fixed arrays."""
     for k, v in kw.items():
@@ -174,5 +177,5 @@ EXPORTS = [
     "fb_match_birdview_dev", "fb_match_birdview",
     "fb_match_bow_dev", "fb_match_bow", "fb_match_triangulation_dev", "fb_match_triangulation",
     "fb_pose_opt_batch_dev", "fb_pose_opt", "fb_pose_gather_front_dev", "fb_pose_gather_bird_dev",
-    "fb_local_ba",
+    "fb_local_ba", "fb_local_ba_sharded",
 ]

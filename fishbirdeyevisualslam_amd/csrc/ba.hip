@@ -575,7 +575,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lam
 // k_ba_update: back-substitution, trial state, scale term sum x (lambda x + b)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(LIN_THREADS) void k_ba_update(BADev D, LinBuf B, State cur, State trial, const double *Dinv,
-                                                           const double *xp, double lambda, double *scalePart) {
+                                                           const double *xp, double lambda, double *scalePart, int countPoses) {
   __shared__ double s_part[LIN_THREADS / 64];
   const int g = blockIdx.x * LIN_THREADS + threadIdx.x;
   double sc = 0;
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_update(BADev D, LinBuf B, St
     else {
       double u[6];
 #pragma unroll
-      for (int i = 0; i < 6; i++) { u[i] = xp[6 * pi + i]; sc += u[i] * (lambda * u[i] + B.bp[6 * pi + i]); }
+      for (int i = 0; i < 6; i++) { u[i] = xp[6 * pi + i]; if (countPoses) sc += u[i] * (lambda * u[i] + B.bp[6 * pi + i]); }
       trial.pose[k] = fb::se3_mul(fb::se3_exp(u), cur.pose[k]);
     }
   }
@@ -618,6 +618,15 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_update(BADev D, LinBuf B, St
     for (int i = 0; i < LIN_THREADS / 64; i++) s += s_part[i];
     scalePart[blockIdx.x] = s;
   }
+}
+
+// Spart[0] = sum over the workgroup partials (sharded BA: the local sum that goes through the all-reduce)
+__global__ void k_ba_sumparts(double *Spart, int nWg, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0;
+  for (int w = 0; w < nWg; w++) s += Spart[(size_t)w * n + i];
+  Spart[i] = s;
 }
 
 // sum of partials in index order + max |diag| (computeLambdaInit)
@@ -649,6 +658,10 @@ __global__ void k_ba_scalars(const double *part, int n, const double *Hpp, int P
 __global__ void k_ba_gate(BADev D, State S, int setLevel, uint8_t *outFlag) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= D.nE) return;
+  if (D.e_level[e] == 2) {  // edge owned by another rank of a sharded BA
+    if (!setLevel) outFlag[e] = 0;
+    return;
+  }
   const int type = D.e_type[e], l = D.e_pt[e];
   const SE3 T = S.pose[D.e_kf[e]];
   const double X[3] = {S.pt[3 * l], S.pt[3 * l + 1], S.pt[3 * l + 2]};
@@ -682,14 +695,32 @@ __global__ void k_ba_export(int n_kf, int npt, const SE3 *pose, const double *pt
 
 #define BA_UP(buf, vec) FB_TRY(buf.upload((vec).data(), (vec).size() * sizeof((vec)[0])))
 
-extern "C" int fb_local_ba(const fb_local_ba_args *A) {
+static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allreduce_fn allreduce, void *ctx);
+
+extern "C" int fb_local_ba(const fb_local_ba_args *A) { return local_ba_impl(A, 0, 1, nullptr, nullptr); }
+
+extern "C" int fb_local_ba_sharded(const fb_local_ba_args *A, int rank, int world, fb_allreduce_fn allreduce, void *ctx) {
+  FB_ARG(world >= 1 && rank >= 0 && rank < world && (world == 1 || allreduce));
+  return local_ba_impl(A, rank, world, allreduce, ctx);
+}
+
+// Landmark-partitioned BA: rank r owns the landmarks l with l % world == r and all their edges, the
+// odometry edges live on rank 0, the keyframe state is replicated.  Per LM trial two small all-reduces: the
+// Schur-reduced system (after k_ba_schur) and [Hpp, bp, chi2, scale] (after the linearisation at the trial state).
+static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allreduce_fn allreduce, void *ctx) {
   FB_TRY(fb::check_device());
+  const bool sharded = world > 1;
+  auto reduce = [&](double *buf, int n, int op) -> int {
+    if (!sharded || n <= 0) return FB_OK;
+    if (allreduce(ctx, buf, n, op) != 0) { fb::set_error("fb_local_ba_sharded: all-reduce callback failed"); return FB_ERR_ARG; }
+    return FB_OK;
+  };
   FB_ARG(A && A->n_kf > 0 && A->n_mp >= 0 && A->n_mpb >= 0 && A->n_obs >= 0 && A->kf_Tcw && A->kf_fixed);
   if (A->stop_flag && *A->stop_flag) return FB_OK;  // Optimizer.cc:902-906 / 2498-2500
   const bool odom = A->with_odom != 0;
   const int n_kf = A->n_kf, n_mp = A->n_mp, n_mpb = odom ? A->n_mpb : 0;
   const int npt = A->n_mp + A->n_mpb;  // bird points keep their slots even when unused
-  const int nF = A->n_obs, nB = odom ? A->n_bobs : 0, nE = nF + nB, nO = odom ? A->n_odom : 0;
+  const int nF = A->n_obs, nB = odom ? A->n_bobs : 0, nE = nF + nB, nO = (odom && rank == 0) ? A->n_odom : 0;
   (void)n_mpb;
   // ---- host preprocessing: indices, CSR by landmark / pose
   std::vector<int> poseIdx(n_kf, -1);
@@ -713,6 +744,8 @@ extern "C" int fb_local_ba(const fb_local_ba_args *A) {
     for (int k = 0; k < 3; k++) e_meas[3 * e + k] = A->bobs_xc[3 * i + k];
     e_info[e] = (1.0 * (double)A->bobs_inv_sigma2[i]) * (double)A->wB;
   }
+  if (sharded)
+    for (int e = 0; e < nE; e++) if (e_pt[e] % world != rank) e_level[e] = 2;  // not this rank's landmark
   std::vector<int> lm_start(npt + 1, 0), lm_edges(nE), ps_start(np + 1, 0), ps_edges;
   for (int e = 0; e < nE; e++) lm_start[e_pt[e] + 1]++;
   for (int l = 0; l < npt; l++) lm_start[l + 1] += lm_start[l];
@@ -786,6 +819,7 @@ extern "C" int fb_local_ba(const fb_local_ba_args *A) {
   FB_TRY(d_Dinv.alloc((size_t)npt * 9 * 8)); FB_TRY(d_Spart.alloc((size_t)nWg * rows * rows * 8));
   FB_TRY(d_xp.alloc((size_t)std::max(P6, 1) * 8)); FB_TRY(d_ok.alloc(4)); FB_TRY(d_scale.alloc((size_t)nUpdBlocks * 8));
   FB_TRY(d_scal.alloc(4 * 8));
+  FB_HIP(hipMemset(d_scal.p, 0, 4 * 8));
   const size_t schurLds = (size_t)2 * rows * KPAD * 8;
   const size_t solveLds = ((size_t)P6 * (P6 + 1) + P6 + 2) * 8;
   if (schurLds > 160 * 1024 || solveLds > 160 * 1024) { fb::set_error("fb_local_ba: %d free keyframes exceed the LDS-resident reduced system", np); return FB_ERR_CAPACITY; }
@@ -798,6 +832,7 @@ extern "C" int fb_local_ba(const fb_local_ba_args *A) {
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_odom), hipFuncAttributeMaxDynamicSharedMemorySize, (int)odomLds));
   hipStream_t s0 = nullptr;
 
+  double lastScale = 0;  // sum x (lambda x + b) of the most recent k_ba_update (all ranks)
   // one linearisation at state `si` into buffer `bi`; returns chi2 (and max diagonal when wanted)
   auto linearize = [&](int si, int bi, int robust, bool wantDiag, double *chi, double *maxDiag) -> int {
     if (P6 > 0) FB_HIP(hipMemsetAsync(lb[bi].Hpp, 0, (size_t)P6 * P6 * 8, s0));
@@ -807,10 +842,36 @@ extern "C" int fb_local_ba(const fb_local_ba_args *A) {
       k_ba_odom<<<1, 256, odomLds, s0>>>(D, st[si], lb[bi], P6, nLinBlocks); }
     { fb::ProfScope pr(fb::P_BA_MISC, s0);
       k_ba_scalars<<<1, 256, 0, s0>>>(lb[bi].chiPart, nLinBlocks + 1, lb[bi].Hpp, P6, lb[bi].Hll, npt, d_scal.as<double>(), wantDiag ? 1 : 0); }
-    double h[2];
-    FB_HIP(hipMemcpy(h, d_scal.p, 16, hipMemcpyDeviceToHost));
+    double h[3];
+    FB_HIP(hipMemcpy(h, d_scal.p, 24, hipMemcpyDeviceToHost));  // chi2, max diagonal, scale term of the last update
+    if (sharded) {
+      std::vector<double> ex((size_t)P6 * P6 + P6 + 2);
+      if (P6 > 0) {
+        FB_HIP(hipMemcpy(ex.data(), lb[bi].Hpp, (size_t)P6 * P6 * 8, hipMemcpyDeviceToHost));
+        FB_HIP(hipMemcpy(ex.data() + (size_t)P6 * P6, lb[bi].bp, (size_t)P6 * 8, hipMemcpyDeviceToHost));
+      }
+      ex[(size_t)P6 * P6 + P6] = h[0];
+      ex[(size_t)P6 * P6 + P6 + 1] = h[2];
+      FB_TRY(reduce(ex.data(), (int)ex.size(), 0));
+      if (P6 > 0) {
+        FB_HIP(hipMemcpy(lb[bi].Hpp, ex.data(), (size_t)P6 * P6 * 8, hipMemcpyHostToDevice));
+        FB_HIP(hipMemcpy(lb[bi].bp, ex.data() + (size_t)P6 * P6, (size_t)P6 * 8, hipMemcpyHostToDevice));
+      }
+      h[0] = ex[(size_t)P6 * P6 + P6];
+      h[2] = ex[(size_t)P6 * P6 + P6 + 1];
+      if (wantDiag) {  // the pose diagonals add up over the ranks: take the maximum on the REDUCED Hpp
+        double hp = 0;
+        for (int i = 0; i < P6; i++) hp = std::max(hp, std::fabs(ex[(size_t)i * P6 + i]));
+        k_ba_scalars<<<1, 256, 0, s0>>>(lb[bi].chiPart, 0, nullptr, 0, lb[bi].Hll, npt, d_scal.as<double>(), 1);
+        double hl[2];
+        FB_HIP(hipMemcpy(hl, d_scal.p, 16, hipMemcpyDeviceToHost));
+        h[1] = std::max(hp, hl[1]);
+        FB_TRY(reduce(&h[1], 1, 1));
+      }
+    }
     *chi = h[0];
     if (wantDiag) *maxDiag = h[1];
+    lastScale = h[2];
     return FB_OK;
   };
   // SparseOptimizer::optimize + OptimizationAlgorithmLevenberg::solve, host-driven
@@ -833,15 +894,24 @@ extern "C" int fb_local_ba(const fb_local_ba_args *A) {
         { fb::ProfScope pr(fb::P_BA_SCHUR, s0);
           schurKernel<<<nWg, SCHUR_THREADS, schurLds, s0>>>(D, lb[cur], lambda, d_Dinv.as<double>(), d_Spart.as<double>(), P6, NT, lmPerWg); }
         { fb::ProfScope pr(fb::P_BA_SOLVE, s0);
-          k_ba_solve<<<1, SOLVE_THREADS, solveLds, s0>>>(lb[cur], lambda, d_Spart.as<double>(), nWg, P6, NT, d_xp.as<double>(), d_ok.as<int>()); }
+          int nParts = nWg;
+          if (sharded) {  // exchange step 1: the Schur-reduced system
+            const int nS = rows * rows;
+            k_ba_sumparts<<<(nS + 255) / 256, 256, 0, s0>>>(d_Spart.as<double>(), nWg, nS);
+            std::vector<double> ex(nS);
+            FB_HIP(hipMemcpy(ex.data(), d_Spart.p, (size_t)nS * 8, hipMemcpyDeviceToHost));
+            FB_TRY(reduce(ex.data(), nS, 0));
+            FB_HIP(hipMemcpy(d_Spart.p, ex.data(), (size_t)nS * 8, hipMemcpyHostToDevice));
+            nParts = 1;
+          }
+          k_ba_solve<<<1, SOLVE_THREADS, solveLds, s0>>>(lb[cur], lambda, d_Spart.as<double>(), nParts, P6, NT, d_xp.as<double>(), d_ok.as<int>()); }
         { fb::ProfScope pr(fb::P_BA_UPDATE, s0);
-          k_ba_update<<<nUpdBlocks, LIN_THREADS, 0, s0>>>(D, lb[cur], st[cur], st[tr], d_Dinv.as<double>(), d_xp.as<double>(), lambda, d_scale.as<double>());
+          k_ba_update<<<nUpdBlocks, LIN_THREADS, 0, s0>>>(D, lb[cur], st[cur], st[tr], d_Dinv.as<double>(), d_xp.as<double>(), lambda, d_scale.as<double>(), rank == 0 ? 1 : 0);
           k_ba_scalars<<<1, 256, 0, s0>>>(d_scale.as<double>(), nUpdBlocks, nullptr, 0, nullptr, 0, d_scal.as<double>() + 2, 0); }
         double tempChi = 0, dummy = 0;
         FB_TRY(linearize(tr, tr, robust, false, &tempChi, &dummy));
-        double hs[1];
+        double hs[1] = {lastScale};  // exchange step 2 happened inside linearize()
         int ok2 = 1;
-        FB_HIP(hipMemcpy(hs, d_scal.as<double>() + 2, 8, hipMemcpyDeviceToHost));
         FB_HIP(hipMemcpy(&ok2, d_ok.p, 4, hipMemcpyDeviceToHost));
         if (!ok2) tempChi = 1.7976931348623157e308;
         rho = currentChi - tempChi;
@@ -885,11 +955,20 @@ extern "C" int fb_local_ba(const fb_local_ba_args *A) {
   FB_HIP(hipDeviceSynchronize());
   std::vector<uint8_t> flags(std::max(nE, 1));
   FB_TRY(d_flags.download(flags.data(), std::max(nE, 1)));
+  std::vector<float> po((size_t)std::max(npt, 1) * 3);
+  FB_TRY(d_ptOut.download(po.data(), (size_t)npt * 12));
+  if (sharded) {  // every rank returns the complete result: owned landmarks / edges are summed with zeros
+    std::vector<double> ex((size_t)npt * 3 + nE);
+    for (int l = 0; l < npt; l++)
+      for (int c = 0; c < 3; c++) ex[(size_t)3 * l + c] = (l % world == rank) ? (double)po[(size_t)3 * l + c] : 0.0;
+    for (int e = 0; e < nE; e++) ex[(size_t)npt * 3 + e] = flags[e];
+    FB_TRY(reduce(ex.data(), (int)ex.size(), 0));
+    for (size_t i = 0; i < (size_t)npt * 3; i++) po[i] = (float)ex[i];
+    for (int e = 0; e < nE; e++) flags[e] = ex[(size_t)npt * 3 + e] != 0.0;
+  }
   for (int i = 0; i < nF; i++) A->obs_outlier[i] = flags[i];
   for (int i = 0; i < nB; i++) A->bobs_outlier[i] = flags[nF + i];
   FB_TRY(d_kfT.download(A->kf_Tcw, (size_t)n_kf * 48));
-  std::vector<float> po((size_t)std::max(npt, 1) * 3);
-  FB_TRY(d_ptOut.download(po.data(), (size_t)npt * 12));
   for (int i = 0; i < 3 * n_mp; i++) A->mp_xw[i] = po[i];
   for (int i = 0; i < 3 * A->n_mpb; i++) A->mpb_xw[i] = po[3 * n_mp + i];
   return FB_OK;

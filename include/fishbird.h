@@ -427,6 +427,14 @@ typedef struct fb_local_ba_args {
 } fb_local_ba_args;
 int fb_local_ba(const fb_local_ba_args *args); /* host pointers */
 
+/* One local BA over `world` GPUs (one process per GPU), SURVEY 8(e): rank r owns the landmarks l with
+ * l % world == r and all their edges, odometry edges live on rank 0, keyframes are replicated.  Every rank
+ * passes the SAME complete problem and receives the complete result.  The library calls `allreduce` (the
+ * only callback of this ABI) to combine `n` doubles in host memory in place over the ranks: op 0 = sum,
+ * 1 = max.  Two calls per LM trial: the Schur-reduced pose system, then [Hpp, bp, chi2, scale].       */
+typedef int (*fb_allreduce_fn)(void *ctx, double *buf, int32_t n, int32_t op);
+int fb_local_ba_sharded(const fb_local_ba_args *args, int rank, int world, fb_allreduce_fn allreduce, void *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,61 @@
+"""Worker of the world_size-2 tests (spawned by test_dist_*.py with RANK/WORLD_SIZE/MASTER_* set)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    mode = sys.argv[1]
+    import torch
+    import torch.distributed as dist
+    from fishbirdeyevisualslam_amd import dist as fbd
+    rank, world = fbd.init_from_env(backend="gloo")
+    assert world == 2
+    if mode == "helpers":
+        # max over ranks, shard assignment, the all-reduce callback called through its C function pointer
+        assert fbd.max_over_ranks(1.0 + rank) == 2.0
+        assert fbd.shard_sequences(8, rank, world) == [rank, rank + 2, rank + 4, rank + 6]
+        cb = fbd.make_allreduce()
+        buf = (C.c_double * 5)(*[float(rank + 1) * (i + 1) for i in range(5)])
+        assert cb(None, buf, 5, 0) == 0
+        assert list(buf) == [3.0 * (i + 1) for i in range(5)]
+        buf2 = (C.c_double * 2)(float(rank), -float(rank))
+        assert cb(None, buf2, 2, 1) == 0
+        assert list(buf2) == [1.0, 0.0]
+        print("rank %d helpers ok" % rank, flush=True)
+    elif mode == "ba":
+        # landmark-sharded local BA on ONE GPU shared by the two ranks, gloo for the exchange
+        import fishbirdeyevisualslam_amd as fb
+        from fishbirdeyevisualslam_amd import ba_problem, synth
+        L = fb.lib()
+        p = synth.make_ba_problem(4000, n_kf=8, n_mp=1200, n_mpb=300)
+        a, out_s, keep = ba_problem.local_ba_args(p, with_odom=1)
+        cb = fbd.make_allreduce()
+        fbd.local_ba_sharded(L, a, rank, world, cb)
+        a1, out_1, keep1 = ba_problem.local_ba_args(p, with_odom=1)
+        fb.check(L.fb_local_ba(C.byref(a1)), "fb_local_ba")
+        rel = lambda x, y: float(np.abs(x - y).max() / max(1.0, np.abs(y).max()))
+        r = [rel(out_s["kf_Tcw"], out_1["kf_Tcw"]), rel(out_s["mp_xw"], out_1["mp_xw"]), rel(out_s["mpb_xw"], out_1["mpb_xw"])]
+        same = bool(np.array_equal(out_s["obs_outlier"], out_1["obs_outlier"]) and
+                    np.array_equal(out_s["bobs_outlier"][: len(p["bobs_kf"])], out_1["bobs_outlier"][: len(p["bobs_kf"])]))
+        # both ranks must hold the identical complete result
+        t = torch.from_numpy(out_s["kf_Tcw"].astype(np.float64).copy())
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmin = t.clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        identical = bool(torch.equal(tmax, tmin))
+        print("rank %d ba rel=%s flags_equal=%s identical_across_ranks=%s" % (rank, ["%.2e" % x for x in r], same, identical), flush=True)
+        assert max(r) <= 1e-4 and same and identical
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
