@@ -200,7 +200,14 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
   uint32_t *s_out = reinterpret_cast<uint32_t *>(fsm + 2 * K.fastTileBytes);
   unsigned short *s_list = reinterpret_cast<unsigned short *>(fsm + 2 * K.fastTileBytes + 4 * K.fastMaxOut);  // [fastMaxPix]
   const int b = blockIdx.y, lane = threadIdx.x;
-  int cell = blockIdx.x, l = 0;
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one), so give each
+  // XCD a contiguous run of cells -- neighbouring cells overlap by 6 px and share 64-B lines in that XCD's L2
+  int cell, l = 0;
+  {
+    const int nb = gridDim.x, per = (nb + 7) >> 3;
+    cell = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (cell >= nb) return;
+  }
 #pragma unroll
   for (int i = 1; i < FB_MAX_LEVELS; i++) l += (i < K.nlevels && cell >= K.cellBase[i]) ? 1 : 0;
   const LevelInfo &Lv = K.L[l];
@@ -938,7 +945,7 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
   }
   if (K.totalCells > 0) {
     fb::ProfScope prof_(fb::P_FAST, s);
-    k_fast<<<dim3(K.totalCells, batch), 64, (size_t)2 * K.fastTileBytes + 4 * K.fastMaxOut + 2 * K.fastMaxPix, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
+    k_fast<<<dim3((K.totalCells + 7) / 8 * 8, batch), 64, (size_t)2 * K.fastTileBytes + 4 * K.fastMaxOut + 2 * K.fastMaxPix, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
                                                       o->cand.as<uint32_t>(), candCount);
   }
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->octreeLds));
