@@ -36,7 +36,7 @@ constexpr int T_PROJ = 0, T_XYZ = 1;
 constexpr int LIN_THREADS = 128;
 constexpr int POSE_THREADS = 256;
 constexpr int SCHUR_THREADS = 256;
-constexpr int SOLVE_THREADS = 1024;
+constexpr int SOLVE_THREADS = 256;
 constexpr int CHUNK = 16;  // landmarks per MFMA panel (K = 48)
 constexpr int KP = 3 * CHUNK;
 constexpr int KPAD = KP + 2;  // LDS row stride in doubles (breaks the 2-way bank conflict of stride 48)
@@ -412,38 +412,44 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BADev D, LinBuf B, d
   for (int c0 = l0; c0 < l1; c0 += CHUNK) {
     for (int i = tid; i < 2 * rows * KPAD; i += SCHUR_THREADS) Yp[i] = 0;
     __syncthreads();
-    // one lane per landmark of the chunk: Dinv, then scatter its edges' blocks
-    if (tid < CHUNK && c0 + tid < l1) {
-      const int l = c0 + tid;
-      double M[9];
+    // 16 lanes per landmark of the chunk: every lane inverts D (cheap), lane 0 of the group publishes it, the
+    // group's lanes scatter the landmark's edge blocks in parallel
+    {
+      const int li = tid >> 4, sub = tid & 15;
+      const int l = c0 + li;
+      if (l < l1) {
+        double M[9];
 #pragma unroll
-      for (int i = 0; i < 9; i++) M[i] = B.Hll[(size_t)9 * l + i];
-      M[0] += lambda; M[4] += lambda; M[8] += lambda;
-      const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
-      const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
-      const double id = 1.0 / det;
-      double Di[9];
-      Di[0] = c00 * id; Di[1] = (M[2] * M[7] - M[1] * M[8]) * id; Di[2] = (M[1] * M[5] - M[2] * M[4]) * id;
-      Di[3] = c01 * id; Di[4] = (M[0] * M[8] - M[2] * M[6]) * id; Di[5] = (M[2] * M[3] - M[0] * M[5]) * id;
-      Di[6] = c02 * id; Di[7] = (M[1] * M[6] - M[0] * M[7]) * id; Di[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+        for (int i = 0; i < 9; i++) M[i] = B.Hll[(size_t)9 * l + i];
+        M[0] += lambda; M[4] += lambda; M[8] += lambda;
+        const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+        const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+        const double id = 1.0 / det;
+        double Di[9];
+        Di[0] = c00 * id; Di[1] = (M[2] * M[7] - M[1] * M[8]) * id; Di[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+        Di[3] = c01 * id; Di[4] = (M[0] * M[8] - M[2] * M[6]) * id; Di[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+        Di[6] = c02 * id; Di[7] = (M[1] * M[6] - M[0] * M[7]) * id; Di[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+        if (sub == 0) {
 #pragma unroll
-      for (int i = 0; i < 9; i++) Dinv[(size_t)9 * l + i] = Di[i];
+          for (int i = 0; i < 9; i++) Dinv[(size_t)9 * l + i] = Di[i];
 #pragma unroll
-      for (int c = 0; c < 3; c++) Wp[(size_t)P6 * KPAD + 3 * tid + c] = B.bl[(size_t)3 * l + c];
-      for (int cc = D.lm_start[l]; cc < D.lm_start[l + 1]; cc++) {
-        const int e = D.lm_edges[cc];
-        const int pj = D.poseIdx[D.e_kf[e]];
-        if (pj < 0 || D.e_level[e] != 0) continue;
-        const double *W = B.W + (size_t)e * 18;
+          for (int c = 0; c < 3; c++) Wp[(size_t)P6 * KPAD + 3 * li + c] = B.bl[(size_t)3 * l + c];
+        }
+        for (int cc = D.lm_start[l] + sub; cc < D.lm_start[l + 1]; cc += 16) {
+          const int e = D.lm_edges[cc];
+          const int pj = D.poseIdx[D.e_kf[e]];
+          if (pj < 0 || D.e_level[e] != 0) continue;
+          const double *W = B.W + (size_t)e * 18;
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-          const double w0 = W[i * 3], w1 = W[i * 3 + 1], w2 = W[i * 3 + 2];
-          double *yr = Yp + (size_t)(6 * pj + i) * KPAD + 3 * tid;
-          double *wr = Wp + (size_t)(6 * pj + i) * KPAD + 3 * tid;
-          wr[0] = w0; wr[1] = w1; wr[2] = w2;
-          yr[0] = w0 * Di[0] + w1 * Di[3] + w2 * Di[6];
-          yr[1] = w0 * Di[1] + w1 * Di[4] + w2 * Di[7];
-          yr[2] = w0 * Di[2] + w1 * Di[5] + w2 * Di[8];
+          for (int i = 0; i < 6; i++) {
+            const double w0 = W[i * 3], w1 = W[i * 3 + 1], w2 = W[i * 3 + 2];
+            double *yr = Yp + (size_t)(6 * pj + i) * KPAD + 3 * li;
+            double *wr = Wp + (size_t)(6 * pj + i) * KPAD + 3 * li;
+            wr[0] = w0; wr[1] = w1; wr[2] = w2;
+            yr[0] = w0 * Di[0] + w1 * Di[3] + w2 * Di[6];
+            yr[1] = w0 * Di[1] + w1 * Di[4] + w2 * Di[7];
+            yr[2] = w0 * Di[2] + w1 * Di[5] + w2 * Di[8];
+          }
         }
       }
     }
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BADev D, LinBuf B, d
 // k_ba_solve: reduce partials, S = Hpp + lambda I - sum, LDL^T (no pivoting) and solves.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lambda, const double *Spart, int nWg, int P6,
-                                                            int NT, double *xp, int *okFlag) {
+                                                            int NT, double *xp, double *okFlag) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   double *A = reinterpret_cast<double *>(smem);  // [P6][P6+1] lower triangle used
   const int ld = P6 + 1;
@@ -508,21 +514,73 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lam
     rhs[i] = B.bp[i] - s;
   }
   __syncthreads();
-  // right-looking LDL^T: column j is final after step j-1; the scaled L is never stored
-  // (L[i][j] = A[i][j] / A[j][j]).  One barrier per column.
-  for (int j = 0; j < P6; j++) {
-    const double dj = A[(size_t)j * ld + j];
-    if (dj < 0 && tid == 0) s_ok = 0;
-    const double inv = dj != 0 ? 1.0 / dj : 0.0;
-    const int m = P6 - 1 - j;  // trailing size
-    for (int idx = tid; idx < m * (m + 1) / 2; idx += SOLVE_THREADS) {
-      // idx -> (r >= c) in the trailing lower triangle
-      int r = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-      while ((r + 1) * (r + 2) / 2 <= idx) r++;
-      while (r * (r + 1) / 2 > idx) r--;
-      const int c = idx - r * (r + 1) / 2;
-      const int i = j + 1 + r, k = j + 1 + c;
-      A[(size_t)i * ld + k] -= A[(size_t)i * ld + j] * inv * A[(size_t)k * ld + j];
+  // Blocked right-looking LDL^T with 6x6 blocks (one keyframe per block): per block step every thread factors the
+  // diagonal block redundantly in registers (no broadcast barrier), one thread per row solves the panel, and the
+  // trailing sub-matrix gets a rank-6 update -- two barriers per keyframe instead of one per column.
+  // On exit A holds the unit-lower L below the diagonal and D on it.
+  double *Up = rhs + P6;  // [P6][6] panel u = l * d of the current block step
+  const int nb6 = P6 / 6;
+  for (int J = 0; J < nb6; J++) {
+    const int c0 = 6 * J, c1 = c0 + 6;
+    double Lb[6][6], d[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c <= r; c++) Lb[r][c] = A[(size_t)(c0 + r) * ld + c0 + c];
+    bool neg = false;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      double dc = Lb[c][c];
+#pragma unroll
+      for (int m = 0; m < c; m++) dc -= Lb[c][m] * Lb[c][m] * d[m];
+      if (dc < 0) neg = true;
+      d[c] = dc;
+      const double inv = dc != 0 ? 1.0 / dc : 0.0;
+#pragma unroll
+      for (int r = c + 1; r < 6; r++) {
+        double v = Lb[r][c];
+#pragma unroll
+        for (int m = 0; m < c; m++) v -= Lb[r][m] * Lb[c][m] * d[m];
+        Lb[r][c] = v * inv;
+      }
+    }
+    if (neg && tid == 0) s_ok = 0;
+    __syncthreads();  // everyone has read the diagonal block before it is overwritten
+    if (tid == 0) {
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        A[(size_t)(c0 + r) * ld + c0 + r] = d[r];
+#pragma unroll
+        for (int c = 0; c < r; c++) A[(size_t)(c0 + r) * ld + c0 + c] = Lb[r][c];
+      }
+    }
+    for (int i = c1 + tid; i < P6; i += SOLVE_THREADS) {  // panel: row i of L below the block
+      double u[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double v = A[(size_t)i * ld + c0 + c];
+#pragma unroll
+        for (int m = 0; m < c; m++) v -= u[m] * Lb[c][m];
+        u[c] = v;
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        Up[(size_t)i * 6 + c] = u[c];
+        A[(size_t)i * ld + c0 + c] = d[c] != 0 ? u[c] / d[c] : 0.0;
+      }
+    }
+    __syncthreads();
+    const int tr = tid >> 4, tc = tid & 15;
+    for (int i = c1 + tr; i < P6; i += 16) {
+      double u[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) u[c] = Up[(size_t)i * 6 + c];
+      for (int k = c1 + tc; k <= i; k += 16) {
+        double acc2 = 0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc2 += u[c] * A[(size_t)k * ld + c0 + c];
+        A[(size_t)i * ld + k] -= acc2;
+      }
     }
     __syncthreads();
   }
@@ -533,32 +591,26 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lam
 #pragma unroll
     for (int q = 0; q < RPL; q++) y[q] = (tid + 64 * q < P6) ? rhs[tid + 64 * q] : 0.0;
     for (int i = 0; i < P6; i++) {  // forward: L y = b
-      const double yi = __shfl(y[i >> 6], i & 63, 64);
-      const double di = A[(size_t)i * ld + i];
-      const double inv = di != 0 ? 1.0 / di : 0.0;
+      const int qi = i >> 6;
+      const double yi = __shfl(qi == 0 ? y[0] : (qi == 1 ? y[1] : (qi == 2 ? y[2] : y[3])), i & 63, 64);  // no dynamic register index
 #pragma unroll
       for (int q = 0; q < RPL; q++) {
         const int r = tid + 64 * q;
-        if (r > i && r < P6) y[q] -= A[(size_t)r * ld + i] * inv * yi;
+        if (r > i && r < P6) y[q] -= A[(size_t)r * ld + i] * yi;
       }
     }
 #pragma unroll
     for (int q = 0; q < RPL; q++) {  // D^-1
       const int r = tid + 64 * q;
-      if (r < P6) { const double d = A[(size_t)r * ld + r]; y[q] = d != 0 ? y[q] / d : 0.0; }
+      if (r < P6) { const double dd = A[(size_t)r * ld + r]; y[q] = dd != 0 ? y[q] / dd : 0.0; }
     }
     for (int i = P6 - 1; i >= 0; i--) {  // backward: L^T x = y
-      const double xi = __shfl(y[i >> 6], i & 63, 64);
-      const double di = A[(size_t)i * ld + i];
-      (void)di;
+      const int qi = i >> 6;
+      const double xi = __shfl(qi == 0 ? y[0] : (qi == 1 ? y[1] : (qi == 2 ? y[2] : y[3])), i & 63, 64);
 #pragma unroll
       for (int q = 0; q < RPL; q++) {
         const int r = tid + 64 * q;
-        if (r < i) {
-          const double dr = A[(size_t)r * ld + r];
-          const double inv = dr != 0 ? 1.0 / dr : 0.0;
-          y[q] -= A[(size_t)i * ld + r] * inv * xi;  // L[i][r] = A[i][r]/d_r
-        }
+        if (r < i) y[q] -= A[(size_t)i * ld + r] * xi;
       }
     }
 #pragma unroll
@@ -568,7 +620,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lam
     }
   }
   __syncthreads();
-  if (tid == 0) *okFlag = s_ok;
+  if (tid == 0) *okFlag = s_ok ? 1.0 : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -821,7 +873,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
   FB_TRY(d_scal.alloc(4 * 8));
   FB_HIP(hipMemset(d_scal.p, 0, 4 * 8));
   const size_t schurLds = (size_t)2 * rows * KPAD * 8;
-  const size_t solveLds = ((size_t)P6 * (P6 + 1) + P6 + 2) * 8;
+  const size_t solveLds = ((size_t)P6 * (P6 + 1) + P6 + (size_t)P6 * 6 + 2) * 8;
   if (schurLds > 160 * 1024 || solveLds > 160 * 1024) { fb::set_error("fb_local_ba: %d free keyframes exceed the LDS-resident reduced system", np); return FB_ERR_CAPACITY; }
   // accumulator tiles per wave: NT<=8 -> 9, NT<=12 -> 20, NT<=16 -> 34
   auto schurKernel = NT <= 8 ? k_ba_schur<9> : (NT <= 12 ? k_ba_schur<20> : k_ba_schur<34>);
@@ -833,6 +885,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
   hipStream_t s0 = nullptr;
 
   double lastScale = 0;  // sum x (lambda x + b) of the most recent k_ba_update (all ranks)
+  bool lastOk = true;    // LDL^T status of the most recent k_ba_solve
   // one linearisation at state `si` into buffer `bi`; returns chi2 (and max diagonal when wanted)
   auto linearize = [&](int si, int bi, int robust, bool wantDiag, double *chi, double *maxDiag) -> int {
     if (P6 > 0) FB_HIP(hipMemsetAsync(lb[bi].Hpp, 0, (size_t)P6 * P6 * 8, s0));
@@ -842,8 +895,9 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
       k_ba_odom<<<1, 256, odomLds, s0>>>(D, st[si], lb[bi], P6, nLinBlocks); }
     { fb::ProfScope pr(fb::P_BA_MISC, s0);
       k_ba_scalars<<<1, 256, 0, s0>>>(lb[bi].chiPart, nLinBlocks + 1, lb[bi].Hpp, P6, lb[bi].Hll, npt, d_scal.as<double>(), wantDiag ? 1 : 0); }
-    double h[3];
-    FB_HIP(hipMemcpy(h, d_scal.p, 24, hipMemcpyDeviceToHost));  // chi2, max diagonal, scale term of the last update
+    double h[4];
+    FB_HIP(hipMemcpy(h, d_scal.p, 32, hipMemcpyDeviceToHost));  // chi2, max diagonal, scale term + solver status of the last trial
+    lastOk = h[3] != 0.0;
     if (sharded) {
       std::vector<double> ex((size_t)P6 * P6 + P6 + 2);
       if (P6 > 0) {
@@ -894,25 +948,24 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
         { fb::ProfScope pr(fb::P_BA_SCHUR, s0);
           schurKernel<<<nWg, SCHUR_THREADS, schurLds, s0>>>(D, lb[cur], lambda, d_Dinv.as<double>(), d_Spart.as<double>(), P6, NT, lmPerWg); }
         { fb::ProfScope pr(fb::P_BA_SOLVE, s0);
-          int nParts = nWg;
+          // the workgroup partials are summed by a full-width kernel (one workgroup reading nWg x rows^2 doubles is slow)
+          const int nS = rows * rows;
+          k_ba_sumparts<<<(nS + 255) / 256, 256, 0, s0>>>(d_Spart.as<double>(), nWg, nS);
+          const int nParts = 1;
           if (sharded) {  // exchange step 1: the Schur-reduced system
-            const int nS = rows * rows;
-            k_ba_sumparts<<<(nS + 255) / 256, 256, 0, s0>>>(d_Spart.as<double>(), nWg, nS);
             std::vector<double> ex(nS);
             FB_HIP(hipMemcpy(ex.data(), d_Spart.p, (size_t)nS * 8, hipMemcpyDeviceToHost));
             FB_TRY(reduce(ex.data(), nS, 0));
             FB_HIP(hipMemcpy(d_Spart.p, ex.data(), (size_t)nS * 8, hipMemcpyHostToDevice));
-            nParts = 1;
           }
-          k_ba_solve<<<1, SOLVE_THREADS, solveLds, s0>>>(lb[cur], lambda, d_Spart.as<double>(), nParts, P6, NT, d_xp.as<double>(), d_ok.as<int>()); }
+          k_ba_solve<<<1, SOLVE_THREADS, solveLds, s0>>>(lb[cur], lambda, d_Spart.as<double>(), nParts, P6, NT, d_xp.as<double>(), d_scal.as<double>() + 3); }
         { fb::ProfScope pr(fb::P_BA_UPDATE, s0);
           k_ba_update<<<nUpdBlocks, LIN_THREADS, 0, s0>>>(D, lb[cur], st[cur], st[tr], d_Dinv.as<double>(), d_xp.as<double>(), lambda, d_scale.as<double>(), rank == 0 ? 1 : 0);
           k_ba_scalars<<<1, 256, 0, s0>>>(d_scale.as<double>(), nUpdBlocks, nullptr, 0, nullptr, 0, d_scal.as<double>() + 2, 0); }
         double tempChi = 0, dummy = 0;
         FB_TRY(linearize(tr, tr, robust, false, &tempChi, &dummy));
         double hs[1] = {lastScale};  // exchange step 2 happened inside linearize()
-        int ok2 = 1;
-        FB_HIP(hipMemcpy(&ok2, d_ok.p, 4, hipMemcpyDeviceToHost));
+        const int ok2 = lastOk ? 1 : 0;
         if (!ok2) tempChi = 1.7976931348623157e308;
         rho = currentChi - tempChi;
         const double scale = hs[0] + 1e-3;

@@ -65,17 +65,23 @@ struct ProfScope {
 };
 
 // Device scratch that lives for one host-pointer call.
+// hipMalloc/hipFree cost tens of microseconds each and the host-pointer entry points need dozens of scratch
+// buffers per call, so freed blocks are kept in a per-device pool of power-of-two size classes (runtime.hip).
+void *pool_take(size_t bytes, size_t *granted);  // nullptr on failure (error set)
+void pool_give(void *p, size_t granted);
+
 struct DevBuf {
   void *p = nullptr;
-  size_t bytes = 0;
+  size_t bytes = 0, granted = 0;
   DevBuf() {}
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p) pool_give(p, granted); }
   int alloc(size_t n) {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    if (p) { pool_give(p, granted); p = nullptr; }
     bytes = n ? n : 1;
-    FB_HIP(hipMalloc(&p, bytes));
+    p = pool_take(bytes, &granted);
+    if (!p) return FB_ERR_HIP;
     return FB_OK;
   }
   int upload(const void *src, size_t n) {

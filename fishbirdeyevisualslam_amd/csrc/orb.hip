@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
   {
     const int nb = gridDim.x, per = (nb + 7) >> 3;
     cell = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (cell >= nb) return;
+    if (cell >= K.totalCells) return;  // grid is padded to a multiple of 8
   }
 #pragma unroll
   for (int i = 1; i < FB_MAX_LEVELS; i++) l += (i < K.nlevels && cell >= K.cellBase[i]) ? 1 : 0;

@@ -1,6 +1,10 @@
 // runtime.hip -- error channel and device selection of the C-ABI (include/fishbird.h).
 #include "fb_common.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace fb {
 
 static thread_local char g_err[512] = "";
@@ -21,6 +25,49 @@ int check_device() {
     return FB_ERR_NODEVICE;
   }
   return FB_OK;
+}
+
+// ---- device scratch pool (see DevBuf) ----
+namespace {
+std::mutex g_pool_mu;
+std::map<std::pair<int, size_t>, std::vector<void *>> g_free;  // (device, size class) -> blocks
+size_t g_pooled_bytes = 0;
+constexpr size_t kPoolCap = (size_t)4 << 30;  // keep at most 4 GiB of idle scratch
+}  // namespace
+
+void *pool_take(size_t bytes, size_t *granted) {
+  size_t cls = 256;
+  while (cls < bytes) cls <<= 1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_free.find({dev, cls});
+    if (it != g_free.end() && !it->second.empty()) {
+      void *p = it->second.back();
+      it->second.pop_back();
+      g_pooled_bytes -= cls;
+      *granted = cls;
+      return p;
+    }
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, cls);
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu) -> %s", cls, hipGetErrorString(e));
+    return nullptr;
+  }
+  *granted = cls;
+  return p;
+}
+
+void pool_give(void *p, size_t granted) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (g_pooled_bytes + granted > kPoolCap) { (void)hipFree(p); return; }
+  g_free[{dev, granted}].push_back(p);
+  g_pooled_bytes += granted;
 }
 
 bool g_prof_on = false;
