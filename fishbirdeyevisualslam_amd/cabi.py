@@ -125,6 +125,32 @@ class TriangulationArgs(C.Structure):
                 ("matcher", MatcherParams), ("matches12", _vp), ("nmatches", _vp)]
 
 
+class ProjKfArgs(C.Structure):
+    _fields_ = [("batch", _i32), ("cur_stride", _i32), ("kf_stride", _i32),
+                ("n_cur", _vp), ("cur_kps", _vp), ("cur_desc", _vp), ("cur_cell_start", _vp),
+                ("cur_cell_items", _vp), ("cur_blocked", _vp), ("cur_Tcw", _vp),
+                ("n_kf", _vp), ("kf_valid", _vp), ("kf_xw", _vp), ("kf_desc", _vp),
+                ("kf_max_dist", _vp), ("kf_min_dist", _vp), ("kf_angle", _vp),
+                ("cam", Camera), ("grid", GridGeom), ("scale_factors", _f32 * FB_MAX_LEVELS),
+                ("log_scale_factor", _f32), ("n_levels", _i32), ("th", _f32), ("orb_dist", _i32),
+                ("matcher", MatcherParams), ("match_cur_to_kf", _vp), ("nmatches", _vp)]
+
+
+class BowKfArgs(C.Structure):
+    _fields_ = [("batch", _i32), ("kf1_stride", _i32), ("kf2_stride", _i32),
+                ("n1", _vp), ("kps1", _vp), ("desc1", _vp), ("has_mp1", _vp), ("fv1", FeatureVector),
+                ("n2", _vp), ("kps2", _vp), ("desc2", _vp), ("has_mp2", _vp), ("fv2", FeatureVector),
+                ("matcher", MatcherParams), ("matches12", _vp), ("nmatches", _vp)]
+
+
+class FrustumArgs(C.Structure):
+    _fields_ = [("batch", _i32), ("mp_stride", _i32), ("Tcw", _vp), ("Ow", _vp), ("n_mp", _vp), ("mp_valid", _vp),
+                ("mp_xw", _vp), ("mp_normal", _vp), ("mp_max_dist", _vp), ("mp_min_dist", _vp),
+                ("cam", Camera), ("mbf", _f32), ("viewing_cos_limit", _f32), ("log_scale_factor", _f32),
+                ("n_levels", _i32),
+                ("in_view", _vp), ("proj", _vp), ("proj_xr", _vp), ("level", _vp), ("view_cos", _vp)]
+
+
 class PoseOptArgs(C.Structure):
     _fields_ = [("batch", _i32), ("mode", _i32), ("front_stride", _i32), ("bird_stride", _i32),
                 ("fx", _f32), ("fy", _f32), ("cx", _f32), ("cy", _f32), ("wF", _f32), ("wB", _f32),
@@ -176,6 +202,8 @@ EXPORTS = [
     "fb_match_projection_points_dev", "fb_match_projection_points",
     "fb_match_birdview_dev", "fb_match_birdview",
     "fb_match_bow_dev", "fb_match_bow", "fb_match_triangulation_dev", "fb_match_triangulation",
+    "fb_match_projection_keyframe_dev", "fb_match_projection_keyframe", "fb_match_bow_kf_dev", "fb_match_bow_kf",
+    "fb_in_frustum_dev", "fb_in_frustum", "fb_undistort_keypoints_dev", "fb_undistort_keypoints", "fb_image_bounds",
     "fb_pose_opt_batch_dev", "fb_pose_opt", "fb_pose_gather_front_dev", "fb_pose_gather_bird_dev",
     "fb_local_ba", "fb_local_ba_sharded",
 ]

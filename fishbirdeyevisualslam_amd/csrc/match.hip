@@ -23,6 +23,7 @@
 // By induction on q the iteration converges to exactly the serial result (query 0 is final
 // after round 0, query q after at most round q); in practice 2-3 rounds.
 #include "fb_common.h"
+#include "fb_frame_geom.h"
 
 namespace {
 
@@ -254,6 +255,131 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
     __syncthreads();
   }
   for (int i = tid; i < ncur; i += nt) A.match_cur_to_last[co + i] = matchL[i];
+  if (tid == 0) A.nmatches[b] = s_n;
+}
+
+// ---------------------------------------------------------------------------------------
+// M4  SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)  (ORBmatcher.cc:1473-1600)
+// Same greedy structure as M3; the search level comes from MapPoint::PredictScale and every
+// accepted slot blocks all later key-frame points (mvpMapPoints[i2] != NULL, :1545).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MATCH_THREADS) void k_proj_kf(fb_proj_kf_args A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int ncell = A.grid.cols * A.grid.rows;
+  const size_t co = (size_t)b * A.cur_stride, ko = (size_t)b * A.kf_stride;
+  const int ncur = A.n_cur[b], nkf = A.n_kf[b];
+  const Carve cv(A.cur_stride, ncell);
+  const TargetLds T = stage_target(smem, cv, ncur, ncell, A.cur_kps + co, A.cur_desc + co * 32,
+                                   A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co);
+  int *ownerA = reinterpret_cast<int *>(smem + cv.end);  // [cur_stride]
+  int *ownerB = ownerA + A.cur_stride;                   // [cur_stride]
+  int *assignA = ownerB + A.cur_stride;                  // [kf_stride]
+  int *assignB = assignA + A.kf_stride;                  // [kf_stride]
+  int *levelQ = assignB + A.kf_stride;                   // [kf_stride] predicted level, or -1 = gated out
+  float *uQ = reinterpret_cast<float *>(levelQ + A.kf_stride);  // [kf_stride]
+  float *vQ = uQ + A.kf_stride;                                 // [kf_stride]
+  __shared__ int s_changed, s_n, s_hist[HISTO_LENGTH], s_ind[3];
+  __shared__ float s_T[12], s_Ow[3];
+  if (tid < 12) s_T[tid] = A.cur_Tcw[(size_t)b * 12 + tid];
+  if (tid == 64) fb::camera_centre(A.cur_Tcw + (size_t)b * 12, s_Ow);
+  const uint8_t *blocked0 = A.cur_blocked ? A.cur_blocked + co : nullptr;
+  for (int i = tid; i < ncur; i += nt) ownerA[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
+  for (int q = tid; q < nkf; q += nt) assignA[q] = NONE;
+  __syncthreads();
+  // geometric gates are independent of the greedy state: once per key-frame point
+  for (int q = tid; q < nkf; q += nt) {
+    int lvl = -1;
+    float2 uv = make_float2(0.f, 0.f);
+    if (A.kf_valid[ko + q]) {
+      const float X[3] = {A.kf_xw[(ko + q) * 3], A.kf_xw[(ko + q) * 3 + 1], A.kf_xw[(ko + q) * 3 + 2]};
+      float pc[3];
+      xform(s_T, X, pc);
+      const float invzc = (float)(1.0 / pc[2]);
+      const float u = A.cam.fx * pc[0] * invzc + A.cam.cx;
+      const float v = A.cam.fy * pc[1] * invzc + A.cam.cy;
+      if (!(u < A.cam.min_x || u > A.cam.max_x) && !(v < A.cam.min_y || v > A.cam.max_y)) {
+        const float dist3D = fb::norm3(X[0] - s_Ow[0], X[1] - s_Ow[1], X[2] - s_Ow[2]);
+        const float maxD = A.kf_max_dist[ko + q];
+        if (!(dist3D < 0.8f * A.kf_min_dist[ko + q] || dist3D > 1.2f * maxD)) {
+          lvl = fb::predict_scale(maxD, dist3D, A.log_scale_factor, A.n_levels);
+          uv = make_float2(u, v);
+        }
+      }
+    }
+    levelQ[q] = lvl;
+    uQ[q] = uv.x;
+    vQ[q] = uv.y;
+  }
+  __syncthreads();
+
+  for (int round = 0; round <= nkf + 1; round++) {
+    for (int i = tid; i < ncur; i += nt) ownerB[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    for (int q = tid; q < nkf; q += nt) {
+      int best = NONE;
+      const int lvl = levelQ[q];
+      if (lvl >= 0) {
+        const float2 uv = make_float2(uQ[q], vQ[q]);
+        const float radius = A.th * A.scale_factors[lvl];
+        uint32_t d[8];
+        const uint4 *dq = reinterpret_cast<const uint4 *>(A.kf_desc + (ko + q) * 32);
+        const uint4 d0 = dq[0], d1 = dq[1];
+        d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+        int bestDist = 256;
+        for_area<false>(A.grid, T, uv.x, uv.y, radius, lvl - 1, lvl + 1, [&](int i2) {
+          if (ownerA[i2] < q) return;
+          const int dist = fb::hamming256(d, T.desc + i2 * 2);
+          if (dist < bestDist) { bestDist = dist; best = i2; }
+        });
+        if (bestDist > A.orb_dist) best = NONE;
+      }
+      assignB[q] = best;
+      if (best != assignA[q]) s_changed = 1;
+      if (best != NONE) atomicMin(&ownerB[best], q);
+    }
+    __syncthreads();
+    const int changed = s_changed;
+    int *t = ownerA; ownerA = ownerB; ownerB = t;
+    t = assignA; assignA = assignB; assignB = t;
+    __syncthreads();
+    if (!changed) break;
+  }
+
+  int *matchL = ownerB;
+  for (int i = tid; i < ncur; i += nt) matchL[i] = -1;
+  if (tid < HISTO_LENGTH) s_hist[tid] = 0;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  const bool ori = A.matcher.check_orientation != 0;
+  for (int q = tid; q < nkf; q += nt) {
+    const int c = assignA[q];
+    if (c == NONE) continue;
+    matchL[c] = q;  // a claimed slot blocks every later point: one claimer per slot
+    atomicAdd(&s_n, 1);
+    if (ori) {
+      const int bin = rot_bin(A.kf_angle[ko + q] - A.cur_kps[co + c].angle);
+      atomicAdd(&s_hist[bin], 1);
+      assignB[q] = bin;
+    }
+  }
+  __syncthreads();
+  if (ori) {
+    if (tid == 0) three_maxima(s_hist, s_ind[0], s_ind[1], s_ind[2]);
+    __syncthreads();
+    for (int q = tid; q < nkf; q += nt) {
+      const int c = assignA[q];
+      if (c == NONE) continue;
+      const int bin = assignB[q];
+      if (bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2]) {
+        matchL[c] = -1;
+        atomicSub(&s_n, 1);
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < ncur; i += nt) A.match_cur_to_kf[co + i] = matchL[i];
   if (tid == 0) A.nmatches[b] = s_n;
 }
 
@@ -653,6 +779,21 @@ int fb_match_projection_frame_dev(const fb_proj_frame_args *A, void *stream) {
   return FB_OK;
 }
 
+int fb_match_projection_keyframe_dev(const fb_proj_kf_args *A, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(A && A->batch >= 0 && A->cur_stride > 0 && A->kf_stride >= 0 && A->cur_stride < 65536);
+  FB_ARG(A->n_levels > 0 && A->n_levels <= FB_MAX_LEVELS);
+  if (A->batch == 0) return FB_OK;
+  const int ncell = A->grid.cols * A->grid.rows;
+  const size_t lds = match_lds_bytes(A->cur_stride, ncell, 2 * A->cur_stride + 5 * A->kf_stride);
+  FB_TRY(check_lds(lds, "fb_match_projection_keyframe"));
+  FB_TRY(set_max_lds(k_proj_kf, lds));
+  fb::ProfScope prof_(fb::P_PROJ_KF, fb::as_stream(stream));
+  k_proj_kf<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
 int fb_match_projection_points_dev(const fb_proj_points_args *A, void *stream) {
   FB_TRY(fb::check_device());
   FB_ARG(A && A->batch >= 0 && A->cur_stride > 0 && A->mp_stride >= 0 && A->cur_stride < 65536);
@@ -718,6 +859,27 @@ int fb_match_projection_frame(const fb_proj_frame_args *H) {
   FB_TRY(fb_match_projection_frame_dev(&D, nullptr));
   FB_HIP(hipDeviceSynchronize());
   FB_TRY(o0.download(H->match_cur_to_last, B * cs * 4));
+  return o1.download(H->nmatches, B * 4);
+}
+
+int fb_match_projection_keyframe(const fb_proj_kf_args *H) {
+  FB_TRY(fb::check_device());
+  FB_ARG(H && H->batch >= 0);
+  fb_proj_kf_args D = *H;
+  const size_t B = H->batch, cs = H->cur_stride, ks = H->kf_stride, ncell = (size_t)H->grid.cols * H->grid.rows;
+  UP(b0, n_cur, B * 4) UP(b1, cur_kps, B * cs * sizeof(fb_keypoint)) UP(b2, cur_desc, B * cs * 32)
+  UP(b3, cur_cell_start, B * (ncell + 1) * 4) UP(b4, cur_cell_items, B * cs * 4) UP(b5, cur_blocked, B * cs)
+  UP(b6, cur_Tcw, B * 48) UP(b7, n_kf, B * 4) UP(b8, kf_valid, B * ks) UP(b9, kf_xw, B * ks * 12)
+  UP(b10, kf_desc, B * ks * 32) UP(b11, kf_max_dist, B * ks * 4) UP(b12, kf_min_dist, B * ks * 4)
+  UP(b13, kf_angle, B * ks * 4)
+  fb::DevBuf o0, o1;
+  FB_TRY(o0.alloc(B * cs * 4));
+  FB_TRY(o1.alloc(B * 4));
+  D.match_cur_to_kf = o0.as<int32_t>();
+  D.nmatches = o1.as<int32_t>();
+  FB_TRY(fb_match_projection_keyframe_dev(&D, nullptr));
+  FB_HIP(hipDeviceSynchronize());
+  FB_TRY(o0.download(H->match_cur_to_kf, B * cs * 4));
   return o1.download(H->nmatches, B * 4);
 }
 

@@ -82,7 +82,11 @@ __device__ __forceinline__ void load_desc(const uint8_t *p, uint32_t d[8]) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BOW_THREADS) void k_match_bow(fb_bow_args A) {
+// KFKF = false: M5 (keyframe -> frame).  KFKF = true: M6, SearchByBoW(pKF1, pKF2) (ORBmatcher.cc:523-656): the
+// candidate side must carry a good MapPoint (:575-581), the distance test is strict (:598) and the result is
+// indexed by the query side (vpMatches12[idx1], :602).
+template <bool KFKF>
+__global__ __launch_bounds__(BOW_THREADS) void k_match_bow_t(fb_bow_args A, const uint8_t *f_has_mp, int32_t *match12) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const size_t ko = (size_t)b * A.kf_stride, fo = (size_t)b * A.f_stride;
@@ -118,11 +122,13 @@ __global__ __launch_bounds__(BOW_THREADS) void k_match_bow(fb_bow_args A) {
           for (int c = F.start[fi]; c < F.start[fi + 1]; c++) {
             const int realIdxF = F.items[c];
             if (ownerA[realIdxF] < q) continue;  // vpMapPointMatches[realIdxF] already set by an earlier feature
+            if (KFKF && !f_has_mp[fo + realIdxF]) continue;
             const int dist = fb::hamming256(d, fdesc + realIdxF * 2);
             if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
             else if (dist < bestDist2) bestDist2 = dist;
           }
-          if (bestDist1 <= TH_LOW && (float)bestDist1 < A.matcher.nnratio * (float)bestDist2) best = bestIdxF;
+          const bool low = KFKF ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW;
+          if (low && (float)bestDist1 < A.matcher.nnratio * (float)bestDist2) best = bestIdxF;
         }
       }
       assignB[q] = best;
@@ -166,7 +172,15 @@ __global__ __launch_bounds__(BOW_THREADS) void k_match_bow(fb_bow_args A) {
     }
     __syncthreads();
   }
-  for (int i = tid; i < nF; i += nt) A.match_f_to_kf[fo + i] = matchL[i];
+  if (KFKF) {
+    const int nK = A.n_kf[b];
+    for (int i = tid; i < nK; i += nt) match12[ko + i] = -1;
+    __syncthreads();
+    for (int i = tid; i < nF; i += nt)
+      if (matchL[i] >= 0) match12[ko + matchL[i]] = i;
+  } else {
+    for (int i = tid; i < nF; i += nt) A.match_f_to_kf[fo + i] = matchL[i];
+  }
   if (tid == 0) A.nmatches[b] = s_n;
 }
 
@@ -288,9 +302,28 @@ int fb_match_bow_dev(const fb_bow_args *A, void *stream) {
   if (A->batch == 0) return FB_OK;
   const size_t lds = (size_t)A->f_stride * 32 + (size_t)A->f_stride * 8 + (size_t)A->kf_fv.item_stride * 8 + 16;
   FB_TRY(lds_ok(lds, "fb_match_bow"));
-  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match_bow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match_bow_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   fb::ProfScope prof_(fb::P_BOW, fb::as_stream(stream));
-  k_match_bow<<<A->batch, BOW_THREADS, lds, fb::as_stream(stream)>>>(*A);
+  k_match_bow_t<false><<<A->batch, BOW_THREADS, lds, fb::as_stream(stream)>>>(*A, nullptr, nullptr);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+int fb_match_bow_kf_dev(const fb_bow_kf_args *K, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(K && K->batch >= 0 && K->kf1_stride > 0 && K->kf2_stride > 0 && K->fv1.item_stride >= 0 && K->fv2.item_stride >= 0);
+  FB_ARG(K->has_mp2 && K->matches12);
+  if (K->batch == 0) return FB_OK;
+  fb_bow_args A{};  // KF1 plays the query ("kf") side, KF2 the candidate ("f") side
+  A.batch = K->batch; A.kf_stride = K->kf1_stride; A.f_stride = K->kf2_stride;
+  A.n_kf = K->n1; A.kf_kps = K->kps1; A.kf_desc = K->desc1; A.kf_has_mp = K->has_mp1; A.kf_fv = K->fv1;
+  A.n_f = K->n2; A.f_kps = K->kps2; A.f_desc = K->desc2; A.f_fv = K->fv2;
+  A.matcher = K->matcher; A.match_f_to_kf = nullptr; A.nmatches = K->nmatches;
+  const size_t lds = (size_t)A.f_stride * 32 + (size_t)A.f_stride * 8 + (size_t)A.kf_fv.item_stride * 8 + 16;
+  FB_TRY(lds_ok(lds, "fb_match_bow_kf"));
+  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match_bow_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  fb::ProfScope prof_(fb::P_BOW_KF, fb::as_stream(stream));
+  k_match_bow_t<true><<<A.batch, BOW_THREADS, lds, fb::as_stream(stream)>>>(A, K->has_mp2, K->matches12);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -330,6 +363,27 @@ int fb_match_bow(const fb_bow_args *H) {
   FB_TRY(fb_match_bow_dev(&D, nullptr));
   FB_HIP(hipDeviceSynchronize());
   FB_TRY(o0.download(H->match_f_to_kf, B * fs * 4));
+  return o1.download(H->nmatches, B * 4);
+}
+
+int fb_match_bow_kf(const fb_bow_kf_args *H) {
+  FB_TRY(fb::check_device());
+  FB_ARG(H && H->batch >= 0);
+  fb_bow_kf_args D = *H;
+  const size_t B = H->batch, s1 = H->kf1_stride, s2 = H->kf2_stride;
+  UPF(b0, n1, B * 4) UPF(b1, kps1, B * s1 * sizeof(fb_keypoint)) UPF(b2, desc1, B * s1 * 32) UPF(b3, has_mp1, B * s1)
+  UPF(b4, n2, B * 4) UPF(b5, kps2, B * s2 * sizeof(fb_keypoint)) UPF(b6, desc2, B * s2 * 32) UPF(b7, has_mp2, B * s2)
+  FvUp u1, u2;
+  FB_TRY(u1.up(H->fv1, D.fv1, B));
+  FB_TRY(u2.up(H->fv2, D.fv2, B));
+  fb::DevBuf o0, o1;
+  FB_TRY(o0.alloc(B * s1 * 4));
+  FB_TRY(o1.alloc(B * 4));
+  D.matches12 = o0.as<int32_t>();
+  D.nmatches = o1.as<int32_t>();
+  FB_TRY(fb_match_bow_kf_dev(&D, nullptr));
+  FB_HIP(hipDeviceSynchronize());
+  FB_TRY(o0.download(H->matches12, B * s1 * 4));
   return o1.download(H->nmatches, B * 4);
 }
 

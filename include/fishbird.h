@@ -338,6 +338,102 @@ typedef struct fb_triangulation_args {
 int fb_match_triangulation_dev(const fb_triangulation_args *args, void *stream);
 int fb_match_triangulation(const fb_triangulation_args *args);
 
+/* --- M4: SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound,
+ *     th, ORBdist) (ORBmatcher.cc:1473-1600; relocalisation, Tracking.cc:1632,1643).              */
+typedef struct fb_proj_kf_args {
+  int32_t batch;
+  int32_t cur_stride;
+  int32_t kf_stride;
+  const int32_t *n_cur;
+  const fb_keypoint *cur_kps;    /* CurrentFrame.mvKeysUn                                            */
+  const uint8_t *cur_desc;
+  const int32_t *cur_cell_start;
+  const int32_t *cur_cell_items;
+  const uint8_t *cur_blocked;    /* CurrentFrame.mvpMapPoints[i2] != NULL on entry; may be NULL      */
+  const float *cur_Tcw;          /* [batch][12]                                                      */
+  const int32_t *n_kf;           /* vpMPs.size()                                                     */
+  const uint8_t *kf_valid;       /* vpMPs[i] && !isBad() && !sAlreadyFound.count(vpMPs[i])           */
+  const float *kf_xw;            /* [..][3] GetWorldPos()                                            */
+  const uint8_t *kf_desc;        /* GetDescriptor()                                                  */
+  const float *kf_max_dist;      /* mfMaxDistance (MapPoint.cc:379-383 applies the 1.2f)             */
+  const float *kf_min_dist;      /* mfMinDistance (MapPoint.cc:373-377 applies the 0.8f)             */
+  const float *kf_angle;         /* pKF->mvKeysUn[i].angle                                           */
+  fb_camera cam;
+  fb_grid_geom grid;
+  float scale_factors[FB_MAX_LEVELS];
+  float log_scale_factor;        /* CurrentFrame.mfLogScaleFactor                                    */
+  int32_t n_levels;              /* CurrentFrame.mnScaleLevels                                       */
+  float th;
+  int32_t orb_dist;
+  fb_matcher_params matcher;
+  int32_t *match_cur_to_kf;      /* [batch][cur_stride]: index into the keyframe's points, or -1     */
+  int32_t *nmatches;
+} fb_proj_kf_args;
+int fb_match_projection_keyframe_dev(const fb_proj_kf_args *args, void *stream);
+int fb_match_projection_keyframe(const fb_proj_kf_args *args);
+
+/* --- M6: SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12)
+ *     (ORBmatcher.cc:523-656; loop closing, LoopClosing.cc:263).                                   */
+typedef struct fb_bow_kf_args {
+  int32_t batch;
+  int32_t kf1_stride, kf2_stride;
+  const int32_t *n1;            /* vpMapPoints1.size()                                               */
+  const fb_keypoint *kps1;      /* pKF1->mvKeysUn (angle)                                            */
+  const uint8_t *desc1;
+  const uint8_t *has_mp1;       /* vpMapPoints1[i] && !isBad()                                       */
+  fb_feature_vector fv1;
+  const int32_t *n2;
+  const fb_keypoint *kps2;
+  const uint8_t *desc2;
+  const uint8_t *has_mp2;       /* vpMapPoints2[i] && !isBad()                                       */
+  fb_feature_vector fv2;
+  fb_matcher_params matcher;    /* ORBmatcher(0.75,true) at LoopClosing.cc:240                       */
+  int32_t *matches12;           /* [batch][kf1_stride]: KF2 feature whose MapPoint is vpMatches12[i], -1 */
+  int32_t *nmatches;
+} fb_bow_kf_args;
+int fb_match_bow_kf_dev(const fb_bow_kf_args *args, void *stream);
+int fb_match_bow_kf(const fb_bow_kf_args *args);
+
+/* ======================================================================== */
+/* Frame geometry either side of the matchers (src/Frame.cc)                 */
+/* ======================================================================== */
+/* --- Frame::isInFrustum(pMP, viewingCosLimit) over a list of map points (Frame.cc:435-491; the loop
+ *     around it is Tracking::SearchLocalPoints, Tracking.cc:1071-1091).  Outputs of a point that is
+ *     not in view are left untouched, as the reference leaves the MapPoint's track members.        */
+typedef struct fb_frustum_args {
+  int32_t batch;
+  int32_t mp_stride;
+  const float *Tcw;             /* [batch][12] mRcw | mtcw                                           */
+  const float *Ow;              /* [batch][3] mOw                                                    */
+  const int32_t *n_mp;
+  const uint8_t *mp_valid;      /* the caller's filter (not already matched, !isBad()); NULL = all   */
+  const float *mp_xw;           /* [..][3]                                                           */
+  const float *mp_normal;       /* [..][3] GetNormal()                                               */
+  const float *mp_max_dist;     /* mfMaxDistance                                                     */
+  const float *mp_min_dist;     /* mfMinDistance                                                     */
+  fb_camera cam;
+  float mbf;
+  float viewing_cos_limit;      /* 0.5 at Tracking.cc:1084                                           */
+  float log_scale_factor;
+  int32_t n_levels;
+  uint8_t *in_view;             /* mbTrackInView                                                     */
+  float *proj;                  /* [..][2] mTrackProjX, mTrackProjY                                  */
+  float *proj_xr;               /* mTrackProjXR; may be NULL                                         */
+  int32_t *level;               /* mnTrackScaleLevel                                                 */
+  float *view_cos;              /* mTrackViewCos                                                     */
+} fb_frustum_args;
+int fb_in_frustum_dev(const fb_frustum_args *args, void *stream);
+int fb_in_frustum(const fb_frustum_args *args);
+
+/* --- Frame::UndistortKeyPoints (Frame.cc:636-669): cv::fisheye::undistortPoints(pts, K, D, R=I, P=K) on
+ *     every key point; D[0]==0 copies.  K4 = fx,fy,cx,cy, D4 = k1..k4 (host).  d_kps_un may alias d_kps. */
+int fb_undistort_keypoints_dev(const fb_keypoint *d_kps, const int32_t *d_n, int batch, int kp_stride,
+                               const float *K4, const float *D4, fb_keypoint *d_kps_un, void *stream);
+int fb_undistort_keypoints(const fb_keypoint *kps, int n, const float *K4, const float *D4,
+                           fb_keypoint *kps_un); /* host pointers */
+/* --- Frame::ComputeImageBounds (Frame.cc:741-795): bounds[4] = mnMinX, mnMaxX, mnMinY, mnMaxY.      */
+int fb_image_bounds(int cols, int rows, const float *K4, const float *D4, float *bounds);
+
 /* ======================================================================== */
 /* Optimizer::PoseOptimization / PoseOptimizationWithBird / BirdOptimization */
 /* (include/Optimizer.h:40-68, src/Optimizer.cc:246-835)                     */

@@ -550,3 +550,6 @@ int orc_match_triangulation(const fb_triangulation_args *A) {
 }
 
 }  // extern "C"
+
+#include <limits>
+#include "match_more_oracle.inc"
