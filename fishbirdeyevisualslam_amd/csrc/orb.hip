@@ -131,6 +131,85 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src0
   *reinterpret_cast<uint32_t *>(dst + (long long)dy * dpitch + dx4) = packed;
 }
 
+// Same arithmetic, restructured for throughput (used when the source is dword aligned and the scale is <= 2, i.e.
+// always for the ORB pyramid): a lane owns 4 adjacent destination pixels and walks RR destination rows.  The column
+// constants (window offset, byte offsets, packed weights) live in registers for the whole walk; per source row the
+// lane fetches one 12-byte window (3 dword loads) and does the horizontal pass with v_alignbyte + v_perm + v_dot2;
+// a source row shared by two successive destination rows (4 of 5 at scale 1.2) is filtered once.
+constexpr int RESIZE_ROWS = 4;
+
+__global__ __launch_bounds__(256) void k_resize_rows(const uint8_t *__restrict__ src0, long long srcImgStride, int sw,
+                                                     int sh, int spitch, uint8_t *__restrict__ dst0,
+                                                     long long dstImgStride, int dw, int dh, int dpitch, ResizeTabs tb) {
+  const int b = blockIdx.z;
+  const int dyBase = __builtin_amdgcn_readfirstlane((blockIdx.y * blockDim.y + threadIdx.y) * RESIZE_ROWS);
+  const int dx4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (dyBase >= dh || dx4 >= dpitch) return;
+  const uint8_t *src = src0 + (long long)b * srcImgStride;
+  uint8_t *dst = dst0 + (long long)b * dstImgStride;
+  // column constants
+  const int dxf = min(dx4, dw - 1);
+  const int a = tb.xofs[dxf] & ~3;
+  const int aw = min(a, spitch - 12);  // keep the 12-byte window inside the row (only the zero-padded tail moves)
+  int sel[4];                          // dword index of the first tap inside the window
+  uint32_t sh8[4];                     // byte shift of the first tap inside that dword
+  uint32_t wgt[4];                     // a0 | a1 << 16
+  bool live[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int dx = dx4 + k;
+    live[k] = dx < dw;
+    const int dxc = min(dx, dw - 1);
+    const int sx = tb.xofs[dxc];
+    int a0 = tb.ialpha[dxc * 2], a1 = tb.ialpha[dxc * 2 + 1];
+    if (sx + 1 > sw - 1) { a0 += a1; a1 = 0; }  // right border: both taps read sx
+    const int o = sx - aw;
+    sel[k] = o >> 2;
+    sh8[k] = (uint32_t)(o & 3);
+    wgt[k] = (uint32_t)(a0 & 0xffff) | ((uint32_t)a1 << 16);
+  }
+  auto hpass = [&](int sy, int h[4]) {
+    sy = sy >= 0 ? (sy < sh ? sy : sh - 1) : 0;
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (long long)sy * spitch + aw);
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t lo = sel[k] == 0 ? w0 : (sel[k] == 1 ? w1 : w2);
+      const uint32_t hi = sel[k] == 0 ? w1 : w2;
+      const uint32_t two = __builtin_amdgcn_alignbyte(hi, lo, sh8[k]);  // bytes [tap0, tap1, ..]
+      const uint32_t spread = __builtin_amdgcn_perm(0u, two, 0x0c010c00u);  // tap0 | tap1 << 16
+      typedef short short2_t __attribute__((ext_vector_type(2)));
+      union { uint32_t u; short2_t s; } A, B;
+      A.u = spread;
+      B.u = wgt[k];
+      h[k] = __builtin_amdgcn_sdot2(A.s, B.s, 0, false) >> 4;
+    }
+  };
+  int h0[4], h1[4];
+  int prevS1 = -0x40000000;
+  const int dyEnd = min(dyBase + RESIZE_ROWS, dh);
+  for (int dy = dyBase; dy < dyEnd; dy++) {
+    const int sy0 = tb.yofs[dy];
+    const int b0 = tb.ibeta[dy * 2], b1 = tb.ibeta[dy * 2 + 1];
+    if (sy0 == prevS1) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) h0[k] = h1[k];
+    } else {
+      hpass(sy0, h0);
+    }
+    hpass(sy0 + 1, h1);
+    prevS1 = sy0 + 1;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int v = ((__mul24(b0, h0[k]) >> 16) + (__mul24(b1, h1[k]) >> 16) + 2) >> 2;  // |b| <= 2048, h < 2^15
+      v = min(max(v, 0), 255);
+      packed |= (live[k] ? (uint32_t)v : 0u) << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(dst + (long long)dy * dpitch + dx4) = packed;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // FAST-9-16 score = max over the 16 arcs of 9 of min(d) (and of min(-d)), minus 1
 // (cv::cornerScore<16>); the pixel is a corner at threshold t iff score >= t.
@@ -708,6 +787,7 @@ struct fb_orb {
   size_t octreeLds = 0;
   fb::DevBuf pyr, cand, nodeOf, counts, lvlOut, tabs;
   ResizeTabs rt[FB_MAX_LEVELS];
+  bool rowsOK[FB_MAX_LEVELS] = {};  // k_resize_rows' 12-byte window covers every 4-pixel group of the level
   // last call (for fb_orb_get_level)
   const uint8_t *lastImg = nullptr;
   long long lastImgStride = 0;
@@ -838,6 +918,9 @@ int prepare(fb_orb *o, int w, int h, int batch) {
         ibeta[dy * 2] = (short)fb_cvround((1.f - fy) * 2048.f);
         ibeta[dy * 2 + 1] = (short)fb_cvround(fy * 2048.f);
       }
+      bool ok = true;
+      for (int dx4 = 0; dx4 < dwd; dx4 += 4) ok = ok && (xofs[std::min(dx4 + 3, dwd - 1)] + 1 - (xofs[dx4] & ~3)) <= 11;
+      o->rowsOK[l] = ok;
       tabOff[l * 4 + 0] = append(xofs.data(), xofs.size() * 4);
       tabOff[l * 4 + 1] = append(ialpha.data(), ialpha.size() * 2);
       tabOff[l * 4 + 2] = append(yofs.data(), yofs.size() * 4);
@@ -941,7 +1024,13 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
     const int spitch = (l == 1) ? stride : S.pitch;
     dim3 blk(64, 4), grd((D.pitch / 4 + 63) / 64, (D.h + 3) / 4, batch);
     fb::ProfScope prof_(fb::P_RESIZE, s);
-    k_resize<<<grd, blk, 0, s>>>(src, sstr, S.w, S.h, spitch, o->pyr.as<uint8_t>() + D.off, K.pyrStride, D.w, D.h, D.pitch, o->rt[l]);
+    const bool rows = o->rowsOK[l] && spitch >= 12 && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)spitch | (uintptr_t)sstr) & 3) == 0;
+    if (rows) {
+      dim3 grdR((D.pitch / 4 + 63) / 64, (D.h + 4 * RESIZE_ROWS - 1) / (4 * RESIZE_ROWS), batch);
+      k_resize_rows<<<grdR, blk, 0, s>>>(src, sstr, S.w, S.h, spitch, o->pyr.as<uint8_t>() + D.off, K.pyrStride, D.w, D.h, D.pitch, o->rt[l]);
+    } else {
+      k_resize<<<grd, blk, 0, s>>>(src, sstr, S.w, S.h, spitch, o->pyr.as<uint8_t>() + D.off, K.pyrStride, D.w, D.h, D.pitch, o->rt[l]);
+    }
   }
   if (K.totalCells > 0) {
     fb::ProfScope prof_(fb::P_FAST, s);
