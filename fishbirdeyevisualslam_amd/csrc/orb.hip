@@ -43,6 +43,7 @@ struct LevelInfo {
   float hX;
   float scale;
   int patchSize;         // (int)(PATCH_SIZE*scale), :836
+  long long boff;        // byte offset of the level's blurred copy inside one image's blur buffer
 };
 
 struct OrbK {
@@ -51,6 +52,9 @@ struct OrbK {
   int dbg;  // FB_FAST_DBG ablation switch (0 = normal)
   int cellBase[FB_MAX_LEVELS + 1];  // first FAST cell of each level (contiguous copy for one scalar load)
   long long pyrStride;   // bytes per image of levels >= 1
+  long long blurStride;  // bytes per image of the blurred pyramid (all levels)
+  int blurStrips[FB_MAX_LEVELS + 1];  // first k_blur strip of each level
+  int blurEdgeTasks[FB_MAX_LEVELS + 1];  // first k_blur_edges task (3 per row) of each level
   long long candStride;  // candidates per image
   int umax[16];
   LevelInfo L[FB_MAX_LEVELS];
@@ -654,11 +658,12 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
 }
 
 // ------------------------------------------------------------------------------------------
-// One wave per keypoint: orientation (IC_Angle), 7x7 Gaussian blur of the 37x37 footprint,
-// 256 steered BRIEF tests, and the final cv::KeyPoint record.
+// GaussianBlur(level, 7x7, sigma 2, BORDER_REFLECT_101) of every pyramid level (ORBextractor.cc:1080), integer
+// kernel {18,34,49,55,49,34,18}/256 per pass, (sum + 2^15) >> 16 (oracle gaussian_blur7).  A wave owns a strip of
+// 256 columns x BLUR_ROWS rows: a lane filters 4 adjacent pixels and walks down the rows with the last seven
+// horizontal results in registers.  Horizontal pass = 2 x v_dot4_u32_u8 per pixel on a 12-byte window.
 // ------------------------------------------------------------------------------------------
-constexpr int RP = 43, RPITCH = 48;  // raw patch 43x43 (radius 21), rows staged as 12 dwords
-constexpr int BP = 37;               // blurred footprint (radius 18)
+constexpr int BLUR_ROWS = 16;
 
 __device__ __forceinline__ int reflect101(int i, int n) {
   if (i < 0) i = -i;
@@ -666,20 +671,128 @@ __device__ __forceinline__ int reflect101(int i, int n) {
   return i;
 }
 
+__global__ __launch_bounds__(256) void k_blur(OrbK K, const uint8_t *__restrict__ img0, long long imgStride, int pitch0,
+                                              const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur) {
+  const int b = blockIdx.y;
+  const int strip = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  if (strip >= K.blurStrips[K.nlevels]) return;
+  int l = 0;
+  while (strip >= K.blurStrips[l + 1]) l++;
+  const LevelInfo &L = K.L[l];
+  const int w = L.w, h = L.h;
+  const int sidx = strip - K.blurStrips[l];
+  const int nsx = (w + 255) >> 8;
+  const int sy = sidx / nsx, sx = sidx - sy * nsx;
+  const int x0 = sx * 256 + lane * 4;
+  const int y0 = sy * BLUR_ROWS;
+  if (x0 >= w) return;
+  const uint8_t *img;
+  int pitch;
+  if (l == 0) { img = img0 + (long long)b * imgStride; pitch = pitch0; }
+  else { img = pyr + (long long)b * K.pyrStride + L.off; pitch = L.pitch; }
+  uint8_t *out = blur + (long long)b * K.blurStride + L.boff;
+  // column groups whose 12-byte window leaves the row (x0 == 0 and the last one or two groups) belong to k_blur_edges
+  if (x0 < 4 || x0 + 8 > w) return;
+  const uint32_t WA = 18u | (34u << 8) | (49u << 16) | (55u << 24), WB = 49u | (34u << 8) | (18u << 16);
+  int ring[7][4];
+#pragma unroll
+  for (int r = 0; r < BLUR_ROWS + 6; r++) {
+    const int yo = y0 + r - 6;  // destination row completed by this source row
+    if (r >= 6 && yo >= h) break;
+    const int ys = reflect101(min(y0 + r - 3, h + 2), h);
+    const uint8_t *row = img + (long long)ys * pitch;
+    const uint32_t *pw = reinterpret_cast<const uint32_t *>(row + x0 - 4);
+    const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+    int *hr = ring[r % 7];
+    // taps of pixel j are window bytes 1+j .. 7+j
+    hr[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), WB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), WA, 0u, false), false);
+    hr[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), WB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), WA, 0u, false), false);
+    hr[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), WB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), WA, 0u, false), false);
+    hr[3] = __builtin_amdgcn_udot4(w2, WB, __builtin_amdgcn_udot4(w1, WA, 0u, false), false);
+    if (r >= 6) {
+      uint32_t packed = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int c0 = ring[(r + 1) % 7][k], c1 = ring[(r + 2) % 7][k], c2 = ring[(r + 3) % 7][k], c3 = ring[(r + 4) % 7][k];
+        const int c4 = ring[(r + 5) % 7][k], c5 = ring[(r + 6) % 7][k], c6 = ring[r % 7][k];
+        const int sum = __mul24(18, c0 + c6) + __mul24(34, c1 + c5) + __mul24(49, c2 + c4) + __mul24(55, c3);
+        packed |= (uint32_t)min((sum + (1 << 15)) >> 16, 255) << (8 * k);
+      }
+      *reinterpret_cast<uint32_t *>(out + (long long)yo * L.pitch + x0) = packed;
+    }
+  }
+}
+
+// The column groups k_blur leaves out: per level row, group 0 (x0 = 0) and the groups with x0 + 8 > w (one or two).
+// One lane per (row, group), generic BORDER_REFLECT_101 byte path; ~0.3 % of the pixels.
+__global__ __launch_bounds__(256) void k_blur_edges(OrbK K, const uint8_t *__restrict__ img0, long long imgStride,
+                                                    int pitch0, const uint8_t *__restrict__ pyr,
+                                                    uint8_t *__restrict__ blur) {
+  const int b = blockIdx.y;
+  int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= K.blurEdgeTasks[K.nlevels]) return;
+  int l = 0;
+  while (t >= K.blurEdgeTasks[l + 1]) l++;
+  t -= K.blurEdgeTasks[l];
+  const LevelInfo &L = K.L[l];
+  const int w = L.w, h = L.h;
+  const int y = t / 3, g = t - y * 3;
+  const int xr = ((w - 8) & ~3) + 4;          // first group with x0 + 8 > w
+  const int x0 = g == 0 ? 0 : xr + 4 * (g - 1);
+  if (x0 >= w || (g > 0 && x0 < 4)) return;
+  const uint8_t *img;
+  int pitch;
+  if (l == 0) { img = img0 + (long long)b * imgStride; pitch = pitch0; }
+  else { img = pyr + (long long)b * K.pyrStride + L.off; pitch = L.pitch; }
+  int cx[10];
+#pragma unroll
+  for (int i = 0; i < 10; i++) cx[i] = reflect101(min(x0 - 3 + i, w + 2), w);
+  const int wt[7] = {18, 34, 49, 55, 49, 34, 18};
+  int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int dy = 0; dy < 7; dy++) {
+    const uint8_t *row = img + (long long)reflect101(y + dy - 3, h) * pitch;
+    int px[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) px[i] = row[cx[i]];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int hsum = 18 * (px[k] + px[k + 6]) + 34 * (px[k + 1] + px[k + 5]) + 49 * (px[k + 2] + px[k + 4]) + 55 * px[k + 3];
+      acc[k] += wt[dy] * hsum;
+    }
+  }
+  uint8_t *out = blur + (long long)b * K.blurStride + L.boff + (long long)y * L.pitch + x0;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (x0 + k < w) out[k] = (uint8_t)min((acc[k] + (1 << 15)) >> 16, 255);
+}
+
+// ------------------------------------------------------------------------------------------
+// One wave per keypoint: orientation (IC_Angle on the raw level), 256 steered BRIEF tests on the blurred level,
+// and the final cv::KeyPoint record.  Key points sit >= 19 px inside the level (EDGE_THRESHOLD), so the radius-15
+// orientation patch and the radius-18 test footprint never leave the image.
+// ------------------------------------------------------------------------------------------
+// One wave per key point.  The radius-15 raw patch (orientation) and the radius-18 blurred patch (BRIEF tests) are
+// staged into LDS with coalesced dword loads: the 512 rotated sample positions are then LDS gathers instead of
+// scattered byte loads that would each cost a cache-line lookup in the vector L1 (measured: the L1 tag rate, not
+// ALU or HBM, bounded the direct-gather version).
+constexpr int DP_RAW_DW = 9, DP_RAW_ROWS = 31;    // 31 rows x 36 B  (x-15 .. x+15 after dword alignment)
+constexpr int DP_BL_DW = 10, DP_BL_ROWS = 37;     // 37 rows x 40 B  (x-18 .. x+18 after dword alignment)
+
 __global__ __launch_bounds__(64) void k_describe(OrbK K, const uint8_t *__restrict__ img0, long long imgStride,
                                                  int pitch0, const uint8_t *__restrict__ pyr,
+                                                 const uint8_t *__restrict__ blur,
                                                  const uint32_t *__restrict__ lvlOut, const int *__restrict__ lvlCount,
                                                  fb_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                  int32_t *__restrict__ nOut) {
-  __shared__ __attribute__((aligned(16))) uint8_t raw[RP * RPITCH];
-  __shared__ unsigned short hb[RP * BP];
-  __shared__ uint8_t bl[BP * BP + 3];
-  __shared__ __attribute__((aligned(16))) uint8_t dbytes[32];
+  __shared__ __attribute__((aligned(16))) uint32_t rawp[DP_RAW_ROWS * DP_RAW_DW];
+  __shared__ __attribute__((aligned(16))) uint32_t blp[DP_BL_ROWS * DP_BL_DW];
   const int b = blockIdx.y, lane = threadIdx.x;
-  int idx = blockIdx.x, l = 0, total = 0;
+  const int idx = blockIdx.x;
   const int *cnts = lvlCount + b * K.nlevels;
-  int myl = -1, myidx = 0;
-  for (l = 0; l < K.nlevels; l++) {
+  int total = 0, myl = -1, myidx = 0;
+  for (int l = 0; l < K.nlevels; l++) {
     const int c = cnts[l];
     if (myl < 0 && idx < total + c) { myl = l; myidx = idx - total; }
     total += c;
@@ -693,72 +806,69 @@ __global__ __launch_bounds__(64) void k_describe(OrbK K, const uint8_t *__restri
   int pitch;
   if (myl == 0) { img = img0 + (long long)b * imgStride; pitch = pitch0; }
   else { img = pyr + (long long)b * K.pyrStride + Lv.off; pitch = Lv.pitch; }
-  // patch rows as aligned dwords when the 43x43 window is inside the level (the common case); keypoints closer
-  // than 21 px to the border (they are >= 19 px inside) take the byte path with BORDER_REFLECT_101
-  const bool inside = cx - 21 >= 0 && cy - 21 >= 0 && cx + 25 < Lv.w && cy + 21 < Lv.h &&
-                      ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch) & 3) == 0;
-  int ox = 0;
-  if (inside) {
-    const int xa = (cx - 21) & ~3;
-    ox = (cx - 21) - xa;
-    const uint8_t *base = img + (long long)(cy - 21) * pitch + xa;
-    for (int i = lane; i < RP * 12; i += 64) {
-      const int yy = i / 12, xw = i - yy * 12;
-      reinterpret_cast<uint32_t *>(raw)[i] = *reinterpret_cast<const uint32_t *>(base + (long long)yy * pitch + xw * 4);
+  // stage both patches (key points sit >= 19 px inside the level, so neither patch leaves the image)
+  const int bxa = (cx - 18) & ~3, box = (cx - 18) - bxa;
+  {
+    const uint8_t *base = blur + (long long)b * K.blurStride + Lv.boff + (long long)(cy - 18) * Lv.pitch + bxa;
+    for (int i = lane; i < DP_BL_ROWS * DP_BL_DW; i += 64) {
+      const int yy = i / DP_BL_DW, xw = i - yy * DP_BL_DW;
+      blp[i] = *reinterpret_cast<const uint32_t *>(base + (long long)yy * Lv.pitch + xw * 4);
     }
-  } else {
-    for (int i = lane; i < RP * RP; i += 64) {
-      const int yy = i / RP, xx = i - yy * RP;
-      const int sx = reflect101(cx - 21 + xx, Lv.w), sy = reflect101(cy - 21 + yy, Lv.h);
-      raw[yy * RPITCH + xx] = img[(long long)sy * pitch + sx];
+  }
+  int rox;
+  if (((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch) & 3) == 0) {
+    const int rxa = (cx - 15) & ~3;
+    rox = (cx - 15) - rxa;
+    const uint8_t *base = img + (long long)(cy - 15) * pitch + rxa;
+    for (int i = lane; i < DP_RAW_ROWS * DP_RAW_DW; i += 64) {
+      const int yy = i / DP_RAW_DW, xw = i - yy * DP_RAW_DW;
+      rawp[i] = *reinterpret_cast<const uint32_t *>(base + (long long)yy * pitch + xw * 4);
+    }
+  } else {  // caller's level-0 image with an odd stride: byte loads
+    rox = 0;
+    uint8_t *rb = reinterpret_cast<uint8_t *>(rawp);
+    for (int i = lane; i < DP_RAW_ROWS * 31; i += 64) {
+      const int yy = i / 31, xx = i - yy * 31;
+      rb[yy * (DP_RAW_DW * 4) + xx] = img[(long long)(cy - 15 + yy) * pitch + cx - 15 + xx];
     }
   }
   __syncthreads();
-  // IC_Angle (ORBextractor.cc:77-104): lane v+15 sums row v of the circular patch
+  // IC_Angle (ORBextractor.cc:77-104): lanes 2*(v+15) and 2*(v+15)+1 sum the left (u < 0) and right (u >= 0) part
+  // of row v of the circular patch
   int m10 = 0, m01 = 0;
-  if (lane < 31) {
-    const int v = lane - 15, dmax = K.umax[v < 0 ? -v : v];
-    const uint8_t *row = &raw[(21 + v) * RPITCH + ox + 21];
+  if (lane < 62) {
+    const int v = (lane >> 1) - 15, dmax = K.umax[v < 0 ? -v : v];
+    const uint8_t *row = reinterpret_cast<const uint8_t *>(rawp) + (15 + v) * (DP_RAW_DW * 4) + rox + 15;
     int rs = 0;
-    for (int u = -dmax; u <= dmax; u++) { const int val = row[u]; m10 += u * val; rs += val; }
+    if (lane & 1) { for (int u = 0; u <= dmax; u++) { const int val = row[u]; m10 += u * val; rs += val; } }
+    else { for (int u = -dmax; u < 0; u++) { const int val = row[u]; m10 += u * val; rs += val; } }
     m01 = v * rs;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
   const float angle = fb_fast_atan2((float)m01, (float)m10);
-  // separable blur, integer kernel {18,34,49,55,49,34,18}, (sum + 2^15) >> 16 (oracle gaussian_blur7)
-  for (int i = lane; i < RP * BP; i += 64) {
-    const int yy = i / BP, xx = i - yy * BP;
-    const uint8_t *r = &raw[yy * RPITCH + ox + xx];
-    hb[i] = (unsigned short)(18 * (r[0] + r[6]) + 34 * (r[1] + r[5]) + 49 * (r[2] + r[4]) + 55 * r[3]);
-  }
-  __syncthreads();
-  for (int i = lane; i < BP * BP; i += 64) {
-    const int yy = i / BP, xx = i - yy * BP;
-    const unsigned short *c = &hb[yy * BP + xx];
-    const int s = 18 * ((int)c[0] + c[6 * BP]) + 34 * ((int)c[BP] + c[5 * BP]) + 49 * ((int)c[2 * BP] + c[4 * BP]) + 55 * (int)c[3 * BP];
-    bl[i] = (uint8_t)min((s + (1 << 15)) >> 16, 255);
-  }
-  __syncthreads();
   // computeOrbDescriptor (ORBextractor.cc:107-147): lane computes tests 4*lane .. 4*lane+3
   const float factorPI = 0x1.1df46ap-6f;
   float sa, ca;
   fb_sincos_f(angle * factorPI, &sa, &ca);
   const float a = ca, bb = sa;
+  const uint8_t *centre = reinterpret_cast<const uint8_t *>(blp) + 18 * (DP_BL_DW * 4) + box + 18;
   int nib = 0;
 #pragma unroll
   for (int t = 0; t < 4; t++) {
-    const int *pp = &c_pattern[(lane * 4 + t) * 4];
-    const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
-    const int t0 = bl[(18 + fb_cvround(x0 * bb + y0 * a)) * BP + 18 + fb_cvround(x0 * a - y0 * bb)];
-    const int t1 = bl[(18 + fb_cvround(x1 * bb + y1 * a)) * BP + 18 + fb_cvround(x1 * a - y1 * bb)];
+    const int4 pp = reinterpret_cast<const int4 *>(c_pattern)[lane * 4 + t];
+    const float x0 = (float)pp.x, y0 = (float)pp.y, x1 = (float)pp.z, y1 = (float)pp.w;
+    const int t0 = centre[fb_cvround(x0 * bb + y0 * a) * (DP_BL_DW * 4) + fb_cvround(x0 * a - y0 * bb)];
+    const int t1 = centre[fb_cvround(x1 * bb + y1 * a) * (DP_BL_DW * 4) + fb_cvround(x1 * a - y1 * bb)];
     nib |= (t0 < t1) << t;
   }
+  // lane 2j holds the low nibble of descriptor byte j, lane 2j+1 the high nibble; lanes 8j assemble dword j
   const int hi = __shfl_down(nib, 1, 64);
-  if ((lane & 1) == 0) dbytes[lane >> 1] = (uint8_t)(nib | (hi << 4));
-  __syncthreads();
+  const int byteVal = nib | (hi << 4);
+  const int b1 = __shfl_down(byteVal, 2, 64), b2 = __shfl_down(byteVal, 4, 64), b3 = __shfl_down(byteVal, 6, 64);
+  const uint32_t dw = (uint32_t)byteVal | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16) | ((uint32_t)b3 << 24);
   const long long o = (long long)b * K.capOut + idx;
-  if (lane < 2) reinterpret_cast<uint4 *>(desc + o * 32)[lane] = reinterpret_cast<const uint4 *>(dbytes)[lane];
+  if ((lane & 7) == 0) reinterpret_cast<uint32_t *>(desc + o * 32)[lane >> 3] = dw;
   if (lane == 0) {
     fb_keypoint kp;
     kp.x = (float)cx;
@@ -785,7 +895,7 @@ struct fb_orb {
   OrbK K;
   int maxNodes = 0;
   size_t octreeLds = 0;
-  fb::DevBuf pyr, cand, nodeOf, counts, lvlOut, tabs;
+  fb::DevBuf pyr, blur, cand, nodeOf, counts, lvlOut, tabs;
   ResizeTabs rt[FB_MAX_LEVELS];
   bool rowsOK[FB_MAX_LEVELS] = {};  // k_resize_rows' 12-byte window covers every 4-pixel group of the level
   // last call (for fb_orb_get_level)
@@ -846,8 +956,8 @@ int prepare(fb_orb *o, int w, int h, int batch) {
   K.minTh = p.min_th_fast;
   K.capOut = capacity_of(p);
   for (int i = 0; i < 16; i++) K.umax[i] = o->t.umax[i];
-  long long pyrOff = 0, candOff = 0;
-  int cells = 0, outOff = 0, maxNodes = 0;
+  long long pyrOff = 0, candOff = 0, blurOff = 0;
+  int cells = 0, outOff = 0, maxNodes = 0, strips = 0, edgeTasks = 0;
   std::vector<int> xofs, yofs;
   std::vector<short> ialpha, ibeta;
   std::vector<size_t> tabOff(p.nlevels * 4, 0);
@@ -869,6 +979,12 @@ int prepare(fb_orb *o, int w, int h, int batch) {
     L.pitch = (L.w + 63) & ~63;
     L.off = pyrOff;
     if (l > 0) pyrOff += (long long)L.pitch * L.h;
+    L.boff = blurOff;
+    blurOff += (long long)L.pitch * L.h;
+    K.blurStrips[l] = strips;
+    K.blurEdgeTasks[l] = edgeTasks;
+    edgeTasks += 3 * L.h;
+    strips += ((L.w + 255) / 256) * ((L.h + BLUR_ROWS - 1) / BLUR_ROWS);
     const int maxBX = L.w - BORDER, maxBY = L.h - BORDER;
     const float width = (float)(maxBX - BORDER), height = (float)(maxBY - BORDER);
     L.nCols = (int)(width / 30.f);
@@ -946,6 +1062,8 @@ int prepare(fb_orb *o, int w, int h, int batch) {
     K.fastMaxPix = (maxPix + 7) & ~7;
   }
   K.pyrStride = (pyrOff + 255) & ~255ll;
+  K.blurStride = (blurOff + 255) & ~255ll;
+  for (int l = p.nlevels; l <= FB_MAX_LEVELS; l++) { K.blurStrips[l] = strips; K.blurEdgeTasks[l] = edgeTasks; }
   K.candStride = candOff;
   K.outStride = outOff;
   o->maxNodes = maxNodes;
@@ -965,6 +1083,7 @@ int prepare(fb_orb *o, int w, int h, int batch) {
   }
   const size_t B = batch;
   FB_TRY(o->pyr.alloc(B * K.pyrStride + 256));
+  FB_TRY(o->blur.alloc(B * K.blurStride + 256));
   FB_TRY(o->cand.alloc(B * K.candStride * 4 + 16));
   FB_TRY(o->nodeOf.alloc(B * K.candStride * 2 + 16));
   FB_TRY(o->counts.alloc(B * p.nlevels * 4 * 2));  // candCount | lvlCount
@@ -1037,6 +1156,13 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
     k_fast<<<dim3((K.totalCells + 7) / 8 * 8, batch), 64, (size_t)2 * K.fastTileBytes + 4 * K.fastMaxOut + 2 * K.fastMaxPix, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
                                                       o->cand.as<uint32_t>(), candCount);
   }
+  {
+    fb::ProfScope prof_(fb::P_BLUR, s);
+    k_blur<<<dim3((K.blurStrips[nl] + 3) / 4, batch), 256, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
+                                                                    o->blur.as<uint8_t>());
+    k_blur_edges<<<dim3((K.blurEdgeTasks[nl] + 255) / 256, batch), 256, 0, s>>>(K, d_images, (long long)image_stride, stride,
+                                                                               o->pyr.as<uint8_t>(), o->blur.as<uint8_t>());
+  }
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->octreeLds));
   {
   fb::ProfScope prof_(fb::P_OCTREE, s);
@@ -1046,7 +1172,8 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
   {
   fb::ProfScope prof_(fb::P_DESCRIBE, s);
   k_describe<<<dim3(K.capOut, batch), 64, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
-                                                   o->lvlOut.as<uint32_t>(), lvlCount, d_keypoints, d_descriptors, d_n);
+                                                   o->blur.as<uint8_t>(), o->lvlOut.as<uint32_t>(), lvlCount, d_keypoints,
+                                                   d_descriptors, d_n);
   }
   FB_HIP(hipGetLastError());
   o->lastImg = d_images;
@@ -1101,6 +1228,16 @@ int fb_orb_get_level(fb_orb *o, int b, int level, uint8_t *dst, int *w, int *hgt
                                   : o->pyr.as<uint8_t>() + (long long)b * o->K.pyrStride + L.off;
   const int pitch = level == 0 ? o->lastPitch0 : L.pitch;
   FB_HIP(hipMemcpy2D(dst, L.w, src, pitch, L.w, L.h, hipMemcpyDeviceToHost));
+  return FB_OK;
+}
+
+int fb_orb_get_blurred_level(fb_orb *o, int b, int level, uint8_t *dst) {
+  FB_TRY(fb::check_device());
+  FB_ARG(o && dst && o->lastImg && level >= 0 && level < o->p.nlevels && b >= 0 && b < o->batchCap);
+  const LevelInfo &L = o->K.L[level];
+  FB_HIP(hipDeviceSynchronize());
+  const uint8_t *src = o->blur.as<uint8_t>() + (long long)b * o->K.blurStride + L.boff;
+  FB_HIP(hipMemcpy2D(dst, L.w, src, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
   return FB_OK;
 }
 

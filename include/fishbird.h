@@ -112,6 +112,9 @@ int fb_orb_extract_batch_dev(fb_orb *h, const uint8_t *d_images, int batch, int 
 /* debug/parity access to the pyramid level of image `b` of the last batch
  * (public member mvImagePyramid, ORBextractor.h:85). dst is host, w*h bytes.  */
 int fb_orb_get_level(fb_orb *h, int b, int level, uint8_t *dst, int *w, int *hgt);
+/* debug/parity: the same level after GaussianBlur(7x7, 2, 2, BORDER_REFLECT_101) (ORBextractor.cc:1080),
+ * the image computeDescriptors samples.  dst is host, w*h bytes of fb_orb_get_level's size. */
+int fb_orb_get_blurred_level(fb_orb *h, int b, int level, uint8_t *dst);
 /* debug/parity: FAST candidates of (image b, level) of the last batch, the input of
  * DistributeOctTree (vToDistributeKeys, ORBextractor.cc:822-824), packed
  * x | y<<12 | response<<24 in level coordinates, unordered.  Returns the count (>=0). */

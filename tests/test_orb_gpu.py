@@ -29,6 +29,11 @@ def _check_image(params, img, stagewise=True):
                 lv_o = O.orb_level(params, img, l)
                 lv_h = orb.level(0, l, img.size)
                 np.testing.assert_array_equal(lv_h, lv_o, err_msg="pyramid level %d" % l)
+                bl_o = np.zeros_like(lv_o)
+                O.lib().orc_gaussian_blur7(C.c_void_p(lv_o.ctypes.data), lv_o.shape[1], lv_o.shape[0], C.c_void_p(bl_o.ctypes.data))
+                bl_h = np.zeros_like(lv_o)
+                fb.check(fb.lib().fb_orb_get_blurred_level(orb.h, 0, l, C.c_void_p(bl_h.ctypes.data)), "blurred level")
+                np.testing.assert_array_equal(bl_h, bl_o, err_msg="blurred level %d" % l)
                 c_o = O.orb_candidates(params, img, l)
                 c_h = _cands(orb, 0, l)
                 so = c_o[np.lexsort((c_o[:, 0], c_o[:, 1]))]
