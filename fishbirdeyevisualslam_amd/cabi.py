@@ -143,6 +143,41 @@ class BowKfArgs(C.Structure):
                 ("matcher", MatcherParams), ("matches12", _vp), ("nmatches", _vp)]
 
 
+class KfTarget(C.Structure):
+    _fields_ = [("kf_stride", _i32), ("n_kf", _vp), ("kf_kps", _vp), ("kf_desc", _vp), ("kf_cell_start", _vp),
+                ("kf_cell_items", _vp), ("cam", Camera), ("grid", GridGeom),
+                ("scale_factors", _f32 * FB_MAX_LEVELS), ("inv_level_sigma2", _f32 * FB_MAX_LEVELS),
+                ("log_scale_factor", _f32), ("n_levels", _i32)]
+
+
+class MpList(C.Structure):
+    _fields_ = [("mp_stride", _i32), ("n_mp", _vp), ("mp_valid", _vp), ("mp_xw", _vp), ("mp_normal", _vp),
+                ("mp_max_dist", _vp), ("mp_min_dist", _vp), ("mp_desc", _vp)]
+
+
+class FuseArgs(C.Structure):
+    _fields_ = [("batch", _i32), ("kf", KfTarget), ("mp", MpList), ("pose", _vp), ("Ow", _vp), ("th", _f32),
+                ("best_idx", _vp)]
+
+
+class ProjSim3Args(C.Structure):
+    _fields_ = [("batch", _i32), ("kf", KfTarget), ("mp", MpList), ("Scw", _vp), ("kf_matched", _vp), ("th", _i32),
+                ("match_kf_to_mp", _vp), ("nmatches", _vp)]
+
+
+class Sim3Args(C.Structure):
+    _fields_ = [("batch", _i32), ("kf1", KfTarget), ("kf2", KfTarget), ("mp1", MpList), ("mp2", MpList),
+                ("T1w", _vp), ("T2w", _vp), ("s12", _vp), ("R12", _vp), ("t12", _vp), ("th", _f32),
+                ("matches12", _vp), ("nfound", _vp)]
+
+
+class InitMatchArgs(C.Structure):
+    _fields_ = [("batch", _i32), ("f1_stride", _i32), ("f2_stride", _i32), ("n1", _vp), ("kps1", _vp), ("desc1", _vp),
+                ("n2", _vp), ("kps2", _vp), ("desc2", _vp), ("f2_cell_start", _vp), ("f2_cell_items", _vp),
+                ("grid", GridGeom), ("window_size", _i32), ("matcher", MatcherParams),
+                ("prev_matched", _vp), ("matches12", _vp), ("nmatches", _vp)]
+
+
 class FrustumArgs(C.Structure):
     _fields_ = [("batch", _i32), ("mp_stride", _i32), ("Tcw", _vp), ("Ow", _vp), ("n_mp", _vp), ("mp_valid", _vp),
                 ("mp_xw", _vp), ("mp_normal", _vp), ("mp_max_dist", _vp), ("mp_min_dist", _vp),
@@ -203,6 +238,10 @@ EXPORTS = [
     "fb_match_birdview_dev", "fb_match_birdview",
     "fb_match_bow_dev", "fb_match_bow", "fb_match_triangulation_dev", "fb_match_triangulation",
     "fb_match_projection_keyframe_dev", "fb_match_projection_keyframe", "fb_match_bow_kf_dev", "fb_match_bow_kf",
+    "fb_fuse_search_dev", "fb_fuse_search", "fb_fuse_sim3_search_dev", "fb_fuse_sim3_search",
+    "fb_match_projection_sim3_dev", "fb_match_projection_sim3", "fb_match_sim3_dev", "fb_match_sim3",
+    "fb_match_initialization_dev", "fb_match_initialization",
+    "fb_distinctive_descriptors_dev", "fb_distinctive_descriptors",
     "fb_in_frustum_dev", "fb_in_frustum", "fb_undistort_keypoints_dev", "fb_undistort_keypoints", "fb_image_bounds",
     "fb_pose_opt_batch_dev", "fb_pose_opt", "fb_pose_gather_front_dev", "fb_pose_gather_bird_dev",
     "fb_local_ba", "fb_local_ba_sharded",

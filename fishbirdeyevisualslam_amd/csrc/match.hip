@@ -117,10 +117,12 @@ __device__ __forceinline__ void xform(const float *T, const float *X, float *o) 
 // LDS carve for a target frame of n keypoints / ncell cells. All offsets 16-B aligned.
 struct Carve {
   size_t desc, xy, oct, cs, items, end;
-  __host__ __device__ Carve(int n, int ncell) {
+  // withDesc = false: the descriptor table stays in HBM/L2 (frames too large for LDS, e.g. the 2*nFeatures
+  // initialisation extractor); only the key point positions, octaves and the grid are staged
+  __host__ __device__ Carve(int n, int ncell, bool withDesc = true) {
     auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
     desc = 0;
-    xy = up(desc + (size_t)n * 32);
+    xy = up(desc + (withDesc ? (size_t)n * 32 : 0));
     oct = up(xy + (size_t)n * 8);
     cs = up(oct + (size_t)n);
     items = up(cs + (size_t)(ncell + 1) * 2);
@@ -130,7 +132,7 @@ struct Carve {
 
 __device__ __forceinline__ TargetLds stage_target(uint8_t *smem, const Carve &cv, int n, int ncell,
                                                   const fb_keypoint *kps, const uint8_t *desc, const int32_t *cs,
-                                                  const int32_t *items) {
+                                                  const int32_t *items, bool withDesc = true) {
   uint32_t *ldesc = reinterpret_cast<uint32_t *>(smem + cv.desc);
   float2 *lxy = reinterpret_cast<float2 *>(smem + cv.xy);
   uint8_t *loct = smem + cv.oct;
@@ -140,7 +142,8 @@ __device__ __forceinline__ TargetLds stage_target(uint8_t *smem, const Carve &cv
   // descriptor table: n*32 B as 16-byte vectors (rows are 32-B aligned in the C-ABI arrays)
   const uint4 *src = reinterpret_cast<const uint4 *>(desc);
   uint4 *dst = reinterpret_cast<uint4 *>(ldesc);
-  for (int i = tid; i < n * 2; i += nt) dst[i] = src[i];
+  if (withDesc)
+    for (int i = tid; i < n * 2; i += nt) dst[i] = src[i];
   for (int i = tid; i < n; i += nt) {
     const fb_keypoint k = kps[i];
     lxy[i] = make_float2(k.x, k.y);
@@ -149,7 +152,7 @@ __device__ __forceinline__ TargetLds stage_target(uint8_t *smem, const Carve &cv
   for (int i = tid; i <= ncell; i += nt) lcs[i] = (uint16_t)cs[i];
   const int nitems = cs[ncell];
   for (int i = tid; i < nitems; i += nt) litems[i] = (uint16_t)items[i];
-  TargetLds T{reinterpret_cast<const uint4 *>(ldesc), lxy, loct, lcs, litems};
+  TargetLds T{withDesc ? reinterpret_cast<const uint4 *>(ldesc) : src, lxy, loct, lcs, litems};
   return T;
 }
 
@@ -689,8 +692,8 @@ __global__ void k_bird_keys_to_cam(const fb_keypoint *__restrict__ kps, const in
   dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
 }
 
-size_t match_lds_bytes(int cur_stride, int ncell, int extra_ints) {
-  return Carve(cur_stride, ncell).end + (size_t)extra_ints * 4;
+size_t match_lds_bytes(int cur_stride, int ncell, int extra_ints, bool withDesc = true) {
+  return Carve(cur_stride, ncell, withDesc).end + (size_t)extra_ints * 4;
 }
 
 int check_lds(size_t bytes, const char *what) {
@@ -949,3 +952,5 @@ int fb_match_birdview(const fb_birdview_args *H) {
 }
 
 }  // extern "C"
+
+#include "match_kf.inc"

@@ -397,6 +397,117 @@ typedef struct fb_bow_kf_args {
 int fb_match_bow_kf_dev(const fb_bow_kf_args *args, void *stream);
 int fb_match_bow_kf(const fb_bow_kf_args *args);
 
+/* --- M10: the remaining ORBmatcher entry points (same windowed Hamming search) ------------------ */
+/* key-frame side of a map-point -> key-frame search (KeyFrame.h members) */
+typedef struct fb_kf_target {
+  int32_t kf_stride;
+  const int32_t *n_kf;            /* pKF->N                                                        */
+  const fb_keypoint *kf_kps;      /* pKF->mvKeysUn                                                 */
+  const uint8_t *kf_desc;         /* pKF->mDescriptors                                             */
+  const int32_t *kf_cell_start;   /* pKF->mGrid as CSR (fb_grid_build_batch_dev)                   */
+  const int32_t *kf_cell_items;
+  fb_camera cam;                  /* fx, fy, cx, cy, mnMinX/Y, mnMaxX/Y                            */
+  fb_grid_geom grid;
+  float scale_factors[FB_MAX_LEVELS];    /* pKF->mvScaleFactors                                    */
+  float inv_level_sigma2[FB_MAX_LEVELS]; /* pKF->mvInvLevelSigma2                                  */
+  float log_scale_factor;         /* pKF->mfLogScaleFactor                                         */
+  int32_t n_levels;               /* pKF->mnScaleLevels                                            */
+} fb_kf_target;
+
+/* candidate map points (MapPoint getters) */
+typedef struct fb_mp_list {
+  int32_t mp_stride;
+  const int32_t *n_mp;
+  const uint8_t *mp_valid;        /* the entry point's own skip rule, see each function             */
+  const float *mp_xw;             /* [..][3] GetWorldPos()                                         */
+  const float *mp_normal;         /* [..][3] GetNormal()                                           */
+  const float *mp_max_dist;       /* mfMaxDistance                                                 */
+  const float *mp_min_dist;       /* mfMinDistance                                                 */
+  const uint8_t *mp_desc;         /* GetDescriptor()                                               */
+} fb_mp_list;
+
+/* Fuse(pKF, vpMapPoints, th) (ORBmatcher.cc:826-976; LocalMapping.cc:513,538) and
+ * Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (:978-1101; LoopClosing.cc:567).
+ * The search half of Fuse: best_idx[i] = bestIdx if bestDist <= TH_LOW, else -1.  The map mutation that follows
+ * (Replace / AddObservation / AddMapPoint, :950-971 and :1082-1096) stays with the caller, who walks best_idx in
+ * order; the search result does not depend on those mutations.
+ * mp_valid: Fuse = pMP && !isBad() && !IsInKeyFrame(pKF); Fuse-Sim3 = !isBad() && !spAlreadyFound.count(pMP).   */
+typedef struct fb_fuse_args {
+  int32_t batch;
+  fb_kf_target kf;
+  fb_mp_list mp;
+  const float *pose;              /* [batch][12]: GetRotation|GetTranslation (Fuse) or rows 0..2 of Scw (Sim3) */
+  const float *Ow;                /* [batch][3] GetCameraCenter() (Fuse); unused by the Sim3 variant  */
+  float th;
+  int32_t *best_idx;              /* [batch][mp_stride]                                             */
+} fb_fuse_args;
+int fb_fuse_search_dev(const fb_fuse_args *args, void *stream);
+int fb_fuse_search(const fb_fuse_args *args);
+int fb_fuse_sim3_search_dev(const fb_fuse_args *args, void *stream);
+int fb_fuse_sim3_search(const fb_fuse_args *args);
+
+/* SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:291-404; LoopClosing.cc:377).
+ * mp_valid = !isBad() && !spAlreadyFound.count(pMP).                                                 */
+typedef struct fb_proj_sim3_args {
+  int32_t batch;
+  fb_kf_target kf;
+  fb_mp_list mp;
+  const float *Scw;               /* [batch][12]                                                    */
+  const uint8_t *kf_matched;      /* vpMatched[idx] != NULL on entry                                */
+  int32_t th;
+  int32_t *match_kf_to_mp;        /* [batch][kf_stride]: point newly written to vpMatched[idx], or -1 */
+  int32_t *nmatches;
+} fb_proj_sim3_args;
+int fb_match_projection_sim3_dev(const fb_proj_sim3_args *args, void *stream);
+int fb_match_projection_sim3(const fb_proj_sim3_args *args);
+
+/* SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (ORBmatcher.cc:1103-1327; LoopClosing.cc:341).
+ * Per key-frame feature i: the MapPoint it holds (mp*.{xw,desc,max,min}[i]), mp*.mp_valid[i] =
+ * vpMapPoints[i] && !vbAlreadyMatched[i] && !isBad().  kf1/kf2 strides equal mp1/mp2 strides.        */
+typedef struct fb_sim3_args {
+  int32_t batch;
+  fb_kf_target kf1, kf2;
+  fb_mp_list mp1, mp2;
+  const float *T1w, *T2w;         /* [batch][12] GetRotation|GetTranslation of pKF1 / pKF2          */
+  const float *s12;               /* [batch]                                                        */
+  const float *R12;               /* [batch][9]                                                     */
+  const float *t12;               /* [batch][3]                                                     */
+  float th;
+  int32_t *matches12;             /* [batch][kf1 stride]: idx2 with vnMatch1[i1]==idx2 && vnMatch2[idx2]==i1, or -1 */
+  int32_t *nfound;
+} fb_sim3_args;
+int fb_match_sim3_dev(const fb_sim3_args *args, void *stream);
+int fb_match_sim3(const fb_sim3_args *args);
+
+/* SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:406-521; Tracking.cc:1293) */
+typedef struct fb_init_match_args {
+  int32_t batch;
+  int32_t f1_stride, f2_stride;
+  const int32_t *n1;
+  const fb_keypoint *kps1;        /* F1.mvKeysUn                                                    */
+  const uint8_t *desc1;
+  const int32_t *n2;
+  const fb_keypoint *kps2;        /* F2.mvKeysUn                                                    */
+  const uint8_t *desc2;
+  const int32_t *f2_cell_start;   /* F2.mGrid                                                       */
+  const int32_t *f2_cell_items;
+  fb_grid_geom grid;
+  int32_t window_size;
+  fb_matcher_params matcher;      /* ORBmatcher(0.9,true) at Tracking.cc:1292                       */
+  float *prev_matched;            /* [batch][f1_stride][2] vbPrevMatched, in/out                    */
+  int32_t *matches12;             /* [batch][f1_stride] vnMatches12                                 */
+  int32_t *nmatches;
+} fb_init_match_args;
+int fb_match_initialization_dev(const fb_init_match_args *args, void *stream);
+int fb_match_initialization(const fb_init_match_args *args);
+
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:242-307): for each map point, the observation descriptor with
+ * the least median Hamming distance to the others.  CSR over map points: obs_start[n_mp+1], obs_desc[obs_start[n_mp]][32].
+ * best_obs[i] = index (relative to obs_start[i]) of the chosen descriptor, -1 when the point has no observation. */
+int fb_distinctive_descriptors_dev(const int32_t *d_obs_start, const uint8_t *d_obs_desc, int n_mp,
+                                   int32_t *d_best_obs, void *stream);
+int fb_distinctive_descriptors(const int32_t *obs_start, const uint8_t *obs_desc, int n_mp, int32_t *best_obs);
+
 /* ======================================================================== */
 /* Frame geometry either side of the matchers (src/Frame.cc)                 */
 /* ======================================================================== */

@@ -553,3 +553,5 @@ int orc_match_triangulation(const fb_triangulation_args *A) {
 
 #include <limits>
 #include "match_more_oracle.inc"
+#include <algorithm>
+#include "match_kf_oracle.inc"

@@ -92,6 +92,43 @@ def more_cases(L, prefix="orc_", call=None, grid_fn=None):
     lib = L.lib() if hasattr(L, "lib") else L
     u = M.undistort(lib, prefix, kps)
     out["undistort"] = dict(xy=np.stack([u["x"], u["y"]], 1), bounds=M.image_bounds(lib, prefix, 1280, 720))
+    out.update(kf_cases(lib, prefix, call, grid_fn or O.grid_build))
+    return out
+
+
+def kf_cases(lib, prefix, call, grid_fn):
+    """Key-frame side matcher entry points + ComputeDistinctiveDescriptors."""
+    import ctypes as C
+    from fishbirdeyevisualslam_amd import kf_problems as KP
+    pre = "orc_" if prefix == "orc_" else "fb_"
+    geom = P.grid_geom(synth.front_grid_geom(KP.W, KP.H))
+    out = {}
+    for sim3, name in ((False, "fuse_search"), (True, "fuse_sim3_search")):
+        probs = [KP.make_kf_points_problem(8000, 400, 600, sim3)]
+        cs, ci = P.build_grid_host([p["kf_kps"] for p in probs], geom, grid_fn, 400)
+        a, o, keep = KP.fuse_args(probs, cs, ci)
+        call(pre + name, a)
+        out[name] = dict(best_idx=o["best_idx"])
+    a, o, keep = KP.proj_sim3_args(probs, cs, ci)
+    call(pre + "match_projection_sim3", a)
+    out["proj_sim3"] = dict(match=o["match_kf_to_mp"], n=o["nmatches"])
+    probs = [KP.make_sim3_problem(8100, 400, 400, 250)]
+    g1 = P.build_grid_host([p["kps1"] for p in probs], geom, grid_fn, 400)
+    g2 = P.build_grid_host([p["kps2"] for p in probs], geom, grid_fn, 400)
+    a, o, keep = KP.sim3_args(probs, g1, g2)
+    call(pre + "match_sim3", a)
+    out["sim3"] = dict(match=o["matches12"], n=o["nfound"])
+    probs = [KP.make_init_problem(8200, 600, 600)]
+    cs, ci = P.build_grid_host([p["kps2"] for p in probs], geom, grid_fn, 600)
+    a, o, keep = KP.init_args(probs, cs, ci)
+    call(pre + "match_initialization", a)
+    out["init_match"] = dict(match=o["matches12"], n=o["nmatches"], prev=o["prev_matched"])
+    start, desc = KP.make_distinctive_problem(8300, 300, max_obs=12, big=1)
+    best = np.zeros(300, np.int32)
+    rc = getattr(lib, prefix + "distinctive_descriptors")(C.c_void_p(start.ctypes.data), C.c_void_p(desc.ctypes.data), 300,
+                                                         C.c_void_p(best.ctypes.data))
+    assert rc == 0
+    out["distinctive"] = dict(best=best)
     return out
 
 
