@@ -336,30 +336,27 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
   //      at minThFAST (needed only when the cell has to be redone at the lower threshold)
   int nlA = 0, nlB = 0;
   const int cap = K.fastMaxPix;
-  for (int base = 0; base < npix; base += 64) {
-    const int p = base + lane;
-    bool c9 = false, c9i = false;
-    int off = 0;
-    if (p < npix) {
-      const int yq = (int)(((float)p + 0.5f) * inv_dwid);
-      const int yy = yq + 3, xx = p - yq * dwid + 3;
-      off = yy * tp + ox + xx;
+  // Lanes map to (row-in-group, column): 32 columns x 2 rows per iteration for the usual <= 32 px wide cells, 64 x 1
+  // otherwise, so the LDS offset advances by a constant and no index division is needed.  The compass test for ANY
+  // threshold T is "strength > T" with strength = max(max over adjacent compass pairs of min(d_i, d_j),
+  // -(min over adjacent pairs of max(d_i, d_j))): two adjacent compass points brighter, or two darker, by more than T.
+  (void)npix; (void)inv_dwid;
+  const int G = dwid <= 32 ? 32 : 64, rpi = dwid <= 32 ? 2 : 1;
+  const int sxx = lane & (G - 1), sry = dwid <= 32 ? (lane >> 5) : 0;
+  const bool colok = sxx < dwid;
+  const int tp3 = 3 * tp, sstep = rpi * tp;
+  int off = (3 + sry) * tp + ox + 3 + sxx;
+  for (int y = 0; y < dhei; y += rpi, off += sstep) {
+    int strength = -1;
+    if (colok && y + sry < dhei) {
       const uint8_t *c = &tile[off];
       const int v = c[0];
-      const int d0 = v - c[3 * tp], d4 = v - c[3], d8 = v - c[-3 * tp], d12 = v - c[-3];
-      {
-        const int T = K.minTh;
-        const bool b0 = d0 > T, b4 = d4 > T, b8 = d8 > T, b12 = d12 > T;
-        const bool n0 = d0 < -T, n4 = d4 < -T, n8 = d8 < -T, n12 = d12 < -T;
-        c9 = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0) | (n0 & n4) | (n4 & n8) | (n8 & n12) | (n12 & n0);
-      }
-      if (c9) {
-        const int T = K.iniTh;
-        const bool b0 = d0 > T, b4 = d4 > T, b8 = d8 > T, b12 = d12 > T;
-        const bool n0 = d0 < -T, n4 = d4 < -T, n8 = d8 < -T, n12 = d12 < -T;
-        c9i = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0) | (n0 & n4) | (n4 & n8) | (n8 & n12) | (n12 & n0);
-      }
+      const int d0 = v - c[tp3], d4 = v - c[3], d8 = v - c[-tp3], d12 = v - c[-3];
+      const int hi = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));
+      const int lo = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));
+      strength = max(hi, -lo);
     }
+    const bool c9i = strength > K.iniTh, c9 = strength > K.minTh;
     const unsigned long long mA = __ballot(c9i), mB = __ballot(c9 && !c9i);
     if (c9i) s_list[nlA + __popcll(mA & lt)] = (unsigned short)off;
     else if (c9) s_list[cap - 1 - (nlB + __popcll(mB & lt))] = (unsigned short)off;
