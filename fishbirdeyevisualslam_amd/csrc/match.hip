@@ -159,8 +159,16 @@ __device__ __forceinline__ TargetLds stage_target(uint8_t *smem, const Carve &cv
 // ---------------------------------------------------------------------------------------
 // M3  SearchByProjection(CurrentFrame, LastFrame, th, bMono=true)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args A) {
+// Every round after the first re-decides each query from a per-query cache of its CACHE_K best admissible candidates
+// (sorted by distance, ties in grid-walk order = the reference's "first minimum wins"), so the grid walk and the
+// Hamming distances are done once; a query whose cached candidates are all taken and whose cache is incomplete
+// falls back to the full walk.  cacheK = 0 (LDS too small) keeps the full walk every round.
+constexpr int CACHE_K = 4;
+
+__global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args A, int cacheK) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  typedef unsigned short u16;
+  constexpr int NONE16 = 0xFFFF;
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int ncell = A.grid.cols * A.grid.rows;
   const size_t co = (size_t)b * A.cur_stride, lo = (size_t)b * A.last_stride;
@@ -170,62 +178,119 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
                                    A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co);
   int *ownerA = reinterpret_cast<int *>(smem + cv.end);  // [cur_stride]
   int *ownerB = ownerA + A.cur_stride;                   // [cur_stride]
-  int *assignA = ownerB + A.cur_stride;                  // [last_stride]
-  int *assignB = assignA + A.last_stride;                // [last_stride]
-  __shared__ int s_changed, s_n, s_hist[HISTO_LENGTH], s_ind[3];
+  uint32_t *cache = reinterpret_cast<uint32_t *>(ownerB + A.cur_stride);  // [last_stride][cacheK]  dist << 16 | idx
+  u16 *assignA = reinterpret_cast<u16 *>(cache + (size_t)A.last_stride * cacheK);  // [last_stride]
+  u16 *assignB = assignA + A.last_stride;                // [last_stride]
+  u16 *perm = assignB + A.last_stride;                   // [last_stride] queries sorted by octave (processing order)
+  uint8_t *meta = reinterpret_cast<uint8_t *>(perm + A.last_stride);  // [last_stride] cached count | complete << 7
+  __shared__ int s_changed, s_n, s_hist[HISTO_LENGTH], s_ind[3], s_oct[FB_MAX_LEVELS + 1];
   __shared__ float s_T[12];
   if (tid < 12) s_T[tid] = A.cur_Tcw[(size_t)b * 12 + tid];
+  if (tid <= FB_MAX_LEVELS) s_oct[tid] = 0;
   const uint8_t *blocked0 = A.cur_blocked ? A.cur_blocked + co : nullptr;
   for (int i = tid; i < ncur; i += nt) ownerA[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
-  for (int q = tid; q < nlast; q += nt) assignA[q] = NONE;
+  for (int q = tid; q < nlast; q += nt) assignA[q] = NONE16;
   __syncthreads();
+  // The search radius depends only on the octave: hand the lanes of a wave queries of the same octave so that their
+  // grid walks have the same length (the query INDEX keeps deciding priorities, only the processing order changes).
+  auto oct_bin = [&](int q) -> int {
+    const int o = A.last_valid[lo + q] ? A.last_octave[lo + q] : FB_MAX_LEVELS;
+    return o < 0 ? 0 : (o > FB_MAX_LEVELS ? FB_MAX_LEVELS : o);
+  };
+  for (int q = tid; q < nlast; q += nt) atomicAdd(&s_oct[oct_bin(q)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i <= FB_MAX_LEVELS; i++) { const int c = s_oct[i]; s_oct[i] = run; run += c; }
+  }
+  __syncthreads();
+  for (int q = tid; q < nlast; q += nt) perm[atomicAdd(&s_oct[oct_bin(q)], 1)] = (u16)q;
+  __syncthreads();
+
+  // full grid walk of query q against the claims in `owner`; fill = also (re)build the query's cache
+  auto full_search = [&](int q, const int *owner, bool fill) -> int {
+    int best = NONE;
+    uint32_t top[CACHE_K];
+#pragma unroll
+    for (int k = 0; k < CACHE_K; k++) top[k] = 0xFFFFFFFFu;
+    int nElig = 0;
+    if (A.last_valid[lo + q]) {
+      float X[3] = {A.last_xw[(lo + q) * 3], A.last_xw[(lo + q) * 3 + 1], A.last_xw[(lo + q) * 3 + 2]};
+      float pc[3];
+      xform(s_T, X, pc);
+      const float xc = pc[0], yc = pc[1];
+      const float invzc = (float)(1.0 / pc[2]);
+      if (!(invzc < 0)) {
+        const float u = A.cam.fx * xc * invzc + A.cam.cx;
+        const float v = A.cam.fy * yc * invzc + A.cam.cy;
+        if (!(u < A.cam.min_x || u > A.cam.max_x) && !(v < A.cam.min_y || v > A.cam.max_y)) {
+          const int oct = A.last_octave[lo + q];
+          const float radius = A.th * A.scale_factors[oct];
+          uint32_t d[8];
+          const uint4 *dq = reinterpret_cast<const uint4 *>(A.last_desc + (lo + q) * 32);
+          const uint4 d0 = dq[0], d1 = dq[1];
+          d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+          int bestDist = 256;
+          for_area<false>(A.grid, T, u, v, radius, oct - 1, oct + 1, [&](int i2) {
+            const int own = owner[i2];
+            if (own == -1) return;      // occupied on entry: never a candidate
+            const int dist = fb::hamming256(d, T.desc + i2 * 2);
+            if (fill && dist <= TH_HIGH) {  // stable insertion into the sorted top-K (equal keys keep walk order)
+              nElig++;
+              uint32_t e = ((uint32_t)dist << 16) | (uint32_t)i2;
+#pragma unroll
+              for (int k = 0; k < CACHE_K; k++) {
+                if ((e >> 16) < (top[k] >> 16)) { const uint32_t t = top[k]; top[k] = e; e = t; }
+              }
+            }
+            if (own < q) return;        // taken by an earlier query
+            if (dist < bestDist) { bestDist = dist; best = i2; }
+          });
+          if (bestDist > TH_HIGH) best = NONE;
+        }
+      }
+    }
+    if (fill) {
+      const int n = nElig < cacheK ? nElig : cacheK;
+      for (int k = 0; k < cacheK; k++) cache[(size_t)q * cacheK + k] = top[k < CACHE_K ? k : 0];
+      meta[q] = (uint8_t)(n | (nElig <= cacheK ? 0x80 : 0));
+    }
+    return best;
+  };
 
   for (int round = 0; round <= nlast + 1; round++) {
     for (int i = tid; i < ncur; i += nt) ownerB[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
     if (tid == 0) s_changed = 0;
     __syncthreads();
-    for (int q = tid; q < nlast; q += nt) {
+    for (int pq = tid; pq < nlast; pq += nt) {
+      const int q = perm[pq];
       int best = NONE;
-      if (A.last_valid[lo + q]) {
-        float X[3] = {A.last_xw[(lo + q) * 3], A.last_xw[(lo + q) * 3 + 1], A.last_xw[(lo + q) * 3 + 2]};
-        float pc[3];
-        xform(s_T, X, pc);
-        const float xc = pc[0], yc = pc[1];
-        const float invzc = (float)(1.0 / pc[2]);
-        if (!(invzc < 0)) {
-          const float u = A.cam.fx * xc * invzc + A.cam.cx;
-          const float v = A.cam.fy * yc * invzc + A.cam.cy;
-          if (!(u < A.cam.min_x || u > A.cam.max_x) && !(v < A.cam.min_y || v > A.cam.max_y)) {
-            const int oct = A.last_octave[lo + q];
-            const float radius = A.th * A.scale_factors[oct];
-            uint32_t d[8];
-            const uint4 *dq = reinterpret_cast<const uint4 *>(A.last_desc + (lo + q) * 32);
-            const uint4 d0 = dq[0], d1 = dq[1];
-            d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
-            int bestDist = 256;
-            for_area<false>(A.grid, T, u, v, radius, oct - 1, oct + 1, [&](int i2) {
-              if (ownerA[i2] < q) return;  // taken by an earlier query / occupied on entry
-              const int dist = fb::hamming256(d, T.desc + i2 * 2);
-              if (dist < bestDist) { bestDist = dist; best = i2; }
-            });
-            if (bestDist > TH_HIGH) best = NONE;
-          }
+      if (round == 0 || cacheK == 0) {
+        best = full_search(q, ownerA, cacheK > 0);
+      } else {
+        const int m = meta[q], n = m & 0x7f;
+        for (int k = 0; k < n; k++) {
+          const int i2 = (int)(cache[(size_t)q * cacheK + k] & 0xFFFFu);
+          if (!(ownerA[i2] < q)) { best = i2; break; }
         }
+        if (best == NONE && n > 0 && !(m & 0x80)) best = full_search(q, ownerA, false);
       }
-      assignB[q] = best;
-      if (best != assignA[q]) s_changed = 1;
+      const int best16 = best == NONE ? NONE16 : best;
+      assignB[q] = (u16)best16;
+      if (best16 != assignA[q]) s_changed = 1;
       if (best != NONE && A.last_obs_pos[lo + q]) atomicMin(&ownerB[best], q);
     }
     __syncthreads();
     const int changed = s_changed;
     int *t = ownerA; ownerA = ownerB; ownerB = t;
-    t = assignA; assignA = assignB; assignB = t;
+    u16 *t16 = assignA; assignA = assignB; assignB = t16;
     __syncthreads();
     if (!changed) break;
   }
 
   // commit: last writer wins; rotation histogram culling (ORBmatcher.cc:1446-1468)
   int *matchL = ownerB;  // reuse
+  u16 *binQ = assignB;   // reuse: histogram bin of each accepted query
   for (int i = tid; i < ncur; i += nt) matchL[i] = -1;
   if (tid < HISTO_LENGTH) s_hist[tid] = 0;
   if (tid == 0) s_n = 0;
@@ -233,13 +298,13 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
   const bool ori = A.matcher.check_orientation != 0;
   for (int q = tid; q < nlast; q += nt) {
     const int c = assignA[q];
-    if (c == NONE) continue;
+    if (c == NONE16) continue;
     atomicMax(&matchL[c], q);
     atomicAdd(&s_n, 1);
     if (ori) {
       const int bin = rot_bin(A.last_angle[lo + q] - A.cur_kps[co + c].angle);
       atomicAdd(&s_hist[bin], 1);
-      assignB[q] = bin;
+      binQ[q] = (u16)bin;
     }
   }
   __syncthreads();
@@ -248,8 +313,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
     __syncthreads();
     for (int q = tid; q < nlast; q += nt) {
       const int c = assignA[q];
-      if (c == NONE) continue;
-      const int bin = assignB[q];
+      if (c == NONE16) continue;
+      const int bin = binQ[q];
       if (bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2]) {
         matchL[c] = -1;
         atomicSub(&s_n, 1);
@@ -773,11 +838,15 @@ int fb_match_projection_frame_dev(const fb_proj_frame_args *A, void *stream) {
   FB_ARG(A && A->batch >= 0 && A->cur_stride > 0 && A->last_stride >= 0 && A->cur_stride < 65536);
   if (A->batch == 0) return FB_OK;
   const int ncell = A->grid.cols * A->grid.rows;
-  const size_t lds = match_lds_bytes(A->cur_stride, ncell, 2 * A->cur_stride + 2 * A->last_stride);
+  // ints: two owner arrays; per query two u16 assignments + u16 processing order + one meta byte (2 ints) + the cache
+  const int base_ints = 2 * A->cur_stride + 2 * A->last_stride + 4;
+  int cacheK = CACHE_K;
+  size_t lds = match_lds_bytes(A->cur_stride, ncell, base_ints + cacheK * A->last_stride);
+  if (lds > 160 * 1024 - 512) { cacheK = 0; lds = match_lds_bytes(A->cur_stride, ncell, base_ints); }
   FB_TRY(check_lds(lds, "fb_match_projection_frame"));
   FB_TRY(set_max_lds(k_proj_frame, lds));
   fb::ProfScope prof_(fb::P_PROJ_FRAME, fb::as_stream(stream));
-  k_proj_frame<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A);
+  k_proj_frame<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A, cacheK);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
