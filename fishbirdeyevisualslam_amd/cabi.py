@@ -178,6 +178,13 @@ class InitMatchArgs(C.Structure):
                 ("prev_matched", _vp), ("matches12", _vp), ("nmatches", _vp)]
 
 
+class BirdFilterArgs(C.Structure):
+    _fields_ = [("batch", _i32), ("match_stride", _i32), ("kp1_stride", _i32), ("kp2_stride", _i32),
+                ("n_matches", _vp), ("query_idx", _vp), ("train_idx", _vp), ("cam_xyz1", _vp), ("cam_xyz2", _vp),
+                ("Tcw1", _vp), ("Tcw2", _vp), ("occupied2", _vp), ("window_size", _f32), ("keep", _vp),
+                ("pt_world", _vp)]
+
+
 class FrustumArgs(C.Structure):
     _fields_ = [("batch", _i32), ("mp_stride", _i32), ("Tcw", _vp), ("Ow", _vp), ("n_mp", _vp), ("mp_valid", _vp),
                 ("mp_xw", _vp), ("mp_normal", _vp), ("mp_max_dist", _vp), ("mp_min_dist", _vp),
@@ -242,6 +249,7 @@ EXPORTS = [
     "fb_match_projection_sim3_dev", "fb_match_projection_sim3", "fb_match_sim3_dev", "fb_match_sim3",
     "fb_match_initialization_dev", "fb_match_initialization",
     "fb_distinctive_descriptors_dev", "fb_distinctive_descriptors",
+    "fb_bird_filter_matches_dev", "fb_bird_filter_matches",
     "fb_in_frustum_dev", "fb_in_frustum", "fb_undistort_keypoints_dev", "fb_undistort_keypoints", "fb_image_bounds",
     "fb_pose_opt_batch_dev", "fb_pose_opt", "fb_pose_gather_front_dev", "fb_pose_gather_bird_dev",
     "fb_local_ba", "fb_local_ba_sharded",

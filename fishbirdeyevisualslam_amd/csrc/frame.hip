@@ -52,6 +52,53 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_in_frustum(fb_frustum_args A)
   A.view_cos[e] = viewCos;
 }
 
+// Tracking::FilterBirdOutlierInFront geometric test: one workgroup per frame pair.  Pass 1 evaluates every match and
+// lets the passing ones compete for their train slot with atomicMin on the match index (the serial rule "the first
+// passing match takes the slot"); pass 2 writes the flags.
+__global__ __launch_bounds__(256) void k_bird_filter(fb_bird_filter_args A) {
+  extern __shared__ int s_first[];  // [kp2_stride] smallest passing match index per train slot
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const size_t mo = (size_t)b * A.match_stride, o1 = (size_t)b * A.kp1_stride, o2 = (size_t)b * A.kp2_stride;
+  const int nm = A.n_matches[b];
+  __shared__ float s_Twc1[12], s_T2[12];
+  if (tid == 0) {
+    const float *T1 = A.Tcw1 + (size_t)b * 12;
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) s_Twc1[r * 4 + c] = T1[c * 4 + r];
+      s_Twc1[r * 4 + 3] = -((T1[0 * 4 + r] * T1[3] + T1[1 * 4 + r] * T1[7]) + T1[2 * 4 + r] * T1[11]);  // Converter::invT
+    }
+    for (int i = 0; i < 12; i++) s_T2[i] = A.Tcw2[(size_t)b * 12 + i];
+  }
+  for (int i = tid; i < A.kp2_stride; i += nt) s_first[i] = 0x7fffffff;
+  __syncthreads();
+  for (int i = tid; i < nm; i += nt) {
+    const int qi = A.query_idx[mo + i], ti = A.train_idx[mo + i];
+    bool pass = false;
+    float ptw[3] = {0.f, 0.f, 0.f};
+    if (!A.occupied2[o2 + ti]) {
+      const float *p1 = A.cam_xyz1 + (o1 + qi) * 3;
+      float pc2[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) ptw[r] = ((s_Twc1[r * 4] * p1[0] + s_Twc1[r * 4 + 1] * p1[1]) + s_Twc1[r * 4 + 2] * p1[2]) + s_Twc1[r * 4 + 3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) pc2[r] = ((s_T2[r * 4] * ptw[0] + s_T2[r * 4 + 1] * ptw[1]) + s_T2[r * 4 + 2] * ptw[2]) + s_T2[r * 4 + 3];
+      const float *p2 = A.cam_xyz2 + (o2 + ti) * 3;
+      const float d0 = pc2[0] - p2[0], d1 = pc2[1] - p2[1], d2 = pc2[2] - p2[2];
+      const double disC = sqrt((double)d0 * d0 + (double)d1 * d1 + (double)d2 * d2);
+      pass = disC < (double)A.window_size;
+    }
+    if (pass) {
+      atomicMin(&s_first[ti], i);
+#pragma unroll
+      for (int k = 0; k < 3; k++) A.pt_world[(mo + i) * 3 + k] = ptw[k];
+    }
+    A.keep[mo + i] = pass ? 2 : 0;  // 2 = passed the test, resolved below
+  }
+  __syncthreads();
+  for (int i = tid; i < nm; i += nt)
+    if (A.keep[mo + i] == 2) A.keep[mo + i] = (s_first[A.train_idx[mo + i]] == i) ? 1 : 0;
+}
+
 struct CamKD { float K[4], D[4]; };
 
 __global__ __launch_bounds__(FRAME_THREADS) void k_undistort(const fb_keypoint *kps, const int32_t *n, int stride, CamKD C,
@@ -111,6 +158,42 @@ int fb_in_frustum(const fb_frustum_args *H) {
   if (H->proj_xr) FB_TRY(o2.download(H->proj_xr, B * ms * 4));
   FB_TRY(o3.download(H->level, B * ms * 4));
   return o4.download(H->view_cos, B * ms * 4);
+}
+
+int fb_bird_filter_matches_dev(const fb_bird_filter_args *A, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(A && A->batch >= 0 && A->match_stride >= 0 && A->kp1_stride > 0 && A->kp2_stride > 0 && A->kp2_stride <= 40000);
+  if (A->batch == 0 || A->match_stride == 0) return FB_OK;
+  FB_ARG(A->n_matches && A->query_idx && A->train_idx && A->cam_xyz1 && A->cam_xyz2 && A->Tcw1 && A->Tcw2 && A->occupied2 && A->keep && A->pt_world);
+  const size_t lds = (size_t)A->kp2_stride * 4;
+  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bird_filter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  fb::ProfScope prof_(fb::P_FRUSTUM, fb::as_stream(stream));
+  k_bird_filter<<<A->batch, 256, lds, fb::as_stream(stream)>>>(*A);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+int fb_bird_filter_matches(const fb_bird_filter_args *H) {
+  FB_TRY(fb::check_device());
+  FB_ARG(H && H->batch >= 0 && H->match_stride >= 0);
+  fb_bird_filter_args D = *H;
+  const size_t B = H->batch, ms = H->match_stride, s1 = H->kp1_stride, s2 = H->kp2_stride;
+  if (B == 0 || ms == 0) return FB_OK;
+  fb::DevBuf b0, b1, b2, b3, b4, b5, b6, b7, o0, o1;
+  FB_TRY(b0.upload(H->n_matches, B * 4)); D.n_matches = b0.as<int32_t>();
+  FB_TRY(b1.upload(H->query_idx, B * ms * 4)); D.query_idx = b1.as<int32_t>();
+  FB_TRY(b2.upload(H->train_idx, B * ms * 4)); D.train_idx = b2.as<int32_t>();
+  FB_TRY(b3.upload(H->cam_xyz1, B * s1 * 12)); D.cam_xyz1 = b3.as<float>();
+  FB_TRY(b4.upload(H->cam_xyz2, B * s2 * 12)); D.cam_xyz2 = b4.as<float>();
+  FB_TRY(b5.upload(H->Tcw1, B * 48)); D.Tcw1 = b5.as<float>();
+  FB_TRY(b6.upload(H->Tcw2, B * 48)); D.Tcw2 = b6.as<float>();
+  FB_TRY(b7.upload(H->occupied2, B * s2)); D.occupied2 = b7.as<uint8_t>();
+  FB_TRY(o0.upload(H->keep, B * ms)); D.keep = o0.as<uint8_t>();
+  FB_TRY(o1.upload(H->pt_world, B * ms * 12)); D.pt_world = o1.as<float>();
+  FB_TRY(fb_bird_filter_matches_dev(&D, nullptr));
+  FB_HIP(hipDeviceSynchronize());
+  FB_TRY(o0.download(H->keep, B * ms));
+  return o1.download(H->pt_world, B * ms * 12);
 }
 
 int fb_undistort_keypoints_dev(const fb_keypoint *d_kps, const int32_t *d_n, int batch, int kp_stride, const float *K4,

@@ -539,6 +539,27 @@ typedef struct fb_frustum_args {
 int fb_in_frustum_dev(const fb_frustum_args *args, void *stream);
 int fb_in_frustum(const fb_frustum_args *args);
 
+/* --- the geometric test of Tracking::FilterBirdOutlierInFront (Tracking.cc:1825-1914) over the bird matches of a
+ *     frame pair: match i passes when |Tcw2 * (Twc1 * Xc1[query_i]) - Xc2[train_i]| < windowSize (:1868-1886) and its
+ *     train slot holds no MapPointBird yet -- on entry (occupied2) or through an earlier passing match (:1861-1863).
+ *     The MapPointBird bookkeeping (:1891-1903) stays with the caller, who walks `keep` in order.                  */
+typedef struct fb_bird_filter_args {
+  int32_t batch;
+  int32_t match_stride, kp1_stride, kp2_stride;
+  const int32_t *n_matches;       /* vDMatches12.size()                                              */
+  const int32_t *query_idx;       /* [batch][match_stride] DMatch::queryIdx (frame 1)                */
+  const int32_t *train_idx;       /* DMatch::trainIdx (frame 2)                                      */
+  const float *cam_xyz1;          /* [batch][kp1_stride][3] MatchedFrame1->mvKeysBirdCamXYZ          */
+  const float *cam_xyz2;          /* [batch][kp2_stride][3] MatchedFrame2->mvKeysBirdCamXYZ          */
+  const float *Tcw1, *Tcw2;       /* [batch][12]                                                     */
+  const uint8_t *occupied2;       /* [batch][kp2_stride] MatchedFrame2->mvpMapPointsBird[i] != NULL   */
+  float window_size;
+  uint8_t *keep;                  /* [batch][match_stride] 1 = pushed to newMatch                     */
+  float *pt_world;                /* [batch][match_stride][3] ptwC (position of a new MapPointBird)   */
+} fb_bird_filter_args;
+int fb_bird_filter_matches_dev(const fb_bird_filter_args *args, void *stream);
+int fb_bird_filter_matches(const fb_bird_filter_args *args);
+
 /* --- Frame::UndistortKeyPoints (Frame.cc:636-669): cv::fisheye::undistortPoints(pts, K, D, R=I, P=K) on
  *     every key point; D[0]==0 copies.  K4 = fx,fy,cx,cy, D4 = k1..k4 (host).  d_kps_un may alias d_kps. */
 int fb_undistort_keypoints_dev(const fb_keypoint *d_kps, const int32_t *d_n, int batch, int kp_stride,
