@@ -27,6 +27,7 @@ P_FRONT, P_BIRD = 2853088, 811960          # sum of pyramid pixels
 PX0 = {"front": 1280 * 720, "bird": 512 * 512}
 PX7 = {"front": 357 * 201, "bird": 143 * 143}
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
+FP64_MFMA_PEAK_TFLOPS = 78.6                # MI355X public spec, FP64 matrix (= FP64 vector); the local guide lists no f64 row
 
 
 def algorithmic_bytes_per_pair():
@@ -34,11 +35,12 @@ def algorithmic_bytes_per_pair():
     p = {"front": P_FRONT, "bird": P_BIRD}
     resize = sum((p[k] - PX7[k]) + (p[k] - PX0[k]) for k in p)       # read level l-1, write level l
     fast = sum(p.values())                                            # every level read once
-    describe = sum(p.values())                                        # every level read once for blur+BRIEF
+    blur = 2 * sum(p.values())                                        # every level read once, blurred level written once
+    describe = 2 * sum(p.values())                                    # raw level (orientation) + blurred level (BRIEF), once each
     match_front = 32 * 2000 + 32 * 2000 + 16 * 2000 + 8 * 2000        # 184,000 B per 2000x2000 problem
     match_bird = 32 * 2000 + 32 * 1000 + 16 * 2000 + 8 * 1000
     pose = 2000 * 24 + 1000 * 28                                      # edge inputs read once (LDS staged)
-    return {"k_resize": resize, "k_fast": fast, "k_describe": describe, "k_proj_frame": match_front,
+    return {"k_resize": resize, "k_fast": fast, "k_blur": blur, "k_describe": describe, "k_proj_frame": match_front,
             "k_bird_mappoints": match_bird, "k_pose_opt": pose}
 
 
@@ -86,6 +88,28 @@ def local_ba_leg(L, rank, world_size, local_rank, reps=3):
            "points, %d front + %d bird + %d odometry edges" % (len(p["obs_kf"]), len(p["bobs_kf"]), len(p["odom_kf_i"])),
            "mode": "sharded over %d ranks (landmark partition, all-reduce of S,b,chi2)" % world_size if world_size > 1 else "1 GPU",
            "includes": "host<->device copies and the host-driven LM loop"}
+    # MFMA utilisation of the Schur kernel (north_star: "MFMA utilisation for J^T J"): one more BA under the event
+    # profiler.  k_ba_schur multiplies dense LDS panels with v_mfma_f64_16x16x4_f64, upper-triangular 16x16 tiles only.
+    from fishbirdeyevisualslam_amd import cabi
+    a, out, keep = ba_problem.local_ba_args(p, with_odom=1)
+    L.fb_prof_reset()
+    L.fb_prof_enable(1)
+    rc = L.fb_local_ba_sharded(C.byref(a), rank, world_size, cb, None) if world_size > 1 else L.fb_local_ba(C.byref(a))
+    L.fb_prof_enable(0)
+    ents = (cabi.ProfEntry * 40)()
+    n = L.fb_prof_report(ents, 40)
+    kern = {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n)}
+    if rc == 0 and "k_ba_schur" in kern and kern["k_ba_schur"][1] > 0:
+        n_free = int((np.asarray(keep["kf_fixed"] if "kf_fixed" in keep else p["kf_fixed"]) == 0).sum())
+        nt = (6 * n_free + 1 + 15) // 16                       # 16x16 tiles per side of the reduced system (+ rhs column)
+        n_lm = (len(p["mp_xw"]) + len(p["mpb_xw"]) + world_size - 1) // world_size  # landmarks of this rank
+        launches, ms = kern["k_ba_schur"]
+        flop = 2.0 * (nt * (nt + 1) // 2) * 256 * 3 * n_lm      # MFMA flops issued per launch (upper tiles, K = 3 per landmark)
+        tf = flop * launches / (ms * 1e-3) / 1e12
+        res["mfma"] = {"kernel": "k_ba_schur", "dtype": "f64", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": tf / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": ms / launches, "launches_per_ba": launches,
+                       "flop_per_launch": flop, "free_keyframes": n_free, "tiles": nt,
+                       "kernels_ms_per_ba": {k: v[1] for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}}
     if rank == 0 and world_size == 1:
         from oracle import pyoracle as O
         a, out, keep = ba_problem.local_ba_args(p, with_odom=1)
@@ -207,6 +231,11 @@ def main():
                          "achieved_no_overlap": alg.get(dom, 0) * B * 3 / kern_serial[dom][0] / (kern_serial[dom][1] / kern_serial[dom][0] * 1e-3) / 1e9},
             "kernels_ms_per_step_no_overlap": {k: v[1] / 3 for k, v in sorted(kern_serial.items(), key=lambda kv: -kv[1][1])},
             "kernels_ms_per_step": {k: v[1] / a.steps for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
+            # north_star: "HBM GB/s for matching" -- algorithmic bytes / single-stream kernel time, every kernel with a
+            # SURVEY 8(d) byte count (fraction of the 8 TB/s roof)
+            "hbm_gbs_no_overlap": {k: {"gbs": alg[k] * B * 3 / (kern_serial[k][1] * 1e-3) / 1e9,
+                                       "frac": alg[k] * B * 3 / (kern_serial[k][1] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                   for k in alg if k in kern_serial and kern_serial[k][1] > 0},
             "kernel_ms_sum_over_wall": total_ms / (elapsed * 1e3),  # >1: the three streams overlap
             "workload_check": {"kps_front": float(res["n_front"].mean()), "kps_bird": float(res["n_bird"].mean()),
                                "front_matches": float(res["nm_front"].mean()), "bird_matches": float(res["nm_bird"].mean()),
