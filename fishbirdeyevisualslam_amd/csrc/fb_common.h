@@ -56,12 +56,13 @@ enum ProfId {
   P_PROJ_KF, P_BOW_KF, P_FRUSTUM, P_UNDISTORT, P_BLUR, P_FUSE, P_DISTINCT, P_COUNT
 };
 extern bool g_prof_on;
+extern int g_prof_only;  // -1 = every kernel, else only this ProfId is bracketed
 void prof_begin(int id, hipStream_t s);
 void prof_end(hipStream_t s);
 struct ProfScope {
   hipStream_t s;
   bool on;
-  ProfScope(int id, hipStream_t st) : s(st), on(g_prof_on) { if (on) prof_begin(id, s); }
+  ProfScope(int id, hipStream_t st) : s(st), on(g_prof_on && (g_prof_only < 0 || g_prof_only == id)) { if (on) prof_begin(id, s); }
   ~ProfScope() { if (on) prof_end(s); }
 };
 

@@ -1,6 +1,7 @@
 // runtime.hip -- error channel and device selection of the C-ABI (include/fishbird.h).
 #include "fb_common.h"
 
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -71,6 +72,7 @@ void pool_give(void *p, size_t granted) {
 }
 
 bool g_prof_on = false;
+int g_prof_only = -1;
 namespace {
 const char *kProfNames[P_COUNT] = {"k_resize", "k_fast", "k_octree", "k_describe", "k_grid_build", "k_bird_keys_to_cam",
                                    "k_descriptor_distance", "k_proj_frame", "k_proj_points", "k_bird_mappoints",
@@ -100,6 +102,15 @@ void prof_end(hipStream_t s) { (void)hipEventRecord(g_recs.back().b, s); }
 extern "C" {
 
 int fb_prof_enable(int on) { fb::g_prof_on = on != 0; return FB_OK; }
+
+int fb_prof_only(const char *kernel_name) {
+  fb::g_prof_only = -1;
+  if (!kernel_name || !*kernel_name) return FB_OK;
+  for (int i = 0; i < fb::P_COUNT; i++)
+    if (std::strcmp(fb::kProfNames[i], kernel_name) == 0) { fb::g_prof_only = i; return FB_OK; }
+  fb::set_error("fb_prof_only: unknown kernel '%s'", kernel_name);
+  return FB_ERR_ARG;
+}
 
 int fb_prof_reset(void) {
   for (auto &r : fb::g_recs) { fb::g_pool.push_back(r.a); fb::g_pool.push_back(r.b); }

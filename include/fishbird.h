@@ -54,6 +54,7 @@ typedef struct fb_prof_entry {
   double total_ms;
 } fb_prof_entry;
 int fb_prof_enable(int on);
+int fb_prof_only(const char *kernel_name); /* bracket only this kernel (e.g. "k_fast"); NULL or "" = every kernel */
 int fb_prof_reset(void);
 int fb_prof_report(fb_prof_entry *out, int cap); /* returns the number of entries written */
 
