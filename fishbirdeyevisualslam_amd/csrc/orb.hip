@@ -54,7 +54,6 @@ struct OrbK {
   long long pyrStride;   // bytes per image of levels >= 1
   long long blurStride;  // bytes per image of the blurred pyramid (all levels)
   int blurStrips[FB_MAX_LEVELS + 1];  // first k_blur strip of each level
-  int blurEdgeTasks[FB_MAX_LEVELS + 1];  // first k_blur_edges task (3 per row) of each level
   long long candStride;  // candidates per image
   int umax[16];
   LevelInfo L[FB_MAX_LEVELS];
@@ -689,8 +688,23 @@ __global__ __launch_bounds__(256) void k_blur(OrbK K, const uint8_t *__restrict_
   if (l == 0) { img = img0 + (long long)b * imgStride; pitch = pitch0; }
   else { img = pyr + (long long)b * K.pyrStride + L.off; pitch = L.pitch; }
   uint8_t *out = blur + (long long)b * K.blurStride + L.boff;
-  // column groups whose 12-byte window leaves the row (x0 == 0 and the last one or two groups) belong to k_blur_edges
-  if (x0 < 4 || x0 + 8 > w) return;
+  // Column groups whose 12-byte window leaves the row (x0 == 0 and the last one or two groups): the window is loaded
+  // from a clamped start instead and its bytes are rearranged with two v_perm per dword so that every out-of-row
+  // column holds its BORDER_REFLECT_101 partner (which always lies inside the same 12 bytes).
+  const bool edge = x0 < 4 || x0 + 8 > w;
+  const int base = edge ? max(min(x0 - 4, w - 12), 0) : x0 - 4;
+  uint32_t m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
+  if (edge) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      const int c = reflect101(min(x0 - 4 + i, w + 2), w);
+      const int sidx8 = min(max(c - base, 0), 11);
+      const uint32_t lo = sidx8 < 8 ? (uint32_t)sidx8 : 0x0cu, hi = sidx8 < 8 ? 0x0cu : (uint32_t)(sidx8 - 8);
+      m1[i >> 2] |= lo << (8 * (i & 3));
+      m2[i >> 2] |= hi << (8 * (i & 3));
+    }
+  }
+  const bool anyEdge = __ballot(edge) != 0ull;
   const uint32_t WA = 18u | (34u << 8) | (49u << 16) | (55u << 24), WB = 49u | (34u << 8) | (18u << 16);
   int ring[7][4];
 #pragma unroll
@@ -699,8 +713,14 @@ __global__ __launch_bounds__(256) void k_blur(OrbK K, const uint8_t *__restrict_
     if (r >= 6 && yo >= h) break;
     const int ys = reflect101(min(y0 + r - 3, h + 2), h);
     const uint8_t *row = img + (long long)ys * pitch;
-    const uint32_t *pw = reinterpret_cast<const uint32_t *>(row + x0 - 4);
-    const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+    const uint32_t *pw = reinterpret_cast<const uint32_t *>(row + base);
+    uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+    if (anyEdge) {
+      const uint32_t e0 = __builtin_amdgcn_perm(w1, w0, m1[0]) | __builtin_amdgcn_perm(w2, w2, m2[0]);
+      const uint32_t e1 = __builtin_amdgcn_perm(w1, w0, m1[1]) | __builtin_amdgcn_perm(w2, w2, m2[1]);
+      const uint32_t e2 = __builtin_amdgcn_perm(w1, w0, m1[2]) | __builtin_amdgcn_perm(w2, w2, m2[2]);
+      if (edge) { w0 = e0; w1 = e1; w2 = e2; }
+    }
     int *hr = ring[r % 7];
     // taps of pixel j are window bytes 1+j .. 7+j
     hr[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), WB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), WA, 0u, false), false);
@@ -719,50 +739,6 @@ __global__ __launch_bounds__(256) void k_blur(OrbK K, const uint8_t *__restrict_
       *reinterpret_cast<uint32_t *>(out + (long long)yo * L.pitch + x0) = packed;
     }
   }
-}
-
-// The column groups k_blur leaves out: per level row, group 0 (x0 = 0) and the groups with x0 + 8 > w (one or two).
-// One lane per (row, group), generic BORDER_REFLECT_101 byte path; ~0.3 % of the pixels.
-__global__ __launch_bounds__(256) void k_blur_edges(OrbK K, const uint8_t *__restrict__ img0, long long imgStride,
-                                                    int pitch0, const uint8_t *__restrict__ pyr,
-                                                    uint8_t *__restrict__ blur) {
-  const int b = blockIdx.y;
-  int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= K.blurEdgeTasks[K.nlevels]) return;
-  int l = 0;
-  while (t >= K.blurEdgeTasks[l + 1]) l++;
-  t -= K.blurEdgeTasks[l];
-  const LevelInfo &L = K.L[l];
-  const int w = L.w, h = L.h;
-  const int y = t / 3, g = t - y * 3;
-  const int xr = ((w - 8) & ~3) + 4;          // first group with x0 + 8 > w
-  const int x0 = g == 0 ? 0 : xr + 4 * (g - 1);
-  if (x0 >= w || (g > 0 && x0 < 4)) return;
-  const uint8_t *img;
-  int pitch;
-  if (l == 0) { img = img0 + (long long)b * imgStride; pitch = pitch0; }
-  else { img = pyr + (long long)b * K.pyrStride + L.off; pitch = L.pitch; }
-  int cx[10];
-#pragma unroll
-  for (int i = 0; i < 10; i++) cx[i] = reflect101(min(x0 - 3 + i, w + 2), w);
-  const int wt[7] = {18, 34, 49, 55, 49, 34, 18};
-  int acc[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int dy = 0; dy < 7; dy++) {
-    const uint8_t *row = img + (long long)reflect101(y + dy - 3, h) * pitch;
-    int px[10];
-#pragma unroll
-    for (int i = 0; i < 10; i++) px[i] = row[cx[i]];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int hsum = 18 * (px[k] + px[k + 6]) + 34 * (px[k + 1] + px[k + 5]) + 49 * (px[k + 2] + px[k + 4]) + 55 * px[k + 3];
-      acc[k] += wt[dy] * hsum;
-    }
-  }
-  uint8_t *out = blur + (long long)b * K.blurStride + L.boff + (long long)y * L.pitch + x0;
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (x0 + k < w) out[k] = (uint8_t)min((acc[k] + (1 << 15)) >> 16, 255);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -954,7 +930,7 @@ int prepare(fb_orb *o, int w, int h, int batch) {
   K.capOut = capacity_of(p);
   for (int i = 0; i < 16; i++) K.umax[i] = o->t.umax[i];
   long long pyrOff = 0, candOff = 0, blurOff = 0;
-  int cells = 0, outOff = 0, maxNodes = 0, strips = 0, edgeTasks = 0;
+  int cells = 0, outOff = 0, maxNodes = 0, strips = 0;
   std::vector<int> xofs, yofs;
   std::vector<short> ialpha, ibeta;
   std::vector<size_t> tabOff(p.nlevels * 4, 0);
@@ -979,8 +955,6 @@ int prepare(fb_orb *o, int w, int h, int batch) {
     L.boff = blurOff;
     blurOff += (long long)L.pitch * L.h;
     K.blurStrips[l] = strips;
-    K.blurEdgeTasks[l] = edgeTasks;
-    edgeTasks += 3 * L.h;
     strips += ((L.w + 255) / 256) * ((L.h + BLUR_ROWS - 1) / BLUR_ROWS);
     const int maxBX = L.w - BORDER, maxBY = L.h - BORDER;
     const float width = (float)(maxBX - BORDER), height = (float)(maxBY - BORDER);
@@ -1060,7 +1034,7 @@ int prepare(fb_orb *o, int w, int h, int batch) {
   }
   K.pyrStride = (pyrOff + 255) & ~255ll;
   K.blurStride = (blurOff + 255) & ~255ll;
-  for (int l = p.nlevels; l <= FB_MAX_LEVELS; l++) { K.blurStrips[l] = strips; K.blurEdgeTasks[l] = edgeTasks; }
+  for (int l = p.nlevels; l <= FB_MAX_LEVELS; l++) K.blurStrips[l] = strips;
   K.candStride = candOff;
   K.outStride = outOff;
   o->maxNodes = maxNodes;
@@ -1157,8 +1131,6 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
     fb::ProfScope prof_(fb::P_BLUR, s);
     k_blur<<<dim3((K.blurStrips[nl] + 3) / 4, batch), 256, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
                                                                     o->blur.as<uint8_t>());
-    k_blur_edges<<<dim3((K.blurEdgeTasks[nl] + 255) / 256, batch), 256, 0, s>>>(K, d_images, (long long)image_stride, stride,
-                                                                               o->pyr.as<uint8_t>(), o->blur.as<uint8_t>());
   }
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->octreeLds));
   {
