@@ -335,34 +335,54 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
   //      at minThFAST (needed only when the cell has to be redone at the lower threshold)
   int nlA = 0, nlB = 0;
   const int cap = K.fastMaxPix;
-  // Lanes map to (row-in-group, column): 32 columns x 2 rows per iteration for the usual <= 32 px wide cells, 64 x 1
-  // otherwise, so the LDS offset advances by a constant and no index division is needed.  The compass test for ANY
-  // threshold T is "strength > T" with strength = max(max over adjacent compass pairs of min(d_i, d_j),
-  // -(min over adjacent pairs of max(d_i, d_j))): two adjacent compass points brighter, or two darker, by more than T.
+  // Lanes map to (row-pair, column): 32 columns x 2 row pairs per iteration for the usual <= 32 px wide cells, 64 x 1
+  // otherwise, so the LDS offset advances by a constant and no index division is needed.  A lane tests TWO vertically
+  // adjacent pixels at once in packed 16-bit arithmetic (v_pk_sub/min/max_i16).  The compass test for ANY threshold T
+  // is "strength > T" with strength = max(max over adjacent compass pairs of min(d_i, d_j), -(min over adjacent pairs
+  // of max(d_i, d_j))): two adjacent compass points brighter, or two darker, by more than T.
   (void)npix; (void)inv_dwid;
-  const int G = dwid <= 32 ? 32 : 64, rpi = dwid <= 32 ? 2 : 1;
-  const int sxx = lane & (G - 1), sry = dwid <= 32 ? (lane >> 5) : 0;
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const int G = dwid <= 32 ? 32 : 64, ppi = dwid <= 32 ? 2 : 1;  // row pairs per iteration
+  const int sxx = lane & (G - 1), spr = dwid <= 32 ? (lane >> 5) : 0;
   const bool colok = sxx < dwid;
-  const int tp3 = 3 * tp, sstep = rpi * tp;
-  int off = (3 + sry) * tp + ox + 3 + sxx;
-  for (int y = 0; y < dhei; y += rpi, off += sstep) {
-    int strength = -1;
-    if (colok && y + sry < dhei) {
+  const int tp3 = 3 * tp, sstep = 2 * ppi * tp;
+  int off = (3 + 2 * spr) * tp + ox + 3 + sxx;  // upper pixel of the lane's pair
+  for (int y = 0; y < dhei; y += 2 * ppi, off += sstep) {
+    const int r0 = y + 2 * spr;
+    int s0 = -1, s1 = -1;
+    if (colok && r0 < dhei) {
+      // rows r0 and r0+1 (the lower one may lie below the cell: its reads stay inside the LDS tile + score tile and the
+      // result is discarded)
       const uint8_t *c = &tile[off];
-      const int v = c[0];
-      const int d0 = v - c[tp3], d4 = v - c[3], d8 = v - c[-tp3], d12 = v - c[-3];
-      const int hi = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));
-      const int lo = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));
-      strength = max(hi, -lo);
+      const s16x2 v = {(short)c[0], (short)c[tp]};
+      const s16x2 n0 = {(short)c[tp3], (short)c[tp3 + tp]}, n8 = {(short)c[-tp3], (short)c[-tp3 + tp]};
+      const s16x2 n4 = {(short)c[3], (short)c[tp + 3]}, n12 = {(short)c[-3], (short)c[tp - 3]};
+      const s16x2 d0 = v - n0, d4 = v - n4, d8 = v - n8, d12 = v - n12;
+#define PMIN(a, b) __builtin_elementwise_min(a, b)
+#define PMAX(a, b) __builtin_elementwise_max(a, b)
+      const s16x2 hi = PMAX(PMAX(PMIN(d0, d4), PMIN(d4, d8)), PMAX(PMIN(d8, d12), PMIN(d12, d0)));
+      const s16x2 lo = PMIN(PMIN(PMAX(d0, d4), PMAX(d4, d8)), PMIN(PMAX(d8, d12), PMAX(d12, d0)));
+      const s16x2 zero = {0, 0};
+      const s16x2 st = PMAX(hi, zero - lo);
+#undef PMIN
+#undef PMAX
+      s0 = st.x;
+      s1 = (r0 + 1 < dhei) ? (int)st.y : -1;
     }
-    const bool c9i = strength > K.iniTh, c9 = strength > K.minTh;
-    const unsigned long long mA = __ballot(c9i), mB = __ballot(c9 && !c9i);
-    if (c9i) s_list[nlA + __popcll(mA & lt)] = (unsigned short)off;
-    else if (c9) s_list[cap - 1 - (nlB + __popcll(mB & lt))] = (unsigned short)off;
-    nlA += __popcll(mA);
-    nlB += __popcll(mB);
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {
+      const int strength = h2 == 0 ? s0 : s1;
+      const int offp = off + h2 * tp;
+      const bool c9i = strength > K.iniTh, c9 = strength > K.minTh;
+      const unsigned long long mA = __ballot(c9i), mB = __ballot(c9 && !c9i);
+      if (c9i) s_list[nlA + __popcll(mA & lt)] = (unsigned short)offp;
+      else if (c9) s_list[cap - 1 - (nlB + __popcll(mB & lt))] = (unsigned short)offp;
+      nlA += __popcll(mA);
+      nlB += __popcll(mB);
+    }
   }
   __syncthreads();
+  if (K.dbg == 4) { if (nlA + nlB == 123456) cand[0] = 1; return; }
   for (int pass = 0; pass < 2; pass++) {
     const int T = pass == 0 ? K.iniTh : K.minTh;
     // ---- scores: pass 0 scores list A, pass 1 list B
