@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libfishbird_hip.so")
-SOURCES = ["runtime.hip", "match.hip", "match_bow.hip", "frame.hip", "orb.hip", "pose.hip", "ba.hip"]
+SOURCES = ["runtime.hip", "match.hip", "match_bow.hip", "frame.hip", "bow.hip", "orb.hip", "pose.hip", "ba.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fgpu-rdc=0" if False else "-Wall", "-Wno-unused-function"]
 

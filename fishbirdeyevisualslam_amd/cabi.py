@@ -178,6 +178,17 @@ class InitMatchArgs(C.Structure):
                 ("prev_matched", _vp), ("matches12", _vp), ("nmatches", _vp)]
 
 
+class Vocabulary(C.Structure):
+    _fields_ = [("n_nodes", _i32), ("L", _i32), ("child_start", _vp), ("children", _vp), ("descriptors", _vp),
+                ("weights", _vp), ("word_ids", _vp)]
+
+
+class BowTransformArgs(C.Structure):
+    _fields_ = [("batch", _i32), ("f_stride", _i32), ("n_f", _vp), ("desc", _vp), ("levelsup", _i32),
+                ("n_words", _vp), ("bow_ids", _vp), ("bow_vals", _vp), ("fv_n_nodes", _vp), ("fv_node_ids", _vp),
+                ("fv_node_start", _vp), ("fv_items", _vp)]
+
+
 class BirdFilterArgs(C.Structure):
     _fields_ = [("batch", _i32), ("match_stride", _i32), ("kp1_stride", _i32), ("kp2_stride", _i32),
                 ("n_matches", _vp), ("query_idx", _vp), ("train_idx", _vp), ("cam_xyz1", _vp), ("cam_xyz2", _vp),
@@ -249,7 +260,7 @@ EXPORTS = [
     "fb_match_projection_sim3_dev", "fb_match_projection_sim3", "fb_match_sim3_dev", "fb_match_sim3",
     "fb_match_initialization_dev", "fb_match_initialization",
     "fb_distinctive_descriptors_dev", "fb_distinctive_descriptors",
-    "fb_bird_filter_matches_dev", "fb_bird_filter_matches",
+    "fb_bird_filter_matches_dev", "fb_bird_filter_matches", "fb_bow_transform_dev", "fb_bow_transform",
     "fb_in_frustum_dev", "fb_in_frustum", "fb_undistort_keypoints_dev", "fb_undistort_keypoints", "fb_image_bounds",
     "fb_pose_opt_batch_dev", "fb_pose_opt", "fb_pose_gather_front_dev", "fb_pose_gather_bird_dev",
     "fb_local_ba", "fb_local_ba_sharded",

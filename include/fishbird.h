@@ -510,6 +510,44 @@ int fb_distinctive_descriptors_dev(const int32_t *d_obs_start, const uint8_t *d_
 int fb_distinctive_descriptors(const int32_t *obs_start, const uint8_t *obs_desc, int n_mp, int32_t *best_obs);
 
 /* ======================================================================== */
+/* DBoW2 vocabulary transform (Frame::ComputeBoW, src/Frame.cc:628-635)       */
+/* ======================================================================== */
+/* DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> as flat arrays
+ * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:297-329: Node{weight, children, descriptor, word_id}, m_L).
+ * The reference ships no vocabulary file; any tree (k, L) in this form works. */
+typedef struct fb_vocabulary {
+  int32_t n_nodes;
+  int32_t L;                    /* m_L, depth of the leaves                                          */
+  const int32_t *child_start;   /* [n_nodes+1] CSR over m_nodes[i].children                           */
+  const int32_t *children;      /* NodeIds in the children vector's order                            */
+  const uint8_t *descriptors;   /* [n_nodes][32]                                                      */
+  const double *weights;        /* [n_nodes] Node::weight (used at the leaves)                        */
+  const int32_t *word_ids;      /* [n_nodes] Node::word_id (used at the leaves)                       */
+} fb_vocabulary;
+
+/* transform(features, BowVector&, FeatureVector&, levelsup) for TF_IDF weighting + L1 scoring (ORBVocabulary),
+ * TemplatedVocabulary.h:1126-1194, per-feature descent :1217-1259, BowVector::addWeight / normalize(L1)
+ * (BowVector.cpp:30-84).  Outputs per image: the BowVector as (word id ascending, value) pairs and the FeatureVector
+ * in the CSR form the matchers take (fb_feature_vector).  All output arrays have f_stride entries per image
+ * (fv_node_start: f_stride + 1). */
+typedef struct fb_bow_transform_args {
+  int32_t batch;
+  int32_t f_stride;
+  const int32_t *n_f;           /* features per image (<= 4096)                                       */
+  const uint8_t *desc;          /* [batch][f_stride][32] mDescriptors                                 */
+  int32_t levelsup;             /* 4 at Frame.cc:633                                                  */
+  int32_t *n_words;             /* [batch] mBowVec.size()                                             */
+  uint32_t *bow_ids;            /* [batch][f_stride]                                                  */
+  double *bow_vals;             /* [batch][f_stride]                                                  */
+  int32_t *fv_n_nodes;          /* [batch] mFeatVec.size()                                            */
+  uint32_t *fv_node_ids;        /* [batch][f_stride]                                                  */
+  int32_t *fv_node_start;       /* [batch][f_stride + 1]                                              */
+  int32_t *fv_items;            /* [batch][f_stride]                                                  */
+} fb_bow_transform_args;
+int fb_bow_transform_dev(const fb_vocabulary *voc /* device arrays */, const fb_bow_transform_args *args, void *stream);
+int fb_bow_transform(const fb_vocabulary *voc, const fb_bow_transform_args *args); /* host pointers */
+
+/* ======================================================================== */
 /* Frame geometry either side of the matchers (src/Frame.cc)                 */
 /* ======================================================================== */
 /* --- Frame::isInFrustum(pMP, viewingCosLimit) over a list of map points (Frame.cc:435-491; the loop
