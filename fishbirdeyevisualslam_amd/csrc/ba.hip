@@ -747,19 +747,34 @@ __global__ void k_ba_export(int n_kf, int npt, const SE3 *pose, const double *pt
 
 #define BA_UP(buf, vec) FB_TRY(buf.upload((vec).data(), (vec).size() * sizeof((vec)[0])))
 
-static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allreduce_fn allreduce, void *ctx);
+// optimisation schedule: LocalBundleAdjustment[WithOdom] = optimize(5) robust, chi2 gate, optimize(10) plain
+// (Optimizer.cc:2504-2560); BundleAdjustmentWithOdom = ONE optimize(nIterations), robust iff bRobust, no gate (:2048-2050)
+struct BASchedule {
+  int its1, robust1;
+  bool gate;
+  int its2;
+  double delta;  // Huber delta: sqrt(5.991) local (:2290), sqrt(5.99) global (:1836)
+};
+static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allreduce_fn allreduce, void *ctx, const BASchedule &sc);
+static const BASchedule kLocalSchedule = {5, 1, true, 10, (double)(float)sqrt(5.991)};
 
-extern "C" int fb_local_ba(const fb_local_ba_args *A) { return local_ba_impl(A, 0, 1, nullptr, nullptr); }
+extern "C" int fb_local_ba(const fb_local_ba_args *A) { return local_ba_impl(A, 0, 1, nullptr, nullptr, kLocalSchedule); }
+
+extern "C" int fb_global_ba(const fb_local_ba_args *A, int n_iterations, int robust) {
+  FB_ARG(n_iterations >= 0);
+  const BASchedule sc = {n_iterations, robust ? 1 : 0, false, 0, (double)(float)sqrt(5.99)};
+  return local_ba_impl(A, 0, 1, nullptr, nullptr, sc);
+}
 
 extern "C" int fb_local_ba_sharded(const fb_local_ba_args *A, int rank, int world, fb_allreduce_fn allreduce, void *ctx) {
   FB_ARG(world >= 1 && rank >= 0 && rank < world && (world == 1 || allreduce));
-  return local_ba_impl(A, rank, world, allreduce, ctx);
+  return local_ba_impl(A, rank, world, allreduce, ctx, kLocalSchedule);
 }
 
 // Landmark-partitioned BA: rank r owns the landmarks l with l % world == r and all their edges, the
 // odometry edges live on rank 0, the keyframe state is replicated.  Per LM trial two small all-reduces: the
 // Schur-reduced system (after k_ba_schur) and [Hpp, bp, chi2, scale] (after the linearisation at the trial state).
-static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allreduce_fn allreduce, void *ctx) {
+static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allreduce_fn allreduce, void *ctx, const BASchedule &sc) {
   FB_TRY(fb::check_device());
   const bool sharded = world > 1;
   auto reduce = [&](double *buf, int n, int op) -> int {
@@ -848,7 +863,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
   FB_HIP(hipMemset(d_echi2.p, 0, (size_t)std::max(nE, 1) * 8));
   BADev D;
   D.n_kf = n_kf; D.np = np; D.npt = npt; D.nE = nE; D.nO = nO; D.quat = odom ? 1 : 0;
-  D.fx = A->fx; D.fy = A->fy; D.cx = A->cx; D.cy = A->cy; D.delta = (double)(float)sqrt(5.991);
+  D.fx = A->fx; D.fy = A->fy; D.cx = A->cx; D.cy = A->cy; D.delta = sc.delta;
   D.poseIdx = d_poseIdx.as<int>(); D.e_pt = d_ept.as<int>(); D.e_kf = d_ekf.as<int>(); D.e_type = d_etype.as<uint8_t>();
   D.e_meas = d_emeas.as<double>(); D.e_info = d_einfo.as<double>(); D.e_level = d_elevel.as<uint8_t>();
   D.e_chi2 = d_echi2.as<double>(); D.lm_start = d_lms.as<int>(); D.lm_edges = d_lme.as<int>(); D.ps_start = d_pss.as<int>();
@@ -991,11 +1006,11 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
     }
     return FB_OK;
   };
-  if (nE + nO > 0 && (np > 0 || npt > 0)) FB_TRY(optimize(5, 1));
-  const bool more = !(A->stop_flag && *A->stop_flag);
+  if (nE + nO > 0 && (np > 0 || npt > 0)) FB_TRY(optimize(sc.its1, sc.robust1));
+  const bool more = sc.gate && !(A->stop_flag && *A->stop_flag);
   if (more && nE > 0) {
     k_ba_gate<<<(nE + 255) / 256, 256, 0, s0>>>(D, st[cur], 1, nullptr);
-    if (nE + nO > 0) FB_TRY(optimize(10, 0));
+    if (nE + nO > 0) FB_TRY(optimize(sc.its2, 0));
   }
   fb::DevBuf d_flags, d_kfT, d_ptOut;
   FB_TRY(d_flags.alloc(std::max(nE, 1)));
@@ -1019,8 +1034,10 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
     for (size_t i = 0; i < (size_t)npt * 3; i++) po[i] = (float)ex[i];
     for (int e = 0; e < nE; e++) flags[e] = ex[(size_t)npt * 3 + e] != 0.0;
   }
-  for (int i = 0; i < nF; i++) A->obs_outlier[i] = flags[i];
-  for (int i = 0; i < nB; i++) A->bobs_outlier[i] = flags[nF + i];
+  if (sc.gate) {  // the global BA classifies nothing
+    for (int i = 0; i < nF; i++) A->obs_outlier[i] = flags[i];
+    for (int i = 0; i < nB; i++) A->bobs_outlier[i] = flags[nF + i];
+  }
   FB_TRY(d_kfT.download(A->kf_Tcw, (size_t)n_kf * 48));
   for (int i = 0; i < 3 * n_mp; i++) A->mp_xw[i] = po[i];
   for (int i = 0; i < 3 * A->n_mpb; i++) A->mpb_xw[i] = po[3 * n_mp + i];

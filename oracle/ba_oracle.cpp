@@ -370,11 +370,18 @@ struct BAProblem : LMProblem {
 
 }  // namespace
 
-extern "C" int orc_local_ba(const fb_local_ba_args *A) {
+// schedule: its1 < 0 selects LocalBundleAdjustment[WithOdom] (optimize(5) robust, gate, optimize(10)); otherwise
+// BundleAdjustmentWithOdom (Optimizer.cc:1786-2135): ONE optimize(its1), robust iff `robust`, delta sqrt(5.99), no gate
+static int ba_common(const fb_local_ba_args *A, int its1, int robust);
+extern "C" int orc_local_ba(const fb_local_ba_args *A) { return ba_common(A, -1, 1); }
+extern "C" int orc_global_ba(const fb_local_ba_args *A, int n_iterations, int robust) { return ba_common(A, n_iterations, robust); }
+
+static int ba_common(const fb_local_ba_args *A, int its1, int robust1) {
+  const bool global = its1 >= 0;
   BAProblem P;
   P.quat_edges = A->with_odom != 0;
   P.fx = A->fx; P.fy = A->fy; P.cx = A->cx; P.cy = A->cy;
-  P.delta = (float)std::sqrt(5.991);  // thHuberMono
+  P.delta = global ? (float)std::sqrt(5.99) : (float)std::sqrt(5.991);  // thHuber2D (:1836) / thHuberMono
   P.stop = A->stop_flag;
   P.pose.resize(A->n_kf);
   P.fixed.assign(A->kf_fixed, A->kf_fixed + A->n_kf);
@@ -410,9 +417,11 @@ extern "C" int orc_local_ba(const fb_local_ba_args *A) {
     P.edges.push_back(e);
   }
   if (A->stop_flag && *A->stop_flag) return FB_OK;  // Optimizer.cc:2498-2500
+  if (global && !robust1)
+    for (auto &e : P.edges) e.robust = false;
   P.initialize(0);
-  lm_optimize(P, 5);
-  const bool more = !(A->stop_flag && *A->stop_flag);
+  lm_optimize(P, global ? its1 : 5);
+  const bool more = !global && !(A->stop_flag && *A->stop_flag);
   if (more) {
     for (int i = 0; i < A->n_obs; i++) {
       BEdge &e = P.edges[i];
@@ -428,11 +437,13 @@ extern "C" int orc_local_ba(const fb_local_ba_args *A) {
     P.initialize(0);
     lm_optimize(P, 10);
   }
-  for (int i = 0; i < A->n_obs; i++) {
-    const BEdge &e = P.edges[i];
-    A->obs_outlier[i] = (BAProblem::chi2(e) > 5.991 || !P.depthPositive(e)) ? 1 : 0;
+  if (!global) {
+    for (int i = 0; i < A->n_obs; i++) {
+      const BEdge &e = P.edges[i];
+      A->obs_outlier[i] = (BAProblem::chi2(e) > 5.991 || !P.depthPositive(e)) ? 1 : 0;
+    }
+    for (int i = 0; i < nb; i++) A->bobs_outlier[i] = BAProblem::chi2(P.edges[A->n_obs + i]) > 5.991 ? 1 : 0;
   }
-  for (int i = 0; i < nb; i++) A->bobs_outlier[i] = BAProblem::chi2(P.edges[A->n_obs + i]) > 5.991 ? 1 : 0;
   for (int k = 0; k < A->n_kf; k++)
     if (!A->kf_fixed[k]) se3_to_float12(P.pose[k], A->kf_Tcw + 12 * k);  // local keyframes only; fixed ones unchanged
   for (int i = 0; i < 3 * A->n_mp; i++) A->mp_xw[i] = (float)P.pt[i];
