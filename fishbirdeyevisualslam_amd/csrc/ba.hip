@@ -747,6 +747,8 @@ __global__ void k_ba_export(int n_kf, int npt, const SE3 *pose, const double *pt
 
 #define BA_UP(buf, vec) FB_TRY(buf.upload((vec).data(), (vec).size() * sizeof((vec)[0])))
 
+#include "ba_big.inc"
+
 // optimisation schedule: LocalBundleAdjustment[WithOdom] = optimize(5) robust, chi2 gate, optimize(10) plain
 // (Optimizer.cc:2504-2560); BundleAdjustmentWithOdom = ONE optimize(nIterations), robust iff bRobust, no gate (:2048-2050)
 struct BASchedule {
@@ -794,7 +796,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
   int np = 0;
   for (int k = 0; k < n_kf; k++) if (!A->kf_fixed[k]) poseIdx[k] = np++;
   const int P6 = 6 * np;
-  if (P6 + 1 > 256) { fb::set_error("fb_local_ba: more than 42 free keyframes"); return FB_ERR_CAPACITY; }
+  if (P6 > 4096) { fb::set_error("fb_local_ba: more than 682 free keyframes"); return FB_ERR_CAPACITY; }
   std::vector<int> e_pt(nE), e_kf(nE);
   std::vector<uint8_t> e_type(nE), e_level(nE, 0);
   std::vector<double> e_meas((size_t)nE * 3, 0.0), e_info(nE);
@@ -882,18 +884,28 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
     lb[s].Hll = d_Hll[s].as<double>(); lb[s].bl = d_bl[s].as<double>(); lb[s].W = d_W[s].as<double>();
     lb[s].Hpp = d_Hpp[s].as<double>(); lb[s].bp = d_bp[s].as<double>(); lb[s].chiPart = d_chi[s].as<double>();
   }
-  fb::DevBuf d_Dinv, d_Spart, d_xp, d_ok, d_scale, d_scal;
-  FB_TRY(d_Dinv.alloc((size_t)npt * 9 * 8)); FB_TRY(d_Spart.alloc((size_t)nWg * rows * rows * 8));
+  const size_t schurLds = (size_t)2 * rows * KPAD * 8;
+  const size_t solveLds = ((size_t)P6 * (P6 + 1) + P6 + (size_t)P6 * 6 + 2) * 8;
+  // beyond ~23 free key frames the reduced system no longer fits LDS: HBM-resident path of ba_big.inc
+  const bool big = schurLds > 160 * 1024 || solveLds > 160 * 1024 || P6 + 1 > 256;
+  fb::DevBuf d_Dinv, d_Spart, d_xp, d_ok, d_scale, d_scal, d_bigS, d_bigM, d_bigU, d_bigR;
+  FB_TRY(d_Dinv.alloc((size_t)npt * 9 * 8)); FB_TRY(d_Spart.alloc(big ? 8 : (size_t)nWg * rows * rows * 8));
+  if (big) {
+    FB_TRY(d_bigS.alloc((size_t)P6 * P6 * 8 + (size_t)P6 * 8));  // S | r
+    FB_TRY(d_bigM.alloc((size_t)P6 * P6 * 8 + (size_t)P6 * 8));  // M | rhs
+    FB_TRY(d_bigU.alloc((size_t)P6 * BIG_NB * 8));
+  }
   FB_TRY(d_xp.alloc((size_t)std::max(P6, 1) * 8)); FB_TRY(d_ok.alloc(4)); FB_TRY(d_scale.alloc((size_t)nUpdBlocks * 8));
   FB_TRY(d_scal.alloc(4 * 8));
   FB_HIP(hipMemset(d_scal.p, 0, 4 * 8));
-  const size_t schurLds = (size_t)2 * rows * KPAD * 8;
-  const size_t solveLds = ((size_t)P6 * (P6 + 1) + P6 + (size_t)P6 * 6 + 2) * 8;
-  if (schurLds > 160 * 1024 || solveLds > 160 * 1024) { fb::set_error("fb_local_ba: %d free keyframes exceed the LDS-resident reduced system", np); return FB_ERR_CAPACITY; }
   // accumulator tiles per wave: NT<=8 -> 9, NT<=12 -> 20, NT<=16 -> 34
   auto schurKernel = NT <= 8 ? k_ba_schur<9> : (NT <= 12 ? k_ba_schur<20> : k_ba_schur<34>);
-  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(schurKernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
-  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
+  if (!big) {
+    FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(schurKernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
+    FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
+  } else {
+    FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_big_solve), hipFuncAttributeMaxDynamicSharedMemorySize, P6 * 8));
+  }
   const size_t odomLds = (size_t)std::max(nO, 1) * sizeof(OdomLin);
   if (odomLds > 150 * 1024) { fb::set_error("fb_local_ba: too many odometry edges"); return FB_ERR_CAPACITY; }
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_odom), hipFuncAttributeMaxDynamicSharedMemorySize, (int)odomLds));
@@ -960,6 +972,28 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
       int qmax = 0;
       do {
         const int tr = 1 - cur;
+        if (big) {
+          double *S = d_bigS.as<double>(), *rS = S + (size_t)P6 * P6, *M = d_bigM.as<double>(), *rhs = M + (size_t)P6 * P6;
+          { fb::ProfScope pr(fb::P_BA_SCHUR, s0);
+            FB_HIP(hipMemsetAsync(S, 0, (size_t)P6 * P6 * 8 + (size_t)P6 * 8, s0));
+            k_ba_schur_scatter<<<(npt + 15) / 16, 256, 0, s0>>>(D, lb[cur], lambda, d_Dinv.as<double>(), S, rS, P6); }
+          { fb::ProfScope pr(fb::P_BA_SOLVE, s0);
+            if (sharded) {  // exchange step 1: the Schur-reduced system and right-hand side
+              std::vector<double> ex((size_t)P6 * P6 + P6);
+              FB_HIP(hipMemcpy(ex.data(), S, ex.size() * 8, hipMemcpyDeviceToHost));
+              FB_TRY(reduce(ex.data(), (int)ex.size(), 0));
+              FB_HIP(hipMemcpy(S, ex.data(), ex.size() * 8, hipMemcpyHostToDevice));
+            }
+            const long long nel = (long long)P6 * P6;
+            k_big_assemble<<<(unsigned)((nel + 255) / 256), 256, 0, s0>>>(lb[cur], lambda, S, rS, M, rhs, P6, d_scal.as<double>() + 3);
+            for (int k0 = 0; k0 < P6; k0 += BIG_NB) {
+              const int kw = std::min(BIG_NB, P6 - k0);
+              k_big_panel<<<1, 256, 0, s0>>>(M, P6, k0, kw, d_bigU.as<double>(), d_scal.as<double>() + 3);
+              const int nbt = (P6 - k0 - kw + BIG_NB - 1) / BIG_NB;
+              if (nbt > 0) k_big_update<<<nbt * (nbt + 1) / 2, 256, 0, s0>>>(M, P6, k0, kw, d_bigU.as<double>());
+            }
+            k_big_solve<<<1, 256, (size_t)P6 * 8, s0>>>(M, rhs, P6, d_xp.as<double>()); }
+        } else {
         { fb::ProfScope pr(fb::P_BA_SCHUR, s0);
           schurKernel<<<nWg, SCHUR_THREADS, schurLds, s0>>>(D, lb[cur], lambda, d_Dinv.as<double>(), d_Spart.as<double>(), P6, NT, lmPerWg); }
         { fb::ProfScope pr(fb::P_BA_SOLVE, s0);
@@ -974,6 +1008,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
             FB_HIP(hipMemcpy(d_Spart.p, ex.data(), (size_t)nS * 8, hipMemcpyHostToDevice));
           }
           k_ba_solve<<<1, SOLVE_THREADS, solveLds, s0>>>(lb[cur], lambda, d_Spart.as<double>(), nParts, P6, NT, d_xp.as<double>(), d_scal.as<double>() + 3); }
+        }
         { fb::ProfScope pr(fb::P_BA_UPDATE, s0);
           k_ba_update<<<nUpdBlocks, LIN_THREADS, 0, s0>>>(D, lb[cur], st[cur], st[tr], d_Dinv.as<double>(), d_xp.as<double>(), lambda, d_scale.as<double>(), rank == 0 ? 1 : 0);
           k_ba_scalars<<<1, 256, 0, s0>>>(d_scale.as<double>(), nUpdBlocks, nullptr, 0, nullptr, 0, d_scal.as<double>() + 2, 0); }

@@ -701,7 +701,9 @@ int fb_local_ba(const fb_local_ba_args *args); /* host pointers */
  * description: with_odom = 1 (Quat edges), n_odom = 0 (the pose-graph block is commented out in the reference,
  * :2004-2037), kf_fixed[k] = (mnId == 0).  ONE optimize(nIterations) (:2048-2050), Huber delta sqrt(5.99) on every edge
  * iff bRobust (:1836,1891-1895,1980-1984), no chi2 classification: obs_outlier / bobs_outlier are not written.
- * Capacity: the Schur-reduced pose system is LDS resident, i.e. at most 23 free key frames (FB_ERR_CAPACITY beyond).  */
+ * Capacity (local and global BA alike): up to 23 free key frames the Schur-reduced pose system is LDS resident
+ * (MFMA Schur kernel + one-workgroup LDL^T); beyond that it lives in HBM (block scatter + blocked multi-kernel LDL^T),
+ * up to 682 free key frames.                                                                                        */
 int fb_global_ba(const fb_local_ba_args *args, int n_iterations, int robust);
 
 /* One local BA over `world` GPUs (one process per GPU), SURVEY 8(e): rank r owns the landmarks l with
