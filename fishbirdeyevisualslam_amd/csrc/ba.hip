@@ -304,9 +304,10 @@ __global__ __launch_bounds__(POSE_THREADS) void k_ba_pose(BADev D, State S, LinB
 // ------------------------------------------------------------------------------------------
 struct OdomLin { double A[36], Bm[36], err[6]; };
 
-__global__ __launch_bounds__(256) void k_ba_odom(BADev D, State S, LinBuf B, int P6, int chiSlot) {
+template <bool GLOBAL>  // GLOBAL: the per-edge linearisations live in HBM scratch (they do not fit LDS)
+__global__ __launch_bounds__(256) void k_ba_odom(BADev D, State S, LinBuf B, int P6, int chiSlot, OdomLin *olGlobal) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  OdomLin *ol = reinterpret_cast<OdomLin *>(smem);
+  OdomLin *ol = GLOBAL ? olGlobal : reinterpret_cast<OdomLin *>(smem);
   __shared__ double s_chi[256];
   const int tid = threadIdx.x;
   double chi = 0;
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(256) void k_ba_odom(BADev D, State S, LinBuf B, int
     for (int i = 0; i < 6; i++) { ol[e].err[i] = er[i]; if (act) chi += er[i] * (info * er[i]); }
   }
   s_chi[tid] = chi;
+  if (GLOBAL) __threadfence_block();
   __syncthreads();
   if (tid == 0) {
     double s = 0;
@@ -890,10 +892,46 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
   const bool big = schurLds > 160 * 1024 || solveLds > 160 * 1024 || P6 + 1 > 256;
   fb::DevBuf d_Dinv, d_Spart, d_xp, d_ok, d_scale, d_scal, d_bigS, d_bigM, d_bigU, d_bigR;
   FB_TRY(d_Dinv.alloc((size_t)npt * 9 * 8)); FB_TRY(d_Spart.alloc(big ? 8 : (size_t)nWg * rows * rows * 8));
+  fb::DevBuf d_blkStart, d_blkPr, d_blkPc, d_entEr, d_entEc;
+  BigLists lists{};
   if (big) {
     FB_TRY(d_bigS.alloc((size_t)P6 * P6 * 8 + (size_t)P6 * 8));  // S | r
     FB_TRY(d_bigM.alloc((size_t)P6 * P6 * 8 + (size_t)P6 * 8));  // M | rhs
     FB_TRY(d_bigU.alloc((size_t)P6 * BIG_NB * 8));
+    // (row key frame <= column key frame) -> the edge pairs of the landmarks both observe; counting sort by block
+    std::vector<int> cnt((size_t)np * np + 1, 0);
+    auto for_pairs = [&](auto &&f) {
+      for (int l = 0; l < npt; l++)
+        for (int a = lm_start[l]; a < lm_start[l + 1]; a++) {
+          const int pa = poseIdx[e_kf[lm_edges[a]]];
+          if (pa < 0) continue;
+          for (int b2 = a; b2 < lm_start[l + 1]; b2++) {
+            const int pb = poseIdx[e_kf[lm_edges[b2]]];
+            if (pb < 0) continue;
+            if (pa <= pb) f(pa, pb, lm_edges[a], lm_edges[b2]);
+            else f(pb, pa, lm_edges[b2], lm_edges[a]);
+          }
+        }
+    };
+    for_pairs([&](int pr, int pc, int, int) { cnt[(size_t)pr * np + pc + 1]++; });
+    std::vector<int> blkStart(1, 0), blkPr, blkPc, slot((size_t)np * np, -1);
+    for (size_t key = 0; key < (size_t)np * np; key++)
+      if (cnt[key + 1] > 0) {
+        slot[key] = (int)blkPr.size();
+        blkPr.push_back((int)(key / np));
+        blkPc.push_back((int)(key % np));
+        blkStart.push_back(blkStart.back() + cnt[key + 1]);
+      }
+    std::vector<int> fillp(blkStart.begin(), blkStart.end() - 1), entEr(blkStart.back()), entEc(blkStart.back());
+    for_pairs([&](int pr, int pc, int er, int ec) {
+      const int q = fillp[slot[(size_t)pr * np + pc]]++;
+      entEr[q] = er;
+      entEc[q] = ec;
+    });
+    BA_UP(d_blkStart, blkStart); BA_UP(d_blkPr, blkPr); BA_UP(d_blkPc, blkPc); BA_UP(d_entEr, entEr); BA_UP(d_entEc, entEc);
+    lists.nBlocks = (int)blkPr.size();
+    lists.blk_start = d_blkStart.as<int>(); lists.blk_pr = d_blkPr.as<int>(); lists.blk_pc = d_blkPc.as<int>();
+    lists.ent_er = d_entEr.as<int>(); lists.ent_ec = d_entEc.as<int>();
   }
   FB_TRY(d_xp.alloc((size_t)std::max(P6, 1) * 8)); FB_TRY(d_ok.alloc(4)); FB_TRY(d_scale.alloc((size_t)nUpdBlocks * 8));
   FB_TRY(d_scal.alloc(4 * 8));
@@ -906,9 +944,16 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
   } else {
     FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_big_solve), hipFuncAttributeMaxDynamicSharedMemorySize, P6 * 8));
   }
-  const size_t odomLds = (size_t)std::max(nO, 1) * sizeof(OdomLin);
-  if (odomLds > 150 * 1024) { fb::set_error("fb_local_ba: too many odometry edges"); return FB_ERR_CAPACITY; }
-  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_odom), hipFuncAttributeMaxDynamicSharedMemorySize, (int)odomLds));
+  size_t odomLds = (size_t)std::max(nO, 1) * sizeof(OdomLin);
+  fb::DevBuf d_ol;
+  OdomLin *olGlobal = nullptr;
+  if (odomLds > 150 * 1024) {  // long odometry chains: per-edge linearisations in HBM
+    FB_TRY(d_ol.alloc(odomLds));
+    olGlobal = d_ol.as<OdomLin>();
+    odomLds = 0;
+  } else {
+    FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_odom<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)odomLds));
+  }
   hipStream_t s0 = nullptr;
 
   double lastScale = 0;  // sum x (lambda x + b) of the most recent k_ba_update (all ranks)
@@ -919,7 +964,8 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
     { fb::ProfScope pr(fb::P_BA_LINEARIZE, s0);
       if (nLinBlocks > 0) k_ba_linearize<<<nLinBlocks, LIN_THREADS, 0, s0>>>(D, st[si], lb[bi], robust);
       if (np > 0) k_ba_pose<<<np, POSE_THREADS, 0, s0>>>(D, st[si], lb[bi], robust, P6);
-      k_ba_odom<<<1, 256, odomLds, s0>>>(D, st[si], lb[bi], P6, nLinBlocks); }
+      if (olGlobal) k_ba_odom<true><<<1, 256, 0, s0>>>(D, st[si], lb[bi], P6, nLinBlocks, olGlobal);
+      else k_ba_odom<false><<<1, 256, odomLds, s0>>>(D, st[si], lb[bi], P6, nLinBlocks, nullptr); }
     { fb::ProfScope pr(fb::P_BA_MISC, s0);
       k_ba_scalars<<<1, 256, 0, s0>>>(lb[bi].chiPart, nLinBlocks + 1, lb[bi].Hpp, P6, lb[bi].Hll, npt, d_scal.as<double>(), wantDiag ? 1 : 0); }
     double h[4];
@@ -975,8 +1021,10 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
         if (big) {
           double *S = d_bigS.as<double>(), *rS = S + (size_t)P6 * P6, *M = d_bigM.as<double>(), *rhs = M + (size_t)P6 * P6;
           { fb::ProfScope pr(fb::P_BA_SCHUR, s0);
-            FB_HIP(hipMemsetAsync(S, 0, (size_t)P6 * P6 * 8 + (size_t)P6 * 8, s0));
-            k_ba_schur_scatter<<<(npt + 15) / 16, 256, 0, s0>>>(D, lb[cur], lambda, d_Dinv.as<double>(), S, rS, P6); }
+            FB_HIP(hipMemsetAsync(S, 0, (size_t)P6 * P6 * 8 + (size_t)P6 * 8, s0));  // blocks without a shared landmark stay 0
+            if (npt > 0) k_ba_dinv<<<(npt + 255) / 256, 256, 0, s0>>>(D, lb[cur], lambda, d_Dinv.as<double>());
+            if (lists.nBlocks > 0) k_ba_schur_gather<<<(lists.nBlocks + 3) / 4, 256, 0, s0>>>(D, lb[cur], d_Dinv.as<double>(), lists, S, P6);
+            if (np > 0) k_ba_rhs_gather<<<(np + 3) / 4, 256, 0, s0>>>(D, lb[cur], d_Dinv.as<double>(), rS); }
           { fb::ProfScope pr(fb::P_BA_SOLVE, s0);
             if (sharded) {  // exchange step 1: the Schur-reduced system and right-hand side
               std::vector<double> ex((size_t)P6 * P6 + P6);
