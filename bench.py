@@ -215,6 +215,18 @@ def main():
 
     if rank == 0:
         total_ms = sum(v[1] for v in kern_all.values()) / PROBE * a.steps
+        # HBM traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside this process; the
+        # committed profiles/r01_pmc_traffic.json holds the per-launch means of separate PMC passes over this same
+        # workload (profiles/probes/make_summary.py), used only when the batch size matches
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pt = json.load(f)
+            kk = "k_resize_rows" if dom == "k_resize" else dom
+            if pt.get("batch") == B and kk in pt["kernels"]:
+                traffic = pt["kernels"][kk]["fetch_bytes_per_launch"] + pt["kernels"][kk]["write_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         alg = algorithmic_bytes_per_pair()
         launches, ms = kern[dom]
         per_launch_ms = ms / launches
@@ -237,7 +249,8 @@ def main():
                                    "PoseOptimizationWithBird (~2k front + ~1k bird edges)",
                        "frame_pairs_per_step_per_gpu": B, "nfeatures": 2000, "parallelism": "replicas x%d" % world_size},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, raw, mean per launch)" if traffic else None,
                          "avg_launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": alg_per_launch,
                          "note": "dominant kernel chosen in an untimed probe pass with every kernel bracketed; in the timed region (3 "
                                  "concurrent streams) only this kernel carries events; *_no_overlap = same kernel in single-stream steps",

@@ -782,7 +782,9 @@ __global__ __launch_bounds__(64) void k_describe(OrbK K, const uint8_t *__restri
   __shared__ __attribute__((aligned(16))) uint32_t rawp[DP_RAW_ROWS * DP_RAW_DW];
   __shared__ __attribute__((aligned(16))) uint32_t blp[DP_BL_ROWS * DP_BL_DW];
   const int b = blockIdx.y, lane = threadIdx.x;
-  const int idx = blockIdx.x;
+  // XCD-aware mapping (as in k_fast): consecutive workgroups go to different XCDs; give each XCD a contiguous run of
+  // key points (neighbours in the quadtree order overlap in the image) so that their patches share lines in one L2
+  const int idx = (int)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (int)(blockIdx.x >> 3);
   const int *cnts = lvlCount + b * K.nlevels;
   int total = 0, myl = -1, myidx = 0;
   for (int l = 0; l < K.nlevels; l++) {
@@ -1160,7 +1162,7 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
   }
   {
   fb::ProfScope prof_(fb::P_DESCRIBE, s);
-  k_describe<<<dim3(K.capOut, batch), 64, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
+  k_describe<<<dim3((K.capOut + 7) / 8 * 8, batch), 64, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
                                                    o->blur.as<uint8_t>(), o->lvlOut.as<uint32_t>(), lvlCount, d_keypoints,
                                                    d_descriptors, d_n);
   }
