@@ -56,6 +56,7 @@ struct BADev {  // device pointers + sizes, passed by value
   const int *o_i, *o_j;        // [nO]
   const SE3 *o_Zinv;           // [nO]
   const double *o_info;        // [nO]
+  const int *od_start, *od_edges;  // CSR by free pose: incident odometry edges, ascending edge index
 };
 
 struct LinBuf {  // linearisation at one state
@@ -358,9 +359,9 @@ __global__ __launch_bounds__(256) void k_ba_odom(BADev D, State S, LinBuf B, int
   // phase b: lane (k, i) = row i of free pose k
   for (int row = tid; row < P6; row += 256) {
     const int k = row / 6, i = row % 6;
-    for (int e = 0; e < D.nO; e++) {
+    for (int cc = D.od_start[k]; cc < D.od_start[k + 1]; cc++) {  // incident edges only, in edge order
+      const int e = D.od_edges[cc];
       const int pi = D.poseIdx[D.o_i[e]], pj = D.poseIdx[D.o_j[e]];
-      if (pi != k && pj != k) continue;
       const double info = D.o_info[e];
       const OdomLin &o = ol[e];
       // this row belongs to vertex i (Jacobian A) or vertex j (Jacobian Bm)
@@ -862,6 +863,19 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
   BA_UP(d_poseIdx, poseIdx); BA_UP(d_ept, e_pt); BA_UP(d_ekf, e_kf); BA_UP(d_etype, e_type); BA_UP(d_emeas, e_meas);
   BA_UP(d_einfo, e_info); BA_UP(d_elevel, e_level); BA_UP(d_lms, lm_start); BA_UP(d_lme, lm_edges); BA_UP(d_pss, ps_start);
   BA_UP(d_pse, ps_edges); BA_UP(d_oi, o_i); BA_UP(d_oj, o_j); BA_UP(d_oz, oZinv); BA_UP(d_oinfo, o_info);
+  std::vector<int> od_start(np + 1, 0), od_edges;
+  {
+    std::vector<std::vector<int>> inc(np);
+    for (int e = 0; e < nO; e++) {
+      const int pi = poseIdx[o_i[e]], pj = poseIdx[o_j[e]];
+      if (pi >= 0) inc[pi].push_back(e);
+      if (pj >= 0 && pj != pi) inc[pj].push_back(e);
+    }
+    for (int k = 0; k < np; k++) { od_start[k + 1] = od_start[k] + (int)inc[k].size(); od_edges.insert(od_edges.end(), inc[k].begin(), inc[k].end()); }
+    if (od_edges.empty()) od_edges.push_back(0);
+  }
+  fb::DevBuf d_ods, d_ode;
+  BA_UP(d_ods, od_start); BA_UP(d_ode, od_edges);
   FB_TRY(d_fixed.upload(A->kf_fixed, n_kf));
   FB_TRY(d_echi2.alloc((size_t)std::max(nE, 1) * 8));
   FB_HIP(hipMemset(d_echi2.p, 0, (size_t)std::max(nE, 1) * 8));
@@ -873,6 +887,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
   D.e_chi2 = d_echi2.as<double>(); D.lm_start = d_lms.as<int>(); D.lm_edges = d_lme.as<int>(); D.ps_start = d_pss.as<int>();
   D.ps_edges = d_pse.as<int>(); D.o_i = d_oi.as<int>(); D.o_j = d_oj.as<int>(); D.o_Zinv = d_oz.as<SE3>();
   D.o_info = d_oinfo.as<double>();
+  D.od_start = d_ods.as<int>(); D.od_edges = d_ode.as<int>();
   fb::DevBuf d_pose[2], d_pt[2], d_Hll[2], d_bl[2], d_W[2], d_Hpp[2], d_bp[2], d_chi[2];
   State st[2];
   LinBuf lb[2];
