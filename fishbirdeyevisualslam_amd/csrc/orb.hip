@@ -775,11 +775,11 @@ constexpr int DP_BL_DW = 10, DP_BL_ROWS = 37;     // 37 rows x 40 B  (x-18 .. x+
 
 __global__ __launch_bounds__(64) void k_describe(OrbK K, const uint8_t *__restrict__ img0, long long imgStride,
                                                  int pitch0, const uint8_t *__restrict__ pyr,
-                                                 const uint8_t *__restrict__ blur,
+                                                 const uint8_t *__restrict__ blur, const uint4 *__restrict__ angTab,
                                                  const uint32_t *__restrict__ lvlOut, const int *__restrict__ lvlCount,
                                                  fb_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                  int32_t *__restrict__ nOut) {
-  __shared__ __attribute__((aligned(16))) uint32_t rawp[DP_RAW_ROWS * DP_RAW_DW];
+  __shared__ __attribute__((aligned(16))) uint32_t rawp[DP_RAW_ROWS * DP_RAW_DW + 4];
   __shared__ __attribute__((aligned(16))) uint32_t blp[DP_BL_ROWS * DP_BL_DW];
   const int b = blockIdx.y, lane = threadIdx.x;
   // XCD-aware mapping (as in k_fast): consecutive workgroups go to different XCDs; give each XCD a contiguous run of
@@ -802,22 +802,34 @@ __global__ __launch_bounds__(64) void k_describe(OrbK K, const uint8_t *__restri
   if (myl == 0) { img = img0 + (long long)b * imgStride; pitch = pitch0; }
   else { img = pyr + (long long)b * K.pyrStride + Lv.off; pitch = Lv.pitch; }
   // stage both patches (key points sit >= 19 px inside the level, so neither patch leaves the image)
+  // fixed lane -> (row within a group, dword) mapping: 6 rows x 10 dwords (7 x 9 for the raw patch) per pass, so the
+  // global address and the LDS index advance by constants (no per-element division)
   const int bxa = (cx - 18) & ~3, box = (cx - 18) - bxa;
   {
-    const uint8_t *base = blur + (long long)b * K.blurStride + Lv.boff + (long long)(cy - 18) * Lv.pitch + bxa;
-    for (int i = lane; i < DP_BL_ROWS * DP_BL_DW; i += 64) {
-      const int yy = i / DP_BL_DW, xw = i - yy * DP_BL_DW;
-      blp[i] = *reinterpret_cast<const uint32_t *>(base + (long long)yy * Lv.pitch + xw * 4);
+    const int r0 = lane / DP_BL_DW, dwc = lane - r0 * DP_BL_DW;
+    const uint8_t *src = blur + (long long)b * K.blurStride + Lv.boff + (long long)(cy - 18 + r0) * Lv.pitch + bxa + dwc * 4;
+    const long long stepB = 6ll * Lv.pitch;
+    if (lane < 6 * DP_BL_DW) {
+#pragma unroll
+      for (int it = 0; it < (DP_BL_ROWS + 5) / 6; it++) {
+        if (it * 6 + r0 < DP_BL_ROWS) blp[it * 6 * DP_BL_DW + lane] = *reinterpret_cast<const uint32_t *>(src);
+        src += stepB;
+      }
     }
   }
   int rox;
   if (((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch) & 3) == 0) {
     const int rxa = (cx - 15) & ~3;
     rox = (cx - 15) - rxa;
-    const uint8_t *base = img + (long long)(cy - 15) * pitch + rxa;
-    for (int i = lane; i < DP_RAW_ROWS * DP_RAW_DW; i += 64) {
-      const int yy = i / DP_RAW_DW, xw = i - yy * DP_RAW_DW;
-      rawp[i] = *reinterpret_cast<const uint32_t *>(base + (long long)yy * pitch + xw * 4);
+    const int r0 = lane / DP_RAW_DW, dwc = lane - r0 * DP_RAW_DW;
+    const uint8_t *src = img + (long long)(cy - 15 + r0) * pitch + rxa + dwc * 4;
+    const long long stepR = 7ll * pitch;
+    if (lane < 7 * DP_RAW_DW) {
+#pragma unroll
+      for (int it = 0; it < (DP_RAW_ROWS + 6) / 7; it++) {
+        if (it * 7 + r0 < DP_RAW_ROWS) rawp[it * 7 * DP_RAW_DW + lane] = *reinterpret_cast<const uint32_t *>(src);
+        src += stepR;
+      }
     }
   } else {  // caller's level-0 image with an odd stride: byte loads
     rox = 0;
@@ -830,14 +842,22 @@ __global__ __launch_bounds__(64) void k_describe(OrbK K, const uint8_t *__restri
   __syncthreads();
   // IC_Angle (ORBextractor.cc:77-104): lanes 2*(v+15) and 2*(v+15)+1 sum the left (u < 0) and right (u >= 0) part
   // of row v of the circular patch
+  // Each half row is 16 bytes read as dwords; |u| weights and the circular mask (|u| <= umax[|v|]) come from a per-lane
+  // table (angTab[lane] = 4 weight dwords + 4 mask dwords) and the sums are v_dot4_u32_u8.
   int m10 = 0, m01 = 0;
   if (lane < 62) {
-    const int v = (lane >> 1) - 15, dmax = K.umax[v < 0 ? -v : v];
-    const uint8_t *row = reinterpret_cast<const uint8_t *>(rawp) + (15 + v) * (DP_RAW_DW * 4) + rox + 15;
-    int rs = 0;
-    if (lane & 1) { for (int u = 0; u <= dmax; u++) { const int val = row[u]; m10 += u * val; rs += val; } }
-    else { for (int u = -dmax; u < 0; u++) { const int val = row[u]; m10 += u * val; rs += val; } }
-    m01 = v * rs;
+    const int r = lane >> 1, half = lane & 1;
+    const int sb = rox + (half ? 15 : 0);  // left half: u = -15..0 at bytes rox..rox+15, right half: u = 0..15 at rox+15..
+    const uint32_t *rowd = rawp + r * DP_RAW_DW + (sb >> 2);
+    const uint32_t sh = (uint32_t)(sb & 3);
+    const uint32_t d0 = rowd[0], d1 = rowd[1], d2 = rowd[2], d3 = rowd[3], d4 = rowd[4];
+    const uint32_t q0 = __builtin_amdgcn_alignbyte(d1, d0, sh), q1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    const uint32_t q2 = __builtin_amdgcn_alignbyte(d3, d2, sh), q3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    const uint4 W = angTab[lane * 2], Km = angTab[lane * 2 + 1];
+    const uint32_t a10 = __builtin_amdgcn_udot4(q0, W.x, __builtin_amdgcn_udot4(q1, W.y, __builtin_amdgcn_udot4(q2, W.z, __builtin_amdgcn_udot4(q3, W.w, 0u, false), false), false), false);
+    const uint32_t rs = __builtin_amdgcn_udot4(q0, Km.x, __builtin_amdgcn_udot4(q1, Km.y, __builtin_amdgcn_udot4(q2, Km.z, __builtin_amdgcn_udot4(q3, Km.w, 0u, false), false), false), false);
+    m10 = half ? (int)a10 : -(int)a10;
+    m01 = (r - 15) * (int)rs;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
@@ -890,7 +910,7 @@ struct fb_orb {
   OrbK K;
   int maxNodes = 0;
   size_t octreeLds = 0;
-  fb::DevBuf pyr, blur, cand, nodeOf, counts, lvlOut, tabs;
+  fb::DevBuf pyr, blur, cand, nodeOf, counts, lvlOut, tabs, angTab;
   ResizeTabs rt[FB_MAX_LEVELS];
   bool rowsOK[FB_MAX_LEVELS] = {};  // k_resize_rows' 12-byte window covers every 4-pixel group of the level
   // last call (for fb_orb_get_level)
@@ -1075,6 +1095,21 @@ int prepare(fb_orb *o, int w, int h, int batch) {
     o->rt[l].ibeta = reinterpret_cast<const short *>(base + tabOff[l * 4 + 3]);
   }
   const size_t B = batch;
+  {  // IC_Angle tables of k_describe: lane 2r+half owns half of patch row v = r-15; per byte j of its 16-byte span the
+     // weight |u| and the inclusion mask |u| <= umax[|v|] (left half: u = j-15, u = 0 belongs to the right half)
+    std::vector<uint32_t> tab(64 * 8, 0);
+    for (int lane = 0; lane < 62; lane++) {
+      const int v = (lane >> 1) - 15, half = lane & 1, dmax = K.umax[v < 0 ? -v : v];
+      for (int j = 0; j < 16; j++) {
+        const int au = half ? j : 15 - j;
+        const bool inc = au <= dmax && (half || au != 0);
+        if (!inc) continue;
+        tab[lane * 8 + (j >> 2)] |= (uint32_t)au << (8 * (j & 3));
+        tab[lane * 8 + 4 + (j >> 2)] |= 1u << (8 * (j & 3));
+      }
+    }
+    FB_TRY(o->angTab.upload(tab.data(), tab.size() * 4));
+  }
   FB_TRY(o->pyr.alloc(B * K.pyrStride + 256));
   FB_TRY(o->blur.alloc(B * K.blurStride + 256));
   FB_TRY(o->cand.alloc(B * K.candStride * 4 + 16));
@@ -1163,7 +1198,7 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
   {
   fb::ProfScope prof_(fb::P_DESCRIBE, s);
   k_describe<<<dim3((K.capOut + 7) / 8 * 8, batch), 64, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
-                                                   o->blur.as<uint8_t>(), o->lvlOut.as<uint32_t>(), lvlCount, d_keypoints,
+                                                   o->blur.as<uint8_t>(), o->angTab.as<uint4>(), o->lvlOut.as<uint32_t>(), lvlCount, d_keypoints,
                                                    d_descriptors, d_n);
   }
   FB_HIP(hipGetLastError());
