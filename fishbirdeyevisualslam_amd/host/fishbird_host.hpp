@@ -31,6 +31,15 @@ struct MapPointRef {            // what the path needs from a MapPoint / MapPoin
   uint8_t descriptor[32] = {0}; // GetDescriptor()
 };
 
+struct LocalMapPoint {          // a MapPoint of the local map: what isInFrustum reads and the track members it writes
+  MapPointRef ref;
+  float normal[3] = {0, 0, 0};  // GetNormal()
+  float mfMaxDistance = 0, mfMinDistance = 0;
+  bool mbTrackInView = false;   // MapPoint.h track members (written by Frame::isInFrustum)
+  float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackViewCos = 0;
+  int mnTrackScaleLevel = 0;
+};
+
 struct Frame {
   // intrinsics and static grid data (Frame.h statics)
   float fx = 0, fy = 0, cx = 0, cy = 0;
@@ -77,6 +86,47 @@ struct Frame {
   void AssignFeaturesToGrid() {
     assignToGrid(mvKeysUn, frontGrid(), gridStart, gridItems);
     if (birdviewCols > 0) assignToGrid(mvKeysBird, birdGrid(), gridBirdStart, gridBirdItems);
+  }
+
+  // Frame::isInFrustum(pMP, viewingCosLimit) (Frame.cc:435-491) over the whole local map in one call, the loop of
+  // Tracking::SearchLocalPoints (Tracking.cc:1071-1091).  Writes the track members of every point; returns how many
+  // are in view.  mOw = -Rcw^T tcw as Frame::UpdatePoseMatrices computes it (float Mat product, double accumulation).
+  int isInFrustum(std::vector<LocalMapPoint> &points, float viewingCosLimit, float mbf = 0.f) const {
+    const int32_t n = (int32_t)points.size();
+    if (n == 0) return 0;
+    std::vector<uint8_t> valid(n), inView(n, 0);
+    std::vector<float> xw((size_t)n * 3), nrm((size_t)n * 3), mx(n), mn(n), proj((size_t)n * 2, 0.f), xr(n, 0.f), vc(n, 0.f);
+    std::vector<int32_t> lvl(n, 0);
+    for (int i = 0; i < n; i++) {
+      valid[i] = points[i].ref.valid;
+      std::memcpy(&xw[3 * (size_t)i], points[i].ref.Xw, 12);
+      std::memcpy(&nrm[3 * (size_t)i], points[i].normal, 12);
+      mx[i] = points[i].mfMaxDistance; mn[i] = points[i].mfMinDistance;
+    }
+    float Ow[3];
+    for (int r = 0; r < 3; r++) {
+      double s = 0;
+      for (int k = 0; k < 3; k++) s += (double)mTcw[k * 4 + r] * (double)mTcw[k * 4 + 3];
+      Ow[r] = (float)(-s);
+    }
+    fb_frustum_args a{};
+    a.batch = 1; a.mp_stride = n; a.Tcw = mTcw; a.Ow = Ow; a.n_mp = &n; a.mp_valid = valid.data(); a.mp_xw = xw.data();
+    a.mp_normal = nrm.data(); a.mp_max_dist = mx.data(); a.mp_min_dist = mn.data();
+    a.cam = {fx, fy, cx, cy, mnMinX, mnMinY, mnMaxX, mnMaxY};
+    a.mbf = mbf; a.viewing_cos_limit = viewingCosLimit;
+    a.log_scale_factor = mvScaleFactors.size() > 1 ? std::log(mvScaleFactors[1]) : 1.f;
+    a.n_levels = (int32_t)mvScaleFactors.size();
+    a.in_view = inView.data(); a.proj = proj.data(); a.proj_xr = xr.data(); a.level = lvl.data(); a.view_cos = vc.data();
+    check(fb_in_frustum(&a));
+    int cnt = 0;
+    for (int i = 0; i < n; i++) {
+      points[i].mbTrackInView = inView[i] != 0;
+      if (!inView[i]) continue;
+      cnt++;
+      points[i].mTrackProjX = proj[2 * (size_t)i]; points[i].mTrackProjY = proj[2 * (size_t)i + 1];
+      points[i].mTrackProjXR = xr[i]; points[i].mnTrackScaleLevel = lvl[i]; points[i].mTrackViewCos = vc[i];
+    }
+    return cnt;
   }
 };
 
@@ -162,6 +212,39 @@ class ORBmatcher {
     for (int i = 0; i < N; i++)
       if (match[i] >= 0) { cur.mvpMapPoints[i] = last.mvpMapPoints[match[i]]; cur.mvpMapPointHasObs[i] = obs[match[i]]; }
     // culled assignments (rotation histogram) are already -1 in match[]; reproduce the NULL writes
+    return nmatches;
+  }
+
+  // SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th), ORBmatcher.cc:46-130 (TrackLocalMap).
+  // points[i] carries the MapPoint's track members as Frame::isInFrustum left them (below); returns nmatches and
+  // writes F.mvpMapPoints[idx] = index of the matched point.
+  int SearchByProjection(Frame &F, const std::vector<LocalMapPoint> &points, float th = 1.f) const {
+    const int32_t N = F.N(), NM = (int32_t)points.size();
+    std::vector<uint8_t> track(NM > 0 ? NM : 1), obs(NM > 0 ? NM : 1), desc((size_t)(NM > 0 ? NM : 1) * 32), blocked(N > 0 ? N : 1, 0);
+    std::vector<float> proj((size_t)(NM > 0 ? NM : 1) * 2), vcos(NM > 0 ? NM : 1);
+    std::vector<int32_t> level(NM > 0 ? NM : 1), match(N > 0 ? N : 1);
+    for (int i = 0; i < NM; i++) {
+      track[i] = points[i].mbTrackInView && points[i].ref.valid;
+      obs[i] = points[i].ref.hasObservations;
+      proj[2 * i] = points[i].mTrackProjX; proj[2 * i + 1] = points[i].mTrackProjY;
+      level[i] = points[i].mnTrackScaleLevel; vcos[i] = points[i].mTrackViewCos;
+      std::memcpy(&desc[32 * (size_t)i], points[i].ref.descriptor, 32);
+    }
+    for (int i = 0; i < N; i++) blocked[i] = F.mvpMapPoints[i] >= 0 && F.mvpMapPointHasObs[i];
+    fb_proj_points_args a{};
+    a.batch = 1; a.cur_stride = N; a.mp_stride = NM > 0 ? NM : 1;
+    a.n_cur = &N; a.cur_kps = F.mvKeysUn.data(); a.cur_desc = F.mDescriptors.data();
+    a.cur_cell_start = F.gridStart.data(); a.cur_cell_items = F.gridItems.data(); a.cur_blocked = blocked.data();
+    a.n_mp = &NM; a.mp_track = track.data(); a.mp_obs_pos = obs.data(); a.mp_proj = proj.data(); a.mp_level = level.data();
+    a.mp_view_cos = vcos.data(); a.mp_desc = desc.data();
+    a.grid = F.frontGrid();
+    for (size_t i = 0; i < F.mvScaleFactors.size() && i < FB_MAX_LEVELS; i++) a.scale_factors[i] = F.mvScaleFactors[i];
+    a.th = th; a.matcher = m_;
+    int32_t nmatches = 0;
+    a.match_cur_to_mp = match.data(); a.nmatches = &nmatches;
+    check(fb_match_projection_points(&a));
+    for (int i = 0; i < N; i++)
+      if (match[i] >= 0) { F.mvpMapPoints[i] = match[i]; F.mvpMapPointHasObs[i] = obs[match[i]]; }
     return nmatches;
   }
 

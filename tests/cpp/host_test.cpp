@@ -1,6 +1,8 @@
 // Exercises the C++ host mirror (fishbird_host.hpp) the way Tracking would: extract -> grid -> self
 // SearchByProjection -> PoseOptimization.  Reads a raw u8 image, writes keypoints + descriptors for the Python
 // test to compare against the oracle, prints the integer results.
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -48,8 +50,26 @@ int main(int argc, char **argv) {
     }
     F.mTcw[3] = 0.02f;  // perturb tx; the optimiser must bring it back
     const int ninl = fishbird::Optimizer::PoseOptimization(&F, framePts);
-    std::printf("N=%d nmatches=%d self=%d inliers=%d tx=%.6f dist00=%d\n", N, nmatches, self, ninl, F.mTcw[3],
-                fishbird::ORBmatcher::DescriptorDistance(F.mDescriptors.data(), F.mDescriptors.data()));
+    // TrackLocalMap: Frame::isInFrustum over the "local map" (the same points), then SearchByProjection(F, points, th)
+    std::vector<fishbird::LocalMapPoint> local(N);
+    const std::vector<float> sf = orb.GetScaleFactors();
+    for (int i = 0; i < N; i++) {
+      local[i].ref = pts[i];
+      const float *X = pts[i].Xw;
+      const float d = std::sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
+      for (int k = 0; k < 3; k++) local[i].normal[k] = X[k] / d;
+      local[i].mfMaxDistance = d * sf[F.mvKeysUn[i].octave];
+      local[i].mfMinDistance = local[i].mfMaxDistance / sf[7];
+    }
+    std::fill(F.mvpMapPoints.begin(), F.mvpMapPoints.end(), -1);
+    const int inView = F.isInFrustum(local, 0.5f);
+    fishbird::ORBmatcher localMatcher(0.8f, true);
+    const int nLocal = localMatcher.SearchByProjection(F, local, 1.f);
+    int selfLocal = 0;
+    for (int i = 0; i < N; i++) if (F.mvpMapPoints[i] == i) selfLocal++;
+    std::printf("N=%d nmatches=%d self=%d inliers=%d tx=%.6f dist00=%d inview=%d local=%d selflocal=%d\n", N, nmatches, self, ninl,
+                F.mTcw[3], fishbird::ORBmatcher::DescriptorDistance(F.mDescriptors.data(), F.mDescriptors.data()), inView, nLocal,
+                selfLocal);
     FILE *o = std::fopen(argv[4], "wb");
     std::fwrite(&N, 4, 1, o);
     std::fwrite(F.mvKeysUn.data(), sizeof(fb_keypoint), N, o);

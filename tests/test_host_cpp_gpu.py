@@ -46,3 +46,8 @@ def test_host_mirror_end_to_end():
     assert d00 == 0
     assert nmatches > 0.9 * N and self_ > 0.9 * nmatches      # a frame matched against itself
     assert inl > 0.9 * nmatches and abs(tx) < 2e-3            # the 2 cm perturbation is optimised away
+    m2 = re.search(r"inview=(\d+) local=(\d+) selflocal=(\d+)", out)
+    assert m2, out
+    in_view, n_local, self_local = int(m2[1]), int(m2[2]), int(m2[3])
+    assert in_view > 0.95 * N                                  # isInFrustum: every point of the frame itself is visible
+    assert n_local > 0.8 * N and self_local > 0.9 * n_local     # TrackLocalMap re-finds the frame's own points
