@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="frame pairs per step and per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="frame pairs per step and per GPU")
     ap.add_argument("--cpu-sample", type=int, default=96, help="frame pairs timed on the host for cpu_baseline (0 = skip)")
     ap.add_argument("--no-ba", action="store_true", help="skip the secondary local-BA measurement")
     ap.add_argument("--serial", action="store_true", help="single-stream steps (kernels do not overlap; for profiling)")
