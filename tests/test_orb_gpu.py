@@ -78,3 +78,10 @@ def test_extract_white_noise_and_constant():
     _check_image(O.orb_params(), g.integers(0, 256, (240, 320), dtype=np.uint8))
     k = _check_image(O.orb_params(), np.full((240, 320), 100, np.uint8))
     assert len(k) == 0
+
+
+@pytest.mark.parametrize("scale,nlevels,nfeat", [(1.5, 5, 1200), (2.0, 4, 800), (1.1, 8, 1500)])
+def test_extract_other_pyramids(scale, nlevels, nfeat):
+    """Scale factors other than 1.2: the resize window logic (k_resize_rows up to scale 2, generic kernel beyond its
+    12-byte window), the level tables and the per-level quotas."""
+    _check_image(O.orb_params(nfeatures=nfeat, scale_factor=scale, nlevels=nlevels), synth.synth_image(1010, 800, 600))
