@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int POSE_THREADS = 512;
+constexpr int POSE_THREADS = 256;
 constexpr int NW = POSE_THREADS / 64;
 constexpr int NACC = 28;  // chi2, 21 x H upper, 6 x b
 
