@@ -37,7 +37,14 @@ def test_ctypes_mirrors_match_the_header_layout():
              "fb_grid_geom": C.sizeof(cabi.GridGeom), "fb_camera": C.sizeof(cabi.Camera), "fb_proj_frame_args": C.sizeof(cabi.ProjFrameArgs),
              "fb_bird_mp_args": C.sizeof(cabi.BirdMpArgs), "fb_proj_points_args": C.sizeof(cabi.ProjPointsArgs),
              "fb_birdview_args": C.sizeof(cabi.BirdviewArgs), "fb_pose_opt_args": C.sizeof(cabi.PoseOptArgs),
-             "fb_local_ba_args": C.sizeof(cabi.LocalBAArgs), "fb_prof_entry": C.sizeof(cabi.ProfEntry)}
+             "fb_local_ba_args": C.sizeof(cabi.LocalBAArgs), "fb_prof_entry": C.sizeof(cabi.ProfEntry),
+             "fb_feature_vector": C.sizeof(cabi.FeatureVector), "fb_bow_args": C.sizeof(cabi.BowArgs),
+             "fb_triangulation_args": C.sizeof(cabi.TriangulationArgs), "fb_proj_kf_args": C.sizeof(cabi.ProjKfArgs),
+             "fb_bow_kf_args": C.sizeof(cabi.BowKfArgs), "fb_kf_target": C.sizeof(cabi.KfTarget), "fb_mp_list": C.sizeof(cabi.MpList),
+             "fb_fuse_args": C.sizeof(cabi.FuseArgs), "fb_proj_sim3_args": C.sizeof(cabi.ProjSim3Args),
+             "fb_sim3_args": C.sizeof(cabi.Sim3Args), "fb_init_match_args": C.sizeof(cabi.InitMatchArgs),
+             "fb_frustum_args": C.sizeof(cabi.FrustumArgs), "fb_bird_filter_args": C.sizeof(cabi.BirdFilterArgs),
+             "fb_vocabulary": C.sizeof(cabi.Vocabulary), "fb_bow_transform_args": C.sizeof(cabi.BowTransformArgs)}
     src = '#include <stdio.h>\n#include "fishbird.h"\nint main(void){\n' + "".join(
         'printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in names) + "return 0;}\n"
     d = tempfile.mkdtemp()
