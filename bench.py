@@ -269,8 +269,8 @@ def main():
                                "pose_inliers": float(res["ninliers"].mean())},
         }
         out["local_ba"] = ba
-        if a.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(front, bird, world, min(a.cpu_sample, B))
+        # the CPU leg is timed on rank 0 of the single-GPU run only (N > 1 would stall the other ranks)
+        out["cpu_baseline"] = cpu_baseline(front, bird, world, min(a.cpu_sample, B)) if (a.cpu_sample > 0 and world_size == 1) else None
         print(json.dumps(out), flush=True)
     if world_size > 1:
         dist.barrier()
