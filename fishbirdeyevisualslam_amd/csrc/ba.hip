@@ -47,6 +47,7 @@ struct BADev {  // device pointers + sizes, passed by value
   const int *poseIdx;          // [n_kf] free index or -1
   const int *e_pt, *e_kf;      // [nE]
   const uint8_t *e_type;       // [nE]
+  const int *e_pj;             // [nE] poseIdx[e_kf[e]] (one dependent load less on the landmark-centric paths)
   const double *e_meas;        // [nE][3]
   const double *e_info;        // [nE]
   uint8_t *e_level;            // [nE]
@@ -412,9 +413,11 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BADev D, LinBuf B, d
   double4_t acc[MAXT];
 #pragma unroll
   for (int t = 0; t < MAXT; t++) acc[t] = (double4_t){0, 0, 0, 0};
+  // the panels are sparse (a landmark touches only the rows of its observing key frames): zero them once, and after each
+  // chunk's MFMA phase clear exactly the entries that chunk wrote instead of re-zeroing 2 x rows x KPAD doubles
+  for (int i = tid; i < 2 * rows * KPAD; i += SCHUR_THREADS) Yp[i] = 0;
+  __syncthreads();
   for (int c0 = l0; c0 < l1; c0 += CHUNK) {
-    for (int i = tid; i < 2 * rows * KPAD; i += SCHUR_THREADS) Yp[i] = 0;
-    __syncthreads();
     // 16 lanes per landmark of the chunk: every lane inverts D (cheap), lane 0 of the group publishes it, the
     // group's lanes scatter the landmark's edge blocks in parallel
     {
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BADev D, LinBuf B, d
         }
         for (int cc = D.lm_start[l] + sub; cc < D.lm_start[l + 1]; cc += 16) {
           const int e = D.lm_edges[cc];
-          const int pj = D.poseIdx[D.e_kf[e]];
+          const int pj = D.e_pj[e];
           if (pj < 0 || D.e_level[e] != 0) continue;
           const double *W = B.W + (size_t)e * 18;
 #pragma unroll
@@ -471,6 +474,29 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BADev D, LinBuf B, d
 #pragma unroll
         for (int k0 = 0; k0 < KP; k0 += 4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[k0], wb[k0], c, 0, 0, 0);
         acc[t] = c;
+      }
+    }
+    __syncthreads();
+    {  // clear what this chunk scattered (same traversal as above)
+      const int li = tid >> 4, sub = tid & 15;
+      const int l = c0 + li;
+      if (l < l1) {
+        if (sub == 0) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) Wp[(size_t)P6 * KPAD + 3 * li + c] = 0;
+        }
+        for (int cc = D.lm_start[l] + sub; cc < D.lm_start[l + 1]; cc += 16) {
+          const int e = D.lm_edges[cc];
+          const int pj = D.e_pj[e];
+          if (pj < 0 || D.e_level[e] != 0) continue;
+#pragma unroll
+          for (int i = 0; i < 6; i++) {
+            double *yr = Yp + (size_t)(6 * pj + i) * KPAD + 3 * li;
+            double *wr = Wp + (size_t)(6 * pj + i) * KPAD + 3 * li;
+            yr[0] = 0; yr[1] = 0; yr[2] = 0;
+            wr[0] = 0; wr[1] = 0; wr[2] = 0;
+          }
+        }
       }
     }
     __syncthreads();
@@ -639,7 +665,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_update(BADev D, LinBuf B, St
     double cl[3] = {B.bl[(size_t)3 * l], B.bl[(size_t)3 * l + 1], B.bl[(size_t)3 * l + 2]};
     for (int cc = D.lm_start[l]; cc < D.lm_start[l + 1]; cc++) {
       const int e = D.lm_edges[cc];
-      const int pj = D.poseIdx[D.e_kf[e]];
+      const int pj = D.e_pj[e];
       if (pj < 0 || D.e_level[e] != 0) continue;
       const double *W = B.W + (size_t)e * 18;
 #pragma unroll
@@ -860,6 +886,10 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
   nWg = std::max(1, (npt + lmPerWg - 1) / std::max(lmPerWg, 1));
   fb::DevBuf d_poseIdx, d_ept, d_ekf, d_etype, d_emeas, d_einfo, d_elevel, d_echi2, d_lms, d_lme, d_pss, d_pse, d_oi, d_oj,
       d_oz, d_oinfo, d_fixed;
+  std::vector<int> e_pj(nE);
+  for (int e = 0; e < nE; e++) e_pj[e] = poseIdx[e_kf[e]];
+  fb::DevBuf d_epj;
+  if (nE > 0) BA_UP(d_epj, e_pj); else FB_TRY(d_epj.alloc(4));
   BA_UP(d_poseIdx, poseIdx); BA_UP(d_ept, e_pt); BA_UP(d_ekf, e_kf); BA_UP(d_etype, e_type); BA_UP(d_emeas, e_meas);
   BA_UP(d_einfo, e_info); BA_UP(d_elevel, e_level); BA_UP(d_lms, lm_start); BA_UP(d_lme, lm_edges); BA_UP(d_pss, ps_start);
   BA_UP(d_pse, ps_edges); BA_UP(d_oi, o_i); BA_UP(d_oj, o_j); BA_UP(d_oz, oZinv); BA_UP(d_oinfo, o_info);
@@ -882,6 +912,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
   BADev D;
   D.n_kf = n_kf; D.np = np; D.npt = npt; D.nE = nE; D.nO = nO; D.quat = odom ? 1 : 0;
   D.fx = A->fx; D.fy = A->fy; D.cx = A->cx; D.cy = A->cy; D.delta = sc.delta;
+  D.e_pj = d_epj.as<int>();
   D.poseIdx = d_poseIdx.as<int>(); D.e_pt = d_ept.as<int>(); D.e_kf = d_ekf.as<int>(); D.e_type = d_etype.as<uint8_t>();
   D.e_meas = d_emeas.as<double>(); D.e_info = d_einfo.as<double>(); D.e_level = d_elevel.as<uint8_t>();
   D.e_chi2 = d_echi2.as<double>(); D.lm_start = d_lms.as<int>(); D.lm_edges = d_lme.as<int>(); D.ps_start = d_pss.as<int>();
