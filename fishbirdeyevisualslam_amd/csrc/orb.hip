@@ -664,12 +664,13 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
     const int cellI = (y - EDGE_THRESHOLD) / Lv.hCell, cellJ = (x - EDGE_THRESHOLD) / Lv.wCell;
     const int dwid = min(Lv.wCell, Lv.w - 2 * EDGE_THRESHOLD - cellJ * Lv.wCell);
     const int inCell = (y - EDGE_THRESHOLD - cellI * Lv.hCell) * dwid + (x - EDGE_THRESHOLD - cellJ * Lv.wCell);
-    const unsigned orderKey = (unsigned)(cellI * Lv.nCols + cellJ) * 4096u + (unsigned)inCell;  // < 2^24
-    const unsigned long long key = ((unsigned long long)r << 56) | ((unsigned long long)(0xFFFFFFu - orderKey) << 32) | (unsigned)k;
+    const unsigned orderKey = (unsigned)(cellI * Lv.nCols + cellJ) * 4096u + (unsigned)inCell;  // < 2^32 (cells < 2^20)
+    // response (8 bits) | inverted order key (32 bits) | candidate index (24 bits)
+    const unsigned long long key = ((unsigned long long)r << 56) | ((unsigned long long)(0xFFFFFFFFu - orderKey) << 24) | (unsigned)k;
     atomicMax(&best[nof[k]], key);
   }
   __syncthreads();
-  for (int p = tid; p < S; p += 256) out[p] = cd[(unsigned)(best[p] & 0xFFFFFFFFull)];
+  for (int p = tid; p < S; p += 256) out[p] = cd[(unsigned)(best[p] & 0xFFFFFFull)];
   if (tid == 0) *outCount = S;
 }
 
@@ -1007,13 +1008,14 @@ int prepare(fb_orb *o, int w, int h, int batch) {
     if (L.wCell + 6 > FAST_MAX_TILE - 3 || L.hCell + 6 > FAST_MAX_TILE) { fb::set_error("FAST cell %dx%d exceeds the LDS tile", L.wCell, L.hCell); return FB_ERR_CAPACITY; }
     L.cellBase = cells;
     cells += L.nCols * L.nRows;
-    if (L.nCols * L.nRows > 4095) { fb::set_error("level %d has more than 4095 FAST cells", l); return FB_ERR_CAPACITY; }
+    if (L.nCols * L.nRows >= (1 << 20)) { fb::set_error("level %d has more than 2^20 FAST cells", l); return FB_ERR_CAPACITY; }
     L.N = o->t.features_per_level[l];
     // NMS worst case: one survivor per 2x2 block of each cell's detection area
     const int dw = std::max(L.w - 2 * EDGE_THRESHOLD, 0), dh = std::max(L.h - 2 * EDGE_THRESHOLD, 0);
     L.candBase = candOff;
     L.candCap = L.nCols * L.nRows * (((L.wCell + 1) / 2) * ((L.hCell + 1) / 2)) + 16;
     (void)dw; (void)dh;
+    if (L.candCap >= (1 << 24)) { fb::set_error("level %d: more than 2^24 FAST candidates possible", l); return FB_ERR_CAPACITY; }
     candOff += (L.candCap + 3) & ~3;
     const int Wr = maxBX - BORDER, Hr = maxBY - BORDER;
     L.nIni = (Hr > 0) ? (int)roundf((float)Wr / Hr) : 0;   // ORBextractor.cc:542

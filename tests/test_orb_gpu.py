@@ -85,3 +85,8 @@ def test_extract_other_pyramids(scale, nlevels, nfeat):
     """Scale factors other than 1.2: the resize window logic (k_resize_rows up to scale 2, generic kernel beyond its
     12-byte window), the level tables and the per-level quotas."""
     _check_image(O.orb_params(nfeatures=nfeat, scale_factor=scale, nlevels=nlevels), synth.synth_image(1010, 800, 600))
+
+
+def test_extract_4k_image():
+    """3840x2160: 8820 FAST cells on level 0 (beyond the 12-bit cell index of the first quadtree key layout)."""
+    _check_image(O.orb_params(nfeatures=4000), synth.synth_image(77, 3840, 2160), stagewise=False)
