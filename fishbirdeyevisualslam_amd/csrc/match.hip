@@ -165,7 +165,7 @@ __device__ __forceinline__ TargetLds stage_target(uint8_t *smem, const Carve &cv
 // falls back to the full walk.  cacheK = 0 (LDS too small) keeps the full walk every round.
 constexpr int CACHE_K = 4;
 
-__global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args A, int cacheK) {
+__global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args A, int cacheK, int descInLds) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   typedef unsigned short u16;
   constexpr int NONE16 = 0xFFFF;
@@ -173,9 +173,9 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
   const int ncell = A.grid.cols * A.grid.rows;
   const size_t co = (size_t)b * A.cur_stride, lo = (size_t)b * A.last_stride;
   const int ncur = A.n_cur[b], nlast = A.n_last[b];
-  const Carve cv(A.cur_stride, ncell);
+  const Carve cv(A.cur_stride, ncell, descInLds != 0);
   const TargetLds T = stage_target(smem, cv, ncur, ncell, A.cur_kps + co, A.cur_desc + co * 32,
-                                   A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co);
+                                   A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co, descInLds != 0);
   int *ownerA = reinterpret_cast<int *>(smem + cv.end);  // [cur_stride]
   int *ownerB = ownerA + A.cur_stride;                   // [cur_stride]
   uint32_t *cache = reinterpret_cast<uint32_t *>(ownerB + A.cur_stride);  // [last_stride][cacheK]  dist << 16 | idx
@@ -331,55 +331,45 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
 // Same greedy structure as M3; the search level comes from MapPoint::PredictScale and every
 // accepted slot blocks all later key-frame points (mvpMapPoints[i2] != NULL, :1545).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MATCH_THREADS) void k_proj_kf(fb_proj_kf_args A) {
+__global__ __launch_bounds__(MATCH_THREADS) void k_proj_kf(fb_proj_kf_args A, int descInLds) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  typedef unsigned short u16;
+  constexpr int NONE16 = 0xFFFF;
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int ncell = A.grid.cols * A.grid.rows;
   const size_t co = (size_t)b * A.cur_stride, ko = (size_t)b * A.kf_stride;
   const int ncur = A.n_cur[b], nkf = A.n_kf[b];
-  const Carve cv(A.cur_stride, ncell);
+  const Carve cv(A.cur_stride, ncell, descInLds != 0);
   const TargetLds T = stage_target(smem, cv, ncur, ncell, A.cur_kps + co, A.cur_desc + co * 32,
-                                   A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co);
+                                   A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co, descInLds != 0);
   int *ownerA = reinterpret_cast<int *>(smem + cv.end);  // [cur_stride]
   int *ownerB = ownerA + A.cur_stride;                   // [cur_stride]
-  int *assignA = ownerB + A.cur_stride;                  // [kf_stride]
-  int *assignB = assignA + A.kf_stride;                  // [kf_stride]
-  int *levelQ = assignB + A.kf_stride;                   // [kf_stride] predicted level, or -1 = gated out
-  float *uQ = reinterpret_cast<float *>(levelQ + A.kf_stride);  // [kf_stride]
-  float *vQ = uQ + A.kf_stride;                                 // [kf_stride]
+  u16 *assignA = reinterpret_cast<u16 *>(ownerB + A.cur_stride);  // [kf_stride] chosen slot or NONE16
+  u16 *assignB = assignA + A.kf_stride;                  // [kf_stride]
   __shared__ int s_changed, s_n, s_hist[HISTO_LENGTH], s_ind[3];
   __shared__ float s_T[12], s_Ow[3];
   if (tid < 12) s_T[tid] = A.cur_Tcw[(size_t)b * 12 + tid];
   if (tid == 64) fb::camera_centre(A.cur_Tcw + (size_t)b * 12, s_Ow);
   const uint8_t *blocked0 = A.cur_blocked ? A.cur_blocked + co : nullptr;
   for (int i = tid; i < ncur; i += nt) ownerA[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
-  for (int q = tid; q < nkf; q += nt) assignA[q] = NONE;
+  for (int q = tid; q < nkf; q += nt) assignA[q] = NONE16;
   __syncthreads();
-  // geometric gates are independent of the greedy state: once per key-frame point
-  for (int q = tid; q < nkf; q += nt) {
-    int lvl = -1;
-    float2 uv = make_float2(0.f, 0.f);
-    if (A.kf_valid[ko + q]) {
-      const float X[3] = {A.kf_xw[(ko + q) * 3], A.kf_xw[(ko + q) * 3 + 1], A.kf_xw[(ko + q) * 3 + 2]};
-      float pc[3];
-      xform(s_T, X, pc);
-      const float invzc = (float)(1.0 / pc[2]);
-      const float u = A.cam.fx * pc[0] * invzc + A.cam.cx;
-      const float v = A.cam.fy * pc[1] * invzc + A.cam.cy;
-      if (!(u < A.cam.min_x || u > A.cam.max_x) && !(v < A.cam.min_y || v > A.cam.max_y)) {
-        const float dist3D = fb::norm3(X[0] - s_Ow[0], X[1] - s_Ow[1], X[2] - s_Ow[2]);
-        const float maxD = A.kf_max_dist[ko + q];
-        if (!(dist3D < 0.8f * A.kf_min_dist[ko + q] || dist3D > 1.2f * maxD)) {
-          lvl = fb::predict_scale(maxD, dist3D, A.log_scale_factor, A.n_levels);
-          uv = make_float2(u, v);
-        }
-      }
-    }
-    levelQ[q] = lvl;
-    uQ[q] = uv.x;
-    vQ[q] = uv.y;
-  }
-  __syncthreads();
+
+  // the geometric gates are cheap and are re-evaluated every round instead of being stored per point
+  auto gate = [&](int q, float &u, float &v) -> int {
+    if (!A.kf_valid[ko + q]) return -1;
+    const float X[3] = {A.kf_xw[(ko + q) * 3], A.kf_xw[(ko + q) * 3 + 1], A.kf_xw[(ko + q) * 3 + 2]};
+    float pc[3];
+    xform(s_T, X, pc);
+    const float invzc = (float)(1.0 / pc[2]);
+    u = A.cam.fx * pc[0] * invzc + A.cam.cx;
+    v = A.cam.fy * pc[1] * invzc + A.cam.cy;
+    if ((u < A.cam.min_x || u > A.cam.max_x) || (v < A.cam.min_y || v > A.cam.max_y)) return -1;
+    const float dist3D = fb::norm3(X[0] - s_Ow[0], X[1] - s_Ow[1], X[2] - s_Ow[2]);
+    const float maxD = A.kf_max_dist[ko + q];
+    if (dist3D < 0.8f * A.kf_min_dist[ko + q] || dist3D > 1.2f * maxD) return -1;
+    return fb::predict_scale(maxD, dist3D, A.log_scale_factor, A.n_levels);
+  };
 
   for (int round = 0; round <= nkf + 1; round++) {
     for (int i = tid; i < ncur; i += nt) ownerB[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
@@ -387,35 +377,37 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_kf(fb_proj_kf_args A) {
     __syncthreads();
     for (int q = tid; q < nkf; q += nt) {
       int best = NONE;
-      const int lvl = levelQ[q];
+      float u, v;
+      const int lvl = gate(q, u, v);
       if (lvl >= 0) {
-        const float2 uv = make_float2(uQ[q], vQ[q]);
         const float radius = A.th * A.scale_factors[lvl];
         uint32_t d[8];
         const uint4 *dq = reinterpret_cast<const uint4 *>(A.kf_desc + (ko + q) * 32);
         const uint4 d0 = dq[0], d1 = dq[1];
         d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
         int bestDist = 256;
-        for_area<false>(A.grid, T, uv.x, uv.y, radius, lvl - 1, lvl + 1, [&](int i2) {
+        for_area<false>(A.grid, T, u, v, radius, lvl - 1, lvl + 1, [&](int i2) {
           if (ownerA[i2] < q) return;
           const int dist = fb::hamming256(d, T.desc + i2 * 2);
           if (dist < bestDist) { bestDist = dist; best = i2; }
         });
         if (bestDist > A.orb_dist) best = NONE;
       }
-      assignB[q] = best;
-      if (best != assignA[q]) s_changed = 1;
+      const int best16 = best == NONE ? NONE16 : best;
+      assignB[q] = (u16)best16;
+      if (best16 != assignA[q]) s_changed = 1;
       if (best != NONE) atomicMin(&ownerB[best], q);
     }
     __syncthreads();
     const int changed = s_changed;
     int *t = ownerA; ownerA = ownerB; ownerB = t;
-    t = assignA; assignA = assignB; assignB = t;
+    u16 *t16 = assignA; assignA = assignB; assignB = t16;
     __syncthreads();
     if (!changed) break;
   }
 
   int *matchL = ownerB;
+  u16 *binQ = assignB;
   for (int i = tid; i < ncur; i += nt) matchL[i] = -1;
   if (tid < HISTO_LENGTH) s_hist[tid] = 0;
   if (tid == 0) s_n = 0;
@@ -423,13 +415,13 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_kf(fb_proj_kf_args A) {
   const bool ori = A.matcher.check_orientation != 0;
   for (int q = tid; q < nkf; q += nt) {
     const int c = assignA[q];
-    if (c == NONE) continue;
+    if (c == NONE16) continue;
     matchL[c] = q;  // a claimed slot blocks every later point: one claimer per slot
     atomicAdd(&s_n, 1);
     if (ori) {
       const int bin = rot_bin(A.kf_angle[ko + q] - A.cur_kps[co + c].angle);
       atomicAdd(&s_hist[bin], 1);
-      assignB[q] = bin;
+      binQ[q] = (u16)bin;
     }
   }
   __syncthreads();
@@ -438,8 +430,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_kf(fb_proj_kf_args A) {
     __syncthreads();
     for (int q = tid; q < nkf; q += nt) {
       const int c = assignA[q];
-      if (c == NONE) continue;
-      const int bin = assignB[q];
+      if (c == NONE16) continue;
+      const int bin = binQ[q];
       if (bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2]) {
         matchL[c] = -1;
         atomicSub(&s_n, 1);
@@ -454,15 +446,15 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_kf(fb_proj_kf_args A) {
 // ---------------------------------------------------------------------------------------
 // M2  SearchByProjection(Frame&, const vector<MapPoint*>&, th)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MATCH_THREADS) void k_proj_points(fb_proj_points_args A) {
+__global__ __launch_bounds__(MATCH_THREADS) void k_proj_points(fb_proj_points_args A, int descInLds) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int ncell = A.grid.cols * A.grid.rows;
   const size_t co = (size_t)b * A.cur_stride, mo = (size_t)b * A.mp_stride;
   const int ncur = A.n_cur[b], nmp = A.n_mp[b];
-  const Carve cv(A.cur_stride, ncell);
+  const Carve cv(A.cur_stride, ncell, descInLds != 0);
   const TargetLds T = stage_target(smem, cv, ncur, ncell, A.cur_kps + co, A.cur_desc + co * 32,
-                                   A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co);
+                                   A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co, descInLds != 0);
   int *ownerA = reinterpret_cast<int *>(smem + cv.end);
   int *ownerB = ownerA + A.cur_stride;
   int *assignA = ownerB + A.cur_stride;
@@ -529,15 +521,15 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_points(fb_proj_points_ar
 // ---------------------------------------------------------------------------------------
 // M9  BirdMapPointMatch
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MATCH_THREADS) void k_bird_mappoints(fb_bird_mp_args A) {
+__global__ __launch_bounds__(MATCH_THREADS) void k_bird_mappoints(fb_bird_mp_args A, int descInLds) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int ncell = A.grid.cols * A.grid.rows;
   const size_t co = (size_t)b * A.cur_stride, ro = (size_t)b * A.ref_stride;
   const int ncur = A.n_cur[b], nref = A.n_ref[b];
-  const Carve cv(A.cur_stride, ncell);
+  const Carve cv(A.cur_stride, ncell, descInLds != 0);
   const TargetLds T = stage_target(smem, cv, ncur, ncell, A.cur_kps + co, A.cur_desc + co * 32,
-                                   A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co);
+                                   A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co, descInLds != 0);
   int *writer = reinterpret_cast<int *>(smem + cv.end);  // [cur_stride]
   __shared__ float s_Tcw[12], s_Tbw[12];
   __shared__ int s_n;
@@ -595,15 +587,15 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_bird_mappoints(fb_bird_mp_arg
 // ---------------------------------------------------------------------------------------
 // M8  BirdviewMatch, isProject = 0
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MATCH_THREADS) void k_birdview(fb_birdview_args A) {
+__global__ __launch_bounds__(MATCH_THREADS) void k_birdview(fb_birdview_args A, int descInLds) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int ncell = A.grid.cols * A.grid.rows;
   const size_t co = (size_t)b * A.cur_stride, ro = (size_t)b * A.ref_stride;
   const int ncur = A.n_cur[b], nref = A.n_ref[b];
-  const Carve cv(A.cur_stride, ncell);
+  const Carve cv(A.cur_stride, ncell, descInLds != 0);
   const TargetLds T = stage_target(smem, cv, ncur, ncell, A.cur_kps + co, A.cur_desc + co * 32,
-                                   A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co);
+                                   A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co, descInLds != 0);
   int *m12 = reinterpret_cast<int *>(smem + cv.end);  // [ref_stride]
   int *bins = m12 + A.ref_stride;                      // [ref_stride] histogram bin of i1 or -1
   __shared__ int s_n, s_nd, s_hist[HISTO_LENGTH], s_ind[3];
@@ -761,6 +753,21 @@ size_t match_lds_bytes(int cur_stride, int ncell, int extra_ints, bool withDesc 
   return Carve(cur_stride, ncell, withDesc).end + (size_t)extra_ints * 4;
 }
 
+// LDS plan of a matcher: the target frame's descriptor table goes to LDS when everything fits, otherwise it stays in
+// HBM/L2 (frames with more key points than ~2900, e.g. nFeatures = 4000) and only positions, octaves and the grid are staged
+struct LdsPlan { size_t bytes; int descInLds; };
+constexpr size_t LDS_BUDGET = 160 * 1024 - 512;  // leave room for the kernels' static __shared__ variables
+int check_lds(size_t bytes, const char *what);
+int plan_lds(int cur_stride, int ncell, int extra_ints, const char *what, LdsPlan *p) {
+  p->descInLds = 1;
+  p->bytes = Carve(cur_stride, ncell, true).end + (size_t)extra_ints * 4;
+  if (p->bytes > LDS_BUDGET) {
+    p->descInLds = 0;
+    p->bytes = Carve(cur_stride, ncell, false).end + (size_t)extra_ints * 4;
+  }
+  return check_lds(p->bytes, what);
+}
+
 int check_lds(size_t bytes, const char *what) {
   if (bytes > 160 * 1024) {
     fb::set_error("%s: frame too large for the LDS-staged matcher (%zu B > 160 KiB)", what, bytes);
@@ -840,13 +847,16 @@ int fb_match_projection_frame_dev(const fb_proj_frame_args *A, void *stream) {
   const int ncell = A->grid.cols * A->grid.rows;
   // ints: two owner arrays; per query two u16 assignments + u16 processing order + one meta byte (2 ints) + the cache
   const int base_ints = 2 * A->cur_stride + 2 * A->last_stride + 4;
-  int cacheK = CACHE_K;
+  // preference: descriptors in LDS + cache, descriptors in LDS, cache only, neither
+  int cacheK = CACHE_K, descInLds = 1;
   size_t lds = match_lds_bytes(A->cur_stride, ncell, base_ints + cacheK * A->last_stride);
-  if (lds > 160 * 1024 - 512) { cacheK = 0; lds = match_lds_bytes(A->cur_stride, ncell, base_ints); }
+  if (lds > LDS_BUDGET) { cacheK = 0; lds = match_lds_bytes(A->cur_stride, ncell, base_ints); }
+  if (lds > LDS_BUDGET) { cacheK = CACHE_K; descInLds = 0; lds = match_lds_bytes(A->cur_stride, ncell, base_ints + cacheK * A->last_stride, false); }
+  if (lds > LDS_BUDGET) { cacheK = 0; lds = match_lds_bytes(A->cur_stride, ncell, base_ints, false); }
   FB_TRY(check_lds(lds, "fb_match_projection_frame"));
   FB_TRY(set_max_lds(k_proj_frame, lds));
   fb::ProfScope prof_(fb::P_PROJ_FRAME, fb::as_stream(stream));
-  k_proj_frame<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A, cacheK);
+  k_proj_frame<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A, cacheK, descInLds);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -857,11 +867,12 @@ int fb_match_projection_keyframe_dev(const fb_proj_kf_args *A, void *stream) {
   FB_ARG(A->n_levels > 0 && A->n_levels <= FB_MAX_LEVELS);
   if (A->batch == 0) return FB_OK;
   const int ncell = A->grid.cols * A->grid.rows;
-  const size_t lds = match_lds_bytes(A->cur_stride, ncell, 2 * A->cur_stride + 5 * A->kf_stride);
-  FB_TRY(check_lds(lds, "fb_match_projection_keyframe"));
+  LdsPlan lp;
+  FB_TRY(plan_lds(A->cur_stride, ncell, 2 * A->cur_stride + A->kf_stride + 2, "fb_match_projection_keyframe", &lp));
+  const size_t lds = lp.bytes;
   FB_TRY(set_max_lds(k_proj_kf, lds));
   fb::ProfScope prof_(fb::P_PROJ_KF, fb::as_stream(stream));
-  k_proj_kf<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A);
+  k_proj_kf<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A, lp.descInLds);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -871,11 +882,12 @@ int fb_match_projection_points_dev(const fb_proj_points_args *A, void *stream) {
   FB_ARG(A && A->batch >= 0 && A->cur_stride > 0 && A->mp_stride >= 0 && A->cur_stride < 65536);
   if (A->batch == 0) return FB_OK;
   const int ncell = A->grid.cols * A->grid.rows;
-  const size_t lds = match_lds_bytes(A->cur_stride, ncell, 2 * A->cur_stride + 2 * A->mp_stride);
-  FB_TRY(check_lds(lds, "fb_match_projection_points"));
+  LdsPlan lp;
+  FB_TRY(plan_lds(A->cur_stride, ncell, 2 * A->cur_stride + 2 * A->mp_stride, "fb_match_projection_points", &lp));
+  const size_t lds = lp.bytes;
   FB_TRY(set_max_lds(k_proj_points, lds));
   fb::ProfScope prof_(fb::P_PROJ_POINTS, fb::as_stream(stream));
-  k_proj_points<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A);
+  k_proj_points<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A, lp.descInLds);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -885,11 +897,12 @@ int fb_match_bird_mappoints_dev(const fb_bird_mp_args *A, void *stream) {
   FB_ARG(A && A->batch >= 0 && A->cur_stride > 0 && A->ref_stride >= 0 && A->cur_stride < 65536);
   if (A->batch == 0) return FB_OK;
   const int ncell = A->grid.cols * A->grid.rows;
-  const size_t lds = match_lds_bytes(A->cur_stride, ncell, A->cur_stride);
-  FB_TRY(check_lds(lds, "fb_match_bird_mappoints"));
+  LdsPlan lp;
+  FB_TRY(plan_lds(A->cur_stride, ncell, A->cur_stride, "fb_match_bird_mappoints", &lp));
+  const size_t lds = lp.bytes;
   FB_TRY(set_max_lds(k_bird_mappoints, lds));
   fb::ProfScope prof_(fb::P_BIRD_MP, fb::as_stream(stream));
-  k_bird_mappoints<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A);
+  k_bird_mappoints<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A, lp.descInLds);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -899,11 +912,12 @@ int fb_match_birdview_dev(const fb_birdview_args *A, void *stream) {
   FB_ARG(A && A->batch >= 0 && A->cur_stride > 0 && A->ref_stride >= 0 && A->cur_stride < 65536);
   if (A->batch == 0) return FB_OK;
   const int ncell = A->grid.cols * A->grid.rows;
-  const size_t lds = match_lds_bytes(A->cur_stride, ncell, 2 * A->ref_stride);
-  FB_TRY(check_lds(lds, "fb_match_birdview"));
+  LdsPlan lp;
+  FB_TRY(plan_lds(A->cur_stride, ncell, 2 * A->ref_stride, "fb_match_birdview", &lp));
+  const size_t lds = lp.bytes;
   FB_TRY(set_max_lds(k_birdview, lds));
   fb::ProfScope prof_(fb::P_BIRDVIEW, fb::as_stream(stream));
-  k_birdview<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A);
+  k_birdview<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A, lp.descInLds);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
