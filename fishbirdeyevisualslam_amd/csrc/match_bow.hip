@@ -86,22 +86,25 @@ __device__ __forceinline__ void load_desc(const uint8_t *p, uint32_t d[8]) {
 // candidate side must carry a good MapPoint (:575-581), the distance test is strict (:598) and the result is
 // indexed by the query side (vpMatches12[idx1], :602).
 template <bool KFKF>
-__global__ __launch_bounds__(BOW_THREADS) void k_match_bow_t(fb_bow_args A, const uint8_t *f_has_mp, int32_t *match12) {
+__global__ __launch_bounds__(BOW_THREADS) void k_match_bow_t(fb_bow_args A, const uint8_t *f_has_mp, int32_t *match12, int descInLds) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const size_t ko = (size_t)b * A.kf_stride, fo = (size_t)b * A.f_stride;
   const int nF = A.n_f[b];
   const FVd K = fv_of(A.kf_fv, b), F = fv_of(A.f_fv, b);
   const int nQ = K.n > 0 ? K.start[K.n] : 0;  // flattened keyframe items = queries in serial order
-  uint4 *fdesc = reinterpret_cast<uint4 *>(smem);                    // [f_stride][2]
-  int *ownerA = reinterpret_cast<int *>(smem + (size_t)A.f_stride * 32);  // [f_stride]
+  // descriptor table of the candidate side: LDS when it fits, else read from HBM/L2 (frames with > ~3400 key points)
+  const size_t descBytes = descInLds ? (size_t)A.f_stride * 32 : 0;
+  const uint4 *fdesc = descInLds ? reinterpret_cast<const uint4 *>(smem) : reinterpret_cast<const uint4 *>(A.f_desc + fo * 32);
+  int *ownerA = reinterpret_cast<int *>(smem + descBytes);  // [f_stride]
   int *ownerB = ownerA + A.f_stride;
   int *assignA = ownerB + A.f_stride;                                // [kf item_stride]
   int *assignB = assignA + A.kf_fv.item_stride;
   __shared__ int s_changed, s_n, s_hist[HISTO_LENGTH], s_ind[3];
-  {
+  if (descInLds) {
     const uint4 *src = reinterpret_cast<const uint4 *>(A.f_desc + fo * 32);
-    for (int i = tid; i < nF * 2; i += nt) fdesc[i] = src[i];
+    uint4 *dst = reinterpret_cast<uint4 *>(smem);
+    for (int i = tid; i < nF * 2; i += nt) dst[i] = src[i];
   }
   for (int i = tid; i < nF; i += nt) ownerA[i] = NONE;
   for (int q = tid; q < nQ; q += nt) assignA[q] = NONE;
@@ -185,22 +188,26 @@ __global__ __launch_bounds__(BOW_THREADS) void k_match_bow_t(fb_bow_args A, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BOW_THREADS) void k_match_triangulation(fb_triangulation_args A) {
+__global__ __launch_bounds__(BOW_THREADS) void k_match_triangulation(fb_triangulation_args A, int descInLds) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const size_t o1 = (size_t)b * A.kf1_stride, o2 = (size_t)b * A.kf2_stride;
   const int n1 = A.n1[b], n2 = A.n2[b];
   const FVd V1 = fv_of(A.fv1, b), V2 = fv_of(A.fv2, b);
   const int nQ = V1.n > 0 ? V1.start[V1.n] : 0;
-  uint4 *desc2 = reinterpret_cast<uint4 *>(smem);                                    // [kf2_stride][2]
-  float4 *k2 = reinterpret_cast<float4 *>(smem + (size_t)A.kf2_stride * 32);         // x, y, angle, octave
-  int *m12 = reinterpret_cast<int *>(smem + (size_t)A.kf2_stride * 48);              // [kf1_stride]
+  const size_t descBytes = descInLds ? (size_t)A.kf2_stride * 32 : 0;
+  const uint4 *desc2 = descInLds ? reinterpret_cast<const uint4 *>(smem) : reinterpret_cast<const uint4 *>(A.desc2 + o2 * 32);
+  float4 *k2 = reinterpret_cast<float4 *>(smem + descBytes);                         // x, y, angle, octave
+  int *m12 = reinterpret_cast<int *>(smem + descBytes + (size_t)A.kf2_stride * 16);  // [kf1_stride]
   int *bins = m12 + A.kf1_stride;                                                    // [kf1_stride]
   __shared__ int s_n, s_hist[HISTO_LENGTH], s_ind[3];
   __shared__ float s_e[2], s_F[9];
   {
-    const uint4 *src = reinterpret_cast<const uint4 *>(A.desc2 + o2 * 32);
-    for (int i = tid; i < n2 * 2; i += nt) desc2[i] = src[i];
+    if (descInLds) {
+      const uint4 *src = reinterpret_cast<const uint4 *>(A.desc2 + o2 * 32);
+      uint4 *dst = reinterpret_cast<uint4 *>(smem);
+      for (int i = tid; i < n2 * 2; i += nt) dst[i] = src[i];
+    }
     for (int i = tid; i < n2; i += nt) {
       const fb_keypoint k = A.kps2[o2 + i];
       k2[i] = make_float4(k.x, k.y, k.angle, __int_as_float(k.octave));
@@ -300,11 +307,13 @@ int fb_match_bow_dev(const fb_bow_args *A, void *stream) {
   FB_TRY(fb::check_device());
   FB_ARG(A && A->batch >= 0 && A->kf_stride > 0 && A->f_stride > 0 && A->kf_fv.item_stride >= 0 && A->f_fv.item_stride >= 0);
   if (A->batch == 0) return FB_OK;
-  const size_t lds = (size_t)A->f_stride * 32 + (size_t)A->f_stride * 8 + (size_t)A->kf_fv.item_stride * 8 + 16;
+  size_t lds = (size_t)A->f_stride * 32 + (size_t)A->f_stride * 8 + (size_t)A->kf_fv.item_stride * 8 + 16;
+  const int descInLds = lds <= 160 * 1024 - 512;
+  if (!descInLds) lds -= (size_t)A->f_stride * 32;
   FB_TRY(lds_ok(lds, "fb_match_bow"));
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match_bow_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   fb::ProfScope prof_(fb::P_BOW, fb::as_stream(stream));
-  k_match_bow_t<false><<<A->batch, BOW_THREADS, lds, fb::as_stream(stream)>>>(*A, nullptr, nullptr);
+  k_match_bow_t<false><<<A->batch, BOW_THREADS, lds, fb::as_stream(stream)>>>(*A, nullptr, nullptr, descInLds);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -319,11 +328,13 @@ int fb_match_bow_kf_dev(const fb_bow_kf_args *K, void *stream) {
   A.n_kf = K->n1; A.kf_kps = K->kps1; A.kf_desc = K->desc1; A.kf_has_mp = K->has_mp1; A.kf_fv = K->fv1;
   A.n_f = K->n2; A.f_kps = K->kps2; A.f_desc = K->desc2; A.f_fv = K->fv2;
   A.matcher = K->matcher; A.match_f_to_kf = nullptr; A.nmatches = K->nmatches;
-  const size_t lds = (size_t)A.f_stride * 32 + (size_t)A.f_stride * 8 + (size_t)A.kf_fv.item_stride * 8 + 16;
+  size_t lds = (size_t)A.f_stride * 32 + (size_t)A.f_stride * 8 + (size_t)A.kf_fv.item_stride * 8 + 16;
+  const int descInLds = lds <= 160 * 1024 - 512;
+  if (!descInLds) lds -= (size_t)A.f_stride * 32;
   FB_TRY(lds_ok(lds, "fb_match_bow_kf"));
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match_bow_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   fb::ProfScope prof_(fb::P_BOW_KF, fb::as_stream(stream));
-  k_match_bow_t<true><<<A.batch, BOW_THREADS, lds, fb::as_stream(stream)>>>(A, K->has_mp2, K->matches12);
+  k_match_bow_t<true><<<A.batch, BOW_THREADS, lds, fb::as_stream(stream)>>>(A, K->has_mp2, K->matches12, descInLds);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -332,11 +343,13 @@ int fb_match_triangulation_dev(const fb_triangulation_args *A, void *stream) {
   FB_TRY(fb::check_device());
   FB_ARG(A && A->batch >= 0 && A->kf1_stride > 0 && A->kf2_stride > 0);
   if (A->batch == 0) return FB_OK;
-  const size_t lds = (size_t)A->kf2_stride * 48 + (size_t)A->kf1_stride * 8 + 16;
+  size_t lds = (size_t)A->kf2_stride * 48 + (size_t)A->kf1_stride * 8 + 16;
+  const int descInLds = lds <= 160 * 1024 - 512;
+  if (!descInLds) lds -= (size_t)A->kf2_stride * 32;
   FB_TRY(lds_ok(lds, "fb_match_triangulation"));
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match_triangulation), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   fb::ProfScope prof_(fb::P_TRIANG, fb::as_stream(stream));
-  k_match_triangulation<<<A->batch, BOW_THREADS, lds, fb::as_stream(stream)>>>(*A);
+  k_match_triangulation<<<A->batch, BOW_THREADS, lds, fb::as_stream(stream)>>>(*A, descInLds);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }

@@ -64,3 +64,28 @@ def test_keyframe_searches_large():
     g1 = P.build_grid_host([p["kps1"] for p in probs], geom, O.grid_build, n)
     g2 = P.build_grid_host([p["kps2"] for p in probs], geom, O.grid_build, n - 500)
     _both(lambda: KP.sim3_args(probs, g1, g2), "orc_match_sim3", "fb_match_sim3", ["matches12", "nfound"])
+
+
+def test_bow_matchers_large():
+    """Key frames made from the 2*nFeatures initialisation frames carry 4000 key points."""
+    from fishbirdeyevisualslam_amd import bow_problem as BP
+    probs = [BP.make_bow_problem(3200 + i, 4000, 4000) for i in range(2)]
+    a, oo, k = BP.bow_args(probs)
+    O.call("orc_match_bow", a)
+    a2, oh, k2 = BP.bow_args(probs)
+    H.call("fb_match_bow", a2)
+    np.testing.assert_array_equal(oh["match_f_to_kf"], oo["match_f_to_kf"])
+    np.testing.assert_array_equal(oh["nmatches"], oo["nmatches"])
+    probs = [M.make_bow_kf_problem(3300 + i, 4000, 3800) for i in range(2)]
+    a, oo, k = M.bow_kf_args(probs)
+    O.call("orc_match_bow_kf", a)
+    a2, oh, k2 = M.bow_kf_args(probs)
+    H.call("fb_match_bow_kf", a2)
+    np.testing.assert_array_equal(oh["matches12"], oo["matches12"])
+    probs = [BP.make_triangulation_problem(3400 + i, 4000, 4000) for i in range(2)]
+    a, oo, k = BP.triangulation_args(probs)
+    O.call("orc_match_triangulation", a)
+    a2, oh, k2 = BP.triangulation_args(probs)
+    H.call("fb_match_triangulation", a2)
+    np.testing.assert_array_equal(oh["matches12"], oo["matches12"])
+    np.testing.assert_array_equal(oh["nmatches"], oo["nmatches"])
