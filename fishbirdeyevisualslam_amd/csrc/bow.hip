@@ -206,12 +206,12 @@ int fb_bow_transform(const fb_vocabulary *HV, const fb_bow_transform_args *H) {
   FB_TRY(b0.upload(H->n_f, B * 4)); D.n_f = b0.as<int32_t>();
   FB_TRY(b1.upload(H->desc, B * fs * 32)); D.desc = b1.as<uint8_t>();
   FB_TRY(o0.alloc(B * 4)); D.n_words = o0.as<int32_t>();
-  FB_TRY(o1.alloc(B * fs * 4)); D.bow_ids = o1.as<uint32_t>();
-  FB_TRY(o2.alloc(B * fs * 8)); D.bow_vals = o2.as<double>();
+  FB_TRY(o1.upload(H->bow_ids, B * fs * 4)); D.bow_ids = o1.as<uint32_t>();  // copy-in: entries past n keep the caller's contents
+  FB_TRY(o2.upload(H->bow_vals, B * fs * 8)); D.bow_vals = o2.as<double>();
   FB_TRY(o3.alloc(B * 4)); D.fv_n_nodes = o3.as<int32_t>();
-  FB_TRY(o4.alloc(B * fs * 4)); D.fv_node_ids = o4.as<uint32_t>();
-  FB_TRY(o5.alloc(B * (fs + 1) * 4)); D.fv_node_start = o5.as<int32_t>();
-  FB_TRY(o6.alloc(B * fs * 4)); D.fv_items = o6.as<int32_t>();
+  FB_TRY(o4.upload(H->fv_node_ids, B * fs * 4)); D.fv_node_ids = o4.as<uint32_t>();
+  FB_TRY(o5.upload(H->fv_node_start, B * (fs + 1) * 4)); D.fv_node_start = o5.as<int32_t>();
+  FB_TRY(o6.upload(H->fv_items, B * fs * 4)); D.fv_items = o6.as<int32_t>();
   FB_TRY(fb_bow_transform_dev(&V, &D, nullptr));
   FB_HIP(hipDeviceSynchronize());
   FB_TRY(o0.download(H->n_words, B * 4));

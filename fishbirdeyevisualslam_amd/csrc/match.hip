@@ -938,7 +938,7 @@ int fb_match_projection_frame(const fb_proj_frame_args *H) {
   UP(b10, last_xw, B * ls * 12) UP(b11, last_desc, B * ls * 32) UP(b12, last_octave, B * ls * 4)
   UP(b13, last_angle, B * ls * 4)
   fb::DevBuf o0, o1;
-  FB_TRY(o0.alloc(B * cs * 4));
+  FB_TRY(o0.upload(H->match_cur_to_last, B * cs * 4));  // copy-in: entries past n keep the caller's contents
   FB_TRY(o1.alloc(B * 4));
   D.match_cur_to_last = o0.as<int32_t>();
   D.nmatches = o1.as<int32_t>();
@@ -959,7 +959,7 @@ int fb_match_projection_keyframe(const fb_proj_kf_args *H) {
   UP(b10, kf_desc, B * ks * 32) UP(b11, kf_max_dist, B * ks * 4) UP(b12, kf_min_dist, B * ks * 4)
   UP(b13, kf_angle, B * ks * 4)
   fb::DevBuf o0, o1;
-  FB_TRY(o0.alloc(B * cs * 4));
+  FB_TRY(o0.upload(H->match_cur_to_kf, B * cs * 4));
   FB_TRY(o1.alloc(B * 4));
   D.match_cur_to_kf = o0.as<int32_t>();
   D.nmatches = o1.as<int32_t>();
@@ -979,7 +979,7 @@ int fb_match_projection_points(const fb_proj_points_args *H) {
   UP(b6, n_mp, B * 4) UP(b7, mp_track, B * ms) UP(b8, mp_obs_pos, B * ms) UP(b9, mp_proj, B * ms * 8)
   UP(b10, mp_level, B * ms * 4) UP(b11, mp_view_cos, B * ms * 4) UP(b12, mp_desc, B * ms * 32)
   fb::DevBuf o0, o1;
-  FB_TRY(o0.alloc(B * cs * 4));
+  FB_TRY(o0.upload(H->match_cur_to_mp, B * cs * 4));
   FB_TRY(o1.alloc(B * 4));
   D.match_cur_to_mp = o0.as<int32_t>();
   D.nmatches = o1.as<int32_t>();
@@ -1018,8 +1018,8 @@ int fb_match_birdview(const fb_birdview_args *H) {
   UP(b3, cur_cell_start, B * (ncell + 1) * 4) UP(b4, cur_cell_items, B * cs * 4) UP(b5, n_ref, B * 4)
   UP(b6, ref_kps, B * rs * sizeof(fb_keypoint)) UP(b7, ref_desc, B * rs * 32)
   fb::DevBuf o0, o1, o2, o3;
-  FB_TRY(o0.alloc(B * rs * 4));
-  FB_TRY(o1.alloc(B * rs * 4));
+  FB_TRY(o0.upload(H->match_ref_to_cur, B * rs * 4));
+  FB_TRY(o1.upload(H->match_dist, B * rs * 4));
   FB_TRY(o2.alloc(B * 4));
   FB_TRY(o3.alloc(B * 4));
   D.match_ref_to_cur = o0.as<int32_t>();

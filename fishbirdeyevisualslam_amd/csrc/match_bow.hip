@@ -369,7 +369,7 @@ int fb_match_bow(const fb_bow_args *H) {
   FB_TRY(u1.up(H->kf_fv, D.kf_fv, B));
   FB_TRY(u2.up(H->f_fv, D.f_fv, B));
   fb::DevBuf o0, o1;
-  FB_TRY(o0.alloc(B * fs * 4));
+  FB_TRY(o0.upload(H->match_f_to_kf, B * fs * 4));  // copy-in: entries past n keep the caller's contents
   FB_TRY(o1.alloc(B * 4));
   D.match_f_to_kf = o0.as<int32_t>();
   D.nmatches = o1.as<int32_t>();
@@ -390,7 +390,7 @@ int fb_match_bow_kf(const fb_bow_kf_args *H) {
   FB_TRY(u1.up(H->fv1, D.fv1, B));
   FB_TRY(u2.up(H->fv2, D.fv2, B));
   fb::DevBuf o0, o1;
-  FB_TRY(o0.alloc(B * s1 * 4));
+  FB_TRY(o0.upload(H->matches12, B * s1 * 4));
   FB_TRY(o1.alloc(B * 4));
   D.matches12 = o0.as<int32_t>();
   D.nmatches = o1.as<int32_t>();
@@ -412,7 +412,7 @@ int fb_match_triangulation(const fb_triangulation_args *H) {
   FB_TRY(u1.up(H->fv1, D.fv1, B));
   FB_TRY(u2.up(H->fv2, D.fv2, B));
   fb::DevBuf o0, o1;
-  FB_TRY(o0.alloc(B * s1 * 4));
+  FB_TRY(o0.upload(H->matches12, B * s1 * 4));
   FB_TRY(o1.alloc(B * 4));
   D.matches12 = o0.as<int32_t>();
   D.nmatches = o1.as<int32_t>();

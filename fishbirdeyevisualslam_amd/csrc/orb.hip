@@ -991,6 +991,10 @@ int prepare(fb_orb *o, int w, int h, int batch) {
     L.w = fb_cvround((float)w * scale);   // ORBextractor.cc:1112
     L.h = fb_cvround((float)h * scale);
     if (l == 0) { L.w = w; L.h = h; }
+    if (L.w < 1 || L.h < 1) {  // cv::resize to an empty Size asserts in the reference as well
+      fb::set_error("pyramid level %d of a %dx%d image is empty (scale factor %.3f, %d levels)", l, w, h, (double)p.scale_factor, p.nlevels);
+      return FB_ERR_ARG;
+    }
     if (L.w >= 4096 || L.h >= 4096) { fb::set_error("image too large (level %d is %dx%d, limit 4095)", l, L.w, L.h); return FB_ERR_ARG; }
     L.pitch = (L.w + 63) & ~63;
     L.off = pyrOff;
@@ -998,7 +1002,8 @@ int prepare(fb_orb *o, int w, int h, int batch) {
     L.boff = blurOff;
     blurOff += (long long)L.pitch * L.h;
     K.blurStrips[l] = strips;
-    strips += ((L.w + 255) / 256) * ((L.h + BLUR_ROWS - 1) / BLUR_ROWS);
+    // levels too small to hold a key point (19 px border on every side) are never sampled: no blur strips for them
+    if (L.w >= 2 * EDGE_THRESHOLD && L.h >= 2 * EDGE_THRESHOLD) strips += ((L.w + 255) / 256) * ((L.h + BLUR_ROWS - 1) / BLUR_ROWS);
     const int maxBX = L.w - BORDER, maxBY = L.h - BORDER;
     const float width = (float)(maxBX - BORDER), height = (float)(maxBY - BORDER);
     L.nCols = (int)(width / 30.f);

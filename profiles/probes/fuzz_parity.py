@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Randomised HIP-vs-oracle parity sweep (ORB extraction on odd sizes / parameters, windowed matchers on odd counts).
+Not part of the test suite: a few hundred random cases, prints every mismatch.  usage: fuzz_parity.py [seconds]"""
+import sys, time
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+import hip_lib as H, oracle_lib as O
+from fishbirdeyevisualslam_amd import kf_problems as KP, more_problems as M, problems as P, synth
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+g = np.random.default_rng(12345)
+t_end = time.time() + budget
+n_cases = n_bad = 0
+exc_count = {}
+
+
+def both(build, on, hn, keys):
+    a, oo, k = build(); O.call(on, a)
+    a2, oh, k2 = build(); H.call(hn, a2)
+    return all(np.array_equal(oh[x], oo[x]) for x in keys)
+
+
+while time.time() < t_end:
+    kind = int(g.integers(0, 6))
+    seed = int(g.integers(0, 1 << 30))
+    try:
+        if kind == 0:      # ORB extraction
+            w, h = int(g.integers(60, 900)), int(g.integers(60, 700))
+            p = O.orb_params(nfeatures=int(g.integers(50, 3000)), nlevels=int(g.integers(1, 9)),
+                             scale_factor=float(np.float32(g.uniform(1.05, 2.2))), ini_th_fast=int(g.integers(8, 40)),
+                             min_th_fast=int(g.integers(2, 8)))
+            img = synth.synth_image(seed, w, h) if g.random() < 0.8 else g.integers(0, 256, (h, w), dtype=np.uint8)
+            orb = H.Orb(p); kh, dh = orb.extract(img); orb.close()
+            ko, do = O.orb_extract(p, img)
+            ok = len(kh) == len(ko) and np.array_equal(kh, ko) and np.array_equal(dh, do)
+            desc = "orb %dx%d nf=%d nl=%d sf=%.3f ini=%d min=%d" % (w, h, p.nfeatures, p.nlevels, p.scale_factor, p.ini_th_fast, p.min_th_fast)
+        else:
+            ncur, nq = int(g.integers(0, 2600)), int(g.integers(0, 2600))
+            geomF = P.grid_geom(synth.front_grid_geom(1280, 720))
+            geomB = P.grid_geom(synth.bird_grid_geom(512, 512))
+            B = int(g.integers(1, 4))
+            if kind == 1:
+                probs = [synth.make_proj_frame_problem(seed + i, max(ncur, 1), nq, dup_frac=float(g.uniform(0, 0.5))) for i in range(B)]
+                cs, ci = P.build_grid_host([p["cur_kps"] for p in probs], geomF, O.grid_build, max(ncur, 1))
+                th = float(g.choice([7.0, 15.0, 30.0, 60.0]))
+                ok = both(lambda: P.proj_frame_args(probs, cs, ci, th=th, check_ori=int(g.integers(0, 2)) * 0 + 1), "orc_match_projection_frame", "fb_match_projection_frame", ["match_cur_to_last", "nmatches"])
+                desc = "m3 ncur=%d nlast=%d B=%d th=%g" % (ncur, nq, B, th)
+            elif kind == 2:
+                probs = [synth.make_proj_points_problem(seed + i, max(ncur, 1), max(nq, 1)) for i in range(B)]
+                cs, ci = P.build_grid_host([p["cur_kps"] for p in probs], geomF, O.grid_build, max(ncur, 1))
+                th = float(g.choice([1.0, 3.0, 5.0]))
+                ok = both(lambda: P.proj_points_args(probs, cs, ci, th=th), "orc_match_projection_points", "fb_match_projection_points", ["match_cur_to_mp", "nmatches"])
+                desc = "m2 ncur=%d nmp=%d B=%d th=%g" % (ncur, nq, B, th)
+            elif kind == 3:
+                probs = [synth.make_bird_mp_problem(seed + i, max(ncur, 1), nq) for i in range(B)]
+                cs, ci = P.build_grid_host([p["cur_kps"] for p in probs], geomB, O.grid_build, max(ncur, 1))
+                ok = both(lambda: P.bird_mp_args(probs, cs, ci, prefill=-1), "orc_match_bird_mappoints", "fb_match_bird_mappoints", ["match_cur_to_ref", "ninliers"])
+                desc = "m9 ncur=%d nref=%d B=%d" % (ncur, nq, B)
+            elif kind == 4:
+                probs = [M.make_proj_kf_problem(seed + i, max(ncur, 1), nq) for i in range(B)]
+                cs, ci = P.build_grid_host([p["cur_kps"] for p in probs], geomF, O.grid_build, max(ncur, 1))
+                th = float(g.choice([3.0, 10.0, 40.0]))
+                ok = both(lambda: M.proj_kf_args(probs, cs, ci, th=th), "orc_match_projection_keyframe", "fb_match_projection_keyframe", ["match_cur_to_kf", "nmatches"])
+                desc = "m4 ncur=%d nkf=%d B=%d th=%g" % (ncur, nq, B, th)
+            else:
+                sim3 = bool(g.integers(0, 2))
+                probs = [KP.make_kf_points_problem(seed + i, max(ncur, 1), nq, sim3) for i in range(B)]
+                cs, ci = P.build_grid_host([p["kf_kps"] for p in probs], P.grid_geom(synth.front_grid_geom(KP.W, KP.H)), O.grid_build, max(ncur, 1))
+                thf, thi = float(g.choice([3.0, 8.0])), int(g.choice([5, 10, 40]))
+                ok = both(lambda: KP.fuse_args(probs, cs, ci, th=thf), "orc_fuse_sim3_search" if sim3 else "orc_fuse_search",
+                          "fb_fuse_sim3_search" if sim3 else "fb_fuse_search", ["best_idx"])
+                if sim3:
+                    ok = ok and both(lambda: KP.proj_sim3_args(probs, cs, ci, th=thi), "orc_match_projection_sim3", "fb_match_projection_sim3", ["match_kf_to_mp", "nmatches"])
+                desc = "fuse sim3=%s nkf=%d nmp=%d B=%d" % (sim3, ncur, nq, B)
+    except Exception as e:  # capacity errors are fine, anything else is reported
+        msg = str(e)
+        ok = any(t in msg.lower() for t in ("capacity", "too large", "exceed", "bad argument", "is empty"))
+        desc = "EXC kind=%d %s" % (kind, msg[:160])
+        if kind == 0:
+            desc += " | orb %dx%d nf=%d nl=%d sf=%.3f" % (w, h, p.nfeatures, p.nlevels, p.scale_factor)
+        exc_count[(kind, msg[:70])] = exc_count.get((kind, msg[:70]), 0) + 1
+    n_cases += 1
+    if not ok:
+        n_bad += 1
+        print("MISMATCH:", desc, flush=True)
+print("fuzz: %d cases, %d mismatches" % (n_cases, n_bad))
+for k, v in sorted(exc_count.items(), key=lambda kv: -kv[1])[:12]:
+    print("  exceptions x%d: kind %d: %s" % (v, k[0], k[1]))

@@ -90,3 +90,16 @@ def test_extract_other_pyramids(scale, nlevels, nfeat):
 def test_extract_4k_image():
     """3840x2160: 8820 FAST cells on level 0 (beyond the 12-bit cell index of the first quadtree key layout)."""
     _check_image(O.orb_params(nfeatures=4000), synth.synth_image(77, 3840, 2160), stagewise=False)
+
+
+def test_extract_degenerate_pyramid_levels():
+    """Levels too small to hold a key point (a few pixels wide) are still resized for the chain but never blurred or
+    sampled; a level that rounds to 0 px is refused (cv::resize asserts on an empty Size in the reference too)."""
+    img = synth.synth_image(5, 100, 80)
+    _check_image(O.orb_params(nfeatures=500, scale_factor=2.0, nlevels=7), img, stagewise=False)
+    orb = H.Orb(O.orb_params(nfeatures=500, scale_factor=2.2, nlevels=8))
+    try:
+        with pytest.raises(RuntimeError, match="is empty"):
+            orb.extract(img)
+    finally:
+        orb.close()
