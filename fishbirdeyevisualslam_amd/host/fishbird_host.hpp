@@ -3,7 +3,9 @@
 //   ORBextractor  (include/ORBextractor.h:51-85)
 //   ORBmatcher    (include/ORBmatcher.h:41-88)      SearchByProjection x2, BirdMapPointMatch, BirdviewMatch
 //   Optimizer     (include/Optimizer.h:40-68)       PoseOptimization, PoseOptimizationWithBird, BirdOptimization,
-//                                                   LocalBundleAdjustment[WithOdom]
+//                                                   LocalBundleAdjustment[WithOdom] (flat graph, or KeyFrame*/Map* as
+//                                                   in the reference: fishbird_map.hpp collects the graph),
+//                                                   BundleAdjustmentWithOdom / GlobalBundleAdjustemntWithOdom
 // on plain-old-data frames (the reference's Frame/KeyFrame/MapPoint own OpenCV and graph state that stays in the
 // host application).  Header only; link with -lfishbird_hip.  Errors throw std::runtime_error(fb_last_error()).
 #ifndef FISHBIRD_HOST_HPP_
@@ -16,6 +18,7 @@
 #include <vector>
 
 #include "../../include/fishbird.h"
+#include "fishbird_map.hpp"
 
 namespace fishbird {
 
@@ -305,6 +308,81 @@ class Optimizer {
     graph.wF = wF; graph.wB = wB; graph.wP = wP;
     graph.stop_flag = reinterpret_cast<volatile uint8_t *>(pbStopFlag);
     check(fb_local_ba(&graph));
+  }
+
+  // ---- the reference signatures on the map stand-ins of fishbird_map.hpp --------------------------------------------
+  // LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap), Optimizer.cc:838-1165
+  static void LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map * /*pMap*/) {
+    BAGraph G;
+    collectLocalGraph(pKF, false, G);
+    if (pbStopFlag && *pbStopFlag) return;  // :1042-1044
+    fb_local_ba_args a = G.args(pKF, 0, 1.f, 1.f, 3.f, pbStopFlag);
+    check(fb_local_ba(&a));
+    writeBackLocal(G, false);
+  }
+  // LocalBundleAdjustmentWithOdom(pKF, pbStopFlag, pMap, wF, wB, wP), Optimizer.cc:2137-2670
+  static void LocalBundleAdjustmentWithOdom(KeyFrame *pKF, bool *pbStopFlag, Map * /*pMap*/, float wF = 1.f, float wB = 1.f,
+                                            float wP = 3.f) {
+    BAGraph G;
+    collectLocalGraph(pKF, switches().bHaveBird, G);
+    if (switches().bTightCouple) G.addOdometryChain(wP);
+    if (pbStopFlag && *pbStopFlag) return;  // :2497-2499
+    fb_local_ba_args a = G.args(pKF, 1, wF, wB, wP, pbStopFlag);
+    check(fb_local_ba(&a));
+    writeBackLocal(G, switches().bHaveBird);
+  }
+  // BundleAdjustmentWithOdom(vpKFs, vpMP, vpMPB, nIterations, pbStopFlag, nLoopKF, bRobust, wF, wB, wP), Optimizer.cc:1787-2135
+  static void BundleAdjustmentWithOdom(const std::vector<KeyFrame *> &vpKFs, const std::vector<MapPoint *> &vpMP,
+                                       const std::vector<MapPointBird *> &vpMPB, int nIterations = 5, bool *pbStopFlag = nullptr,
+                                       unsigned long nLoopKF = 0, bool bRobust = true, float wF = 1.f, float wB = 1.f,
+                                       float wP = 3.f) {
+    BAGraph G;
+    long maxKFid = 0;
+    const KeyFrame *first = nullptr;
+    for (size_t i = 0; i < vpKFs.size(); i++) {
+      KeyFrame *pKF = vpKFs[i];
+      if (pKF->isBad()) continue;
+      G.addKeyFrame(pKF, pKF->mnId == 0);
+      if (!first) first = pKF;
+      if ((long)pKF->mnId > maxKFid) maxKFid = (long)pKF->mnId;
+    }
+    G.nLocal = G.kfs.size();
+    if (!first) return;
+    std::vector<bool> vbNotIncludedMP(vpMP.size(), true), vbNotIncludedMPBird(vpMPB.size(), true);
+    for (size_t i = 0; i < vpMP.size(); i++) {
+      if (vpMP[i]->isBad()) continue;
+      if (G.addMapPoint(vpMP[i], maxKFid) == 0) G.popMapPoint();
+      else vbNotIncludedMP[i] = false;
+    }
+    if (switches().bHaveBird)
+      for (size_t i = 0; i < vpMPB.size(); i++) {
+        if (vpMPB[i]->isBad()) continue;
+        if (G.addMapPointBird(vpMPB[i]) == 0) G.popMapPointBird();
+        else vbNotIncludedMPBird[i] = false;
+      }
+    fb_local_ba_args a = G.args(first, 1, wF, wB, wP, pbStopFlag);
+    check(fb_global_ba(&a, nIterations, bRobust ? 1 : 0));
+    for (size_t k = 0; k < G.kfs.size(); k++) {
+      KeyFrame *pKF = G.kfs[k];
+      if (nLoopKF == 0) pKF->SetPose(&G.kfTcw[12 * k]);
+      else { std::memcpy(pKF->mTcwGBA, &G.kfTcw[12 * k], 48); pKF->mnBAGlobalForKF = nLoopKF; }
+    }
+    for (size_t j = 0; j < G.mps.size(); j++) {
+      MapPoint *pMP = G.mps[j];
+      if (nLoopKF == 0) { pMP->SetWorldPos(&G.mpXw[3 * j]); pMP->UpdateNormalAndDepth(); }
+      else { std::memcpy(pMP->mPosGBA, &G.mpXw[3 * j], 12); pMP->mnBAGlobalForKF = nLoopKF; }
+    }
+    for (size_t j = 0; j < G.mpbs.size(); j++) {
+      MapPointBird *pMPB = G.mpbs[j];
+      if (nLoopKF == 0) pMPB->SetWorldPos(&G.mpbXw[3 * j]);
+      else { std::memcpy(pMPB->mPosGBA, &G.mpbXw[3 * j], 12); pMPB->mnBAGlobalForKF = nLoopKF; }
+    }
+  }
+  // GlobalBundleAdjustemntWithOdom(pMap, nIterations, pbStopFlag, nLoopKF, bRobust), Optimizer.cc:1778-1785 (sic)
+  static void GlobalBundleAdjustemntWithOdom(Map *pMap, int nIterations = 5, bool *pbStopFlag = nullptr,
+                                             unsigned long nLoopKF = 0, bool bRobust = true) {
+    BundleAdjustmentWithOdom(pMap->GetAllKeyFrames(), pMap->GetAllMapPoints(), pMap->GetAllMapPointsBird(), nIterations,
+                             pbStopFlag, nLoopKF, bRobust);
   }
 
  private:

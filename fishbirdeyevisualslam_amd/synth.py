@@ -410,4 +410,4 @@ def make_ba_problem(seed=4000, n_kf=20, n_fixed=2, n_mp=8000, n_mpb=2000, w=1280
                 bobs_xc=np.array(bobs_xc, np.float32).reshape(-1, 3), bobs_inv_sigma2=np.array(bobs_inf, np.float32),
                 odom_kf_i=np.array(oi, np.int32), odom_kf_j=np.array(oj, np.int32),
                 odom_Tij=np.stack([to12(T) for T in oT]) if oT else np.zeros((0, 12), np.float32),
-                odom_info=np.array(oinfo, np.float64))
+                odom_info=np.array(oinfo, np.float64), odo=np.array(odo_n, np.float64).reshape(-1, 3))
