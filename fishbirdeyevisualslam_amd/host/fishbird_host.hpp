@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <set>
 #include <stdexcept>
 #include <vector>
 
@@ -53,6 +54,7 @@ struct Frame {
   // front
   std::vector<fb_keypoint> mvKeysUn;
   std::vector<uint8_t> mDescriptors;          // N x 32
+  FeatureVector mFeatVec;                     // Frame::ComputeBoW (fb_bow_transform)
   std::vector<int32_t> mvpMapPoints;          // index into the caller's map-point table, -1 = NULL
   std::vector<uint8_t> mvpMapPointHasObs;     // Observations()>0 of the point currently in slot i
   std::vector<uint8_t> mvbOutlier;
@@ -172,6 +174,42 @@ class ORBextractor {
   fb_orb_tables t_;
 };
 
+// ---- ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>, TemplatedVocabulary.h) ------------------
+// The tree as flat arrays (fb_vocabulary).  transform() is Frame::ComputeBoW / KeyFrame::ComputeBoW (Frame.cc:628-635):
+// mBowVec as word id -> value, mFeatVec as NodeId -> feature indices.
+typedef std::map<uint32_t, double> BowVector;
+class ORBVocabulary {
+ public:
+  int L = 0;
+  std::vector<int32_t> child_start{0}, children, word_ids;
+  std::vector<uint8_t> descriptors;
+  std::vector<double> weights;
+
+  void transform(const std::vector<uint8_t> &features, BowVector &v, FeatureVector &fv, int levelsup) const {
+    v.clear();
+    fv.clear();
+    const int32_t n = (int32_t)(features.size() / 32);
+    if (n == 0) return;
+    fb_vocabulary V{};
+    V.n_nodes = (int32_t)word_ids.size(); V.L = L; V.child_start = child_start.data(); V.children = children.data();
+    V.descriptors = descriptors.data(); V.weights = weights.data(); V.word_ids = word_ids.data();
+    std::vector<uint32_t> bid(n), nid(n);
+    std::vector<double> bval(n);
+    std::vector<int32_t> nstart(n + 1), items(n);
+    int32_t nw = 0, nn = 0;
+    fb_bow_transform_args a{};
+    a.batch = 1; a.f_stride = n; a.n_f = &n; a.desc = features.data(); a.levelsup = levelsup;
+    a.n_words = &nw; a.bow_ids = bid.data(); a.bow_vals = bval.data();
+    a.fv_n_nodes = &nn; a.fv_node_ids = nid.data(); a.fv_node_start = nstart.data(); a.fv_items = items.data();
+    check(fb_bow_transform(&V, &a));
+    for (int i = 0; i < nw; i++) v[bid[i]] = bval[i];
+    for (int k = 0; k < nn; k++) {
+      std::vector<unsigned> &dst = fv[nid[k]];
+      for (int j = nstart[k]; j < nstart[k + 1]; j++) dst.push_back((unsigned)items[j]);
+    }
+  }
+};
+
 // ---- ORBmatcher --------------------------------------------------------------------------------------------------
 class ORBmatcher {
  public:
@@ -278,7 +316,325 @@ class ORBmatcher {
     return ninl;
   }
 
+  // ================= key-frame side (LocalMapping / LoopClosing / relocalisation / initialisation) =================
+  // SearchByBoW(pKF, F, vpMapPointMatches), ORBmatcher.cc:160-289
+  int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches) const {
+    const std::vector<MapPoint *> vpMapPointsKF = pKF->GetMapPointMatches();
+    const int32_t NK = pKF->N(), NF = F.N();
+    vpMapPointMatches.assign(NF, nullptr);
+    if (NK == 0 || NF == 0) return 0;
+    std::vector<uint8_t> has(NK);
+    for (int i = 0; i < NK; i++) has[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();
+    FvFlat fk(pKF->mFeatVec), ff(F.mFeatVec);
+    std::vector<int32_t> match(NF, -1);
+    int32_t n = 0;
+    fb_bow_args a{};
+    a.batch = 1; a.kf_stride = NK; a.f_stride = NF;
+    a.n_kf = &NK; a.kf_kps = pKF->mvKeysUn.data(); a.kf_desc = pKF->mDescriptors.data(); a.kf_has_mp = has.data(); a.kf_fv = fk.view();
+    a.n_f = &NF; a.f_kps = F.mvKeysUn.data(); a.f_desc = F.mDescriptors.data(); a.f_fv = ff.view();
+    a.matcher = m_; a.match_f_to_kf = match.data(); a.nmatches = &n;
+    check(fb_match_bow(&a));
+    for (int i = 0; i < NF; i++) if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];
+    return n;
+  }
+
+  // SearchByBoW(pKF1, pKF2, vpMatches12), ORBmatcher.cc:523-656
+  int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12) const {
+    const std::vector<MapPoint *> mp1 = pKF1->GetMapPointMatches(), mp2 = pKF2->GetMapPointMatches();
+    const int32_t N1 = pKF1->N(), N2 = pKF2->N();
+    vpMatches12.assign(N1, nullptr);
+    if (N1 == 0 || N2 == 0) return 0;
+    std::vector<uint8_t> h1(N1), h2(N2);
+    for (int i = 0; i < N1; i++) h1[i] = mp1[i] && !mp1[i]->isBad();
+    for (int i = 0; i < N2; i++) h2[i] = mp2[i] && !mp2[i]->isBad();
+    FvFlat f1(pKF1->mFeatVec), f2(pKF2->mFeatVec);
+    std::vector<int32_t> m12(N1, -1);
+    int32_t n = 0;
+    fb_bow_kf_args a{};
+    a.batch = 1; a.kf1_stride = N1; a.kf2_stride = N2;
+    a.n1 = &N1; a.kps1 = pKF1->mvKeysUn.data(); a.desc1 = pKF1->mDescriptors.data(); a.has_mp1 = h1.data(); a.fv1 = f1.view();
+    a.n2 = &N2; a.kps2 = pKF2->mvKeysUn.data(); a.desc2 = pKF2->mDescriptors.data(); a.has_mp2 = h2.data(); a.fv2 = f2.view();
+    a.matcher = m_; a.matches12 = m12.data(); a.nmatches = &n;
+    check(fb_match_bow_kf(&a));
+    for (int i = 0; i < N1; i++) if (m12[i] >= 0) vpMatches12[i] = mp2[m12[i]];
+    return n;
+  }
+
+  // SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo), ORBmatcher.cc:658-824.  F12 row-major 3x3.
+  int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, const float F12[9], std::vector<std::pair<size_t, size_t>> &vMatchedPairs,
+                             bool bOnlyStereo) const {
+    vMatchedPairs.clear();
+    const int32_t N1 = pKF1->N(), N2 = pKF2->N();
+    if (bOnlyStereo || N1 == 0 || N2 == 0) return 0;  // monocular key frames: every candidate fails the stereo test (:701-703)
+    std::vector<uint8_t> h1(N1), h2(N2);
+    for (int i = 0; i < N1; i++) h1[i] = pKF1->GetMapPoint(i) != nullptr;
+    for (int i = 0; i < N2; i++) h2[i] = pKF2->GetMapPoint(i) != nullptr;
+    FvFlat f1(pKF1->mFeatVec), f2(pKF2->mFeatVec);
+    float R2w[9], t2w[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R2w[r * 3 + c] = pKF2->Tcw[r * 4 + c]; t2w[r] = pKF2->Tcw[r * 4 + 3]; }
+    std::vector<int32_t> m12(N1, -1);
+    int32_t n = 0;
+    fb_triangulation_args a{};
+    a.batch = 1; a.kf1_stride = N1; a.kf2_stride = N2;
+    a.n1 = &N1; a.kps1 = pKF1->mvKeysUn.data(); a.desc1 = pKF1->mDescriptors.data(); a.has_mp1 = h1.data(); a.fv1 = f1.view();
+    a.n2 = &N2; a.kps2 = pKF2->mvKeysUn.data(); a.desc2 = pKF2->mDescriptors.data(); a.has_mp2 = h2.data(); a.fv2 = f2.view();
+    a.F12 = F12; a.Cw1 = pKF1->GetCameraCenter(); a.R2w = R2w; a.t2w = t2w;
+    a.fx = pKF2->fx; a.fy = pKF2->fy; a.cx = pKF2->cx; a.cy = pKF2->cy;
+    for (size_t i = 0; i < pKF2->mvScaleFactors.size() && i < FB_MAX_LEVELS; i++) a.scale_factors[i] = pKF2->mvScaleFactors[i];
+    for (size_t i = 0; i < pKF2->mvLevelSigma2.size() && i < FB_MAX_LEVELS; i++) a.level_sigma2[i] = pKF2->mvLevelSigma2[i];
+    a.matcher = m_; a.matches12 = m12.data(); a.nmatches = &n;
+    check(fb_match_triangulation(&a));
+    for (int i = 0; i < N1; i++) if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));
+    return n;
+  }
+
+  // Fuse(pKF, vpMapPoints, th), ORBmatcher.cc:826-976: batched search, then the map mutation in list order
+  int Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, float th = 3.f) const {
+    const int32_t nMPs = (int32_t)vpMapPoints.size();
+    if (nMPs == 0 || pKF->N() == 0) return 0;
+    KfFlat kf(pKF);
+    MpFlat mp(vpMapPoints, [&](MapPoint *p) { return p && !p->isBad() && !p->IsInKeyFrame(pKF); });
+    std::vector<int32_t> best(nMPs, -1);
+    fb_fuse_args a{};
+    a.batch = 1; a.kf = kf.t; a.mp = mp.view(); a.pose = pKF->Tcw; a.Ow = pKF->GetCameraCenter(); a.th = th; a.best_idx = best.data();
+    check(fb_fuse_search(&a));
+    int nFused = 0;
+    for (int i = 0; i < nMPs; i++) {
+      MapPoint *pMP = vpMapPoints[i];
+      // re-evaluated in order: an earlier Replace / AddObservation of this loop can have changed it (:846-850)
+      if (!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF) || best[i] < 0) continue;
+      MapPoint *pMPinKF = pKF->GetMapPoint(best[i]);
+      if (pMPinKF) {
+        if (!pMPinKF->isBad()) {
+          if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+          else pMPinKF->Replace(pMP);
+        }
+      } else {
+        pMP->AddObservation(pKF, best[i]);
+        pKF->AddMapPoint(pMP, best[i]);
+      }
+      nFused++;
+    }
+    return nFused;
+  }
+
+  // Fuse(pKF, Scw, vpPoints, th, vpReplacePoint), ORBmatcher.cc:978-1101.  Scw = rows 0..2 of the 4x4.
+  int Fuse(KeyFrame *pKF, const float Scw[12], const std::vector<MapPoint *> &vpPoints, float th,
+           std::vector<MapPoint *> &vpReplacePoint) const {
+    const int32_t nPoints = (int32_t)vpPoints.size();
+    if (nPoints == 0 || pKF->N() == 0) return 0;
+    const std::set<MapPoint *> spAlreadyFound = pKF->GetMapPoints();
+    KfFlat kf(pKF);
+    MpFlat mp(vpPoints, [&](MapPoint *p) { return p && !p->isBad() && !spAlreadyFound.count(p); });
+    std::vector<int32_t> best(nPoints, -1);
+    fb_fuse_args a{};
+    a.batch = 1; a.kf = kf.t; a.mp = mp.view(); a.pose = Scw; a.Ow = nullptr; a.th = th; a.best_idx = best.data();
+    check(fb_fuse_sim3_search(&a));
+    int nFused = 0;
+    for (int i = 0; i < nPoints; i++) {
+      if (best[i] < 0) continue;
+      MapPoint *pMP = vpPoints[i];
+      MapPoint *pMPinKF = pKF->GetMapPoint(best[i]);
+      if (pMPinKF) {
+        if (!pMPinKF->isBad()) vpReplacePoint[i] = pMPinKF;
+      } else {
+        pMP->AddObservation(pKF, best[i]);
+        pKF->AddMapPoint(pMP, best[i]);
+      }
+      nFused++;
+    }
+    return nFused;
+  }
+
+  // SearchByProjection(pKF, Scw, vpPoints, vpMatched, th), ORBmatcher.cc:291-404
+  int SearchByProjection(KeyFrame *pKF, const float Scw[12], const std::vector<MapPoint *> &vpPoints, std::vector<MapPoint *> &vpMatched,
+                         int th) const {
+    const int32_t N = pKF->N();
+    if (vpPoints.empty() || N == 0) return 0;
+    std::set<MapPoint *> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+    spAlreadyFound.erase(nullptr);
+    KfFlat kf(pKF);
+    MpFlat mp(vpPoints, [&](MapPoint *p) { return p && !p->isBad() && !spAlreadyFound.count(p); });
+    std::vector<uint8_t> matched(N);
+    for (int i = 0; i < N; i++) matched[i] = vpMatched[i] != nullptr;
+    std::vector<int32_t> out(N, -1);
+    int32_t n = 0;
+    fb_proj_sim3_args a{};
+    a.batch = 1; a.kf = kf.t; a.mp = mp.view(); a.Scw = Scw; a.kf_matched = matched.data(); a.th = th;
+    a.match_kf_to_mp = out.data(); a.nmatches = &n;
+    check(fb_match_projection_sim3(&a));
+    for (int i = 0; i < N; i++) if (out[i] >= 0) vpMatched[i] = vpPoints[out[i]];
+    return n;
+  }
+
+  // SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th), ORBmatcher.cc:1103-1327.  R12 row-major 3x3.
+  int SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12, float s12, const float R12[9],
+                   const float t12[3], float th) const {
+    const std::vector<MapPoint *> vp1 = pKF1->GetMapPointMatches(), vp2 = pKF2->GetMapPointMatches();
+    const int N1 = (int)vp1.size(), N2 = (int)vp2.size();
+    if (N1 == 0 || N2 == 0) return 0;
+    std::vector<bool> am1(N1, false), am2(N2, false);
+    for (int i = 0; i < N1; i++) {
+      MapPoint *pMP = vpMatches12[i];
+      if (!pMP) continue;
+      am1[i] = true;
+      const int idx2 = pMP->GetIndexInKeyFrame(pKF2);
+      if (idx2 >= 0 && idx2 < N2) am2[idx2] = true;
+    }
+    KfFlat k1(pKF1), k2(pKF2);
+    int i1 = 0, i2 = 0;
+    MpFlat m1(vp1, [&](MapPoint *p) { const bool ok = p && !am1[i1] && !p->isBad(); i1++; return ok; });
+    MpFlat m2(vp2, [&](MapPoint *p) { const bool ok = p && !am2[i2] && !p->isBad(); i2++; return ok; });
+    std::vector<int32_t> m12(N1, -1);
+    int32_t n = 0;
+    fb_sim3_args a{};
+    a.batch = 1; a.kf1 = k1.t; a.kf2 = k2.t; a.mp1 = m1.view(); a.mp2 = m2.view();
+    a.T1w = pKF1->Tcw; a.T2w = pKF2->Tcw; a.s12 = &s12; a.R12 = R12; a.t12 = t12; a.th = th;
+    a.matches12 = m12.data(); a.nfound = &n;
+    check(fb_match_sim3(&a));
+    for (int i = 0; i < N1; i++) if (m12[i] >= 0) vpMatches12[i] = vp2[m12[i]];
+    return n;
+  }
+
+  // SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize), ORBmatcher.cc:406-521.
+  // vbPrevMatched: N1 x (x, y), updated in place with the matched F2 positions (:514-517).
+  int SearchForInitialization(Frame &F1, Frame &F2, std::vector<float> &vbPrevMatched, std::vector<int> &vnMatches12,
+                              int windowSize = 10) const {
+    const int32_t N1 = F1.N(), N2 = F2.N();
+    vnMatches12.assign(N1, -1);
+    if (N1 == 0 || N2 == 0) return 0;
+    std::vector<int32_t> m12(N1, -1);
+    int32_t n = 0;
+    fb_init_match_args a{};
+    a.batch = 1; a.f1_stride = N1; a.f2_stride = N2;
+    a.n1 = &N1; a.kps1 = F1.mvKeysUn.data(); a.desc1 = F1.mDescriptors.data();
+    a.n2 = &N2; a.kps2 = F2.mvKeysUn.data(); a.desc2 = F2.mDescriptors.data();
+    a.f2_cell_start = F2.gridStart.data(); a.f2_cell_items = F2.gridItems.data(); a.grid = F2.frontGrid();
+    a.window_size = windowSize; a.matcher = m_;
+    a.prev_matched = vbPrevMatched.data(); a.matches12 = m12.data(); a.nmatches = &n;
+    check(fb_match_initialization(&a));
+    for (int i = 0; i < N1; i++) vnMatches12[i] = m12[i];
+    return n;
+  }
+
+  // SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist), ORBmatcher.cc:1473-1600 (relocalisation).
+  // curMapPoints plays CurrentFrame.mvpMapPoints (pointer form).
+  int SearchByProjection(Frame &CurrentFrame, std::vector<MapPoint *> &curMapPoints, KeyFrame *pKF,
+                         const std::set<MapPoint *> &sAlreadyFound, float th, int ORBdist) const {
+    const std::vector<MapPoint *> vpMPs = pKF->GetMapPointMatches();
+    const int32_t N = CurrentFrame.N(), NK = (int32_t)vpMPs.size();
+    if (N == 0 || NK == 0) return 0;
+    std::vector<uint8_t> blocked(N), valid(NK), desc((size_t)NK * 32);
+    std::vector<float> xw((size_t)NK * 3), mx(NK), mn(NK), ang(NK);
+    for (int i = 0; i < N; i++) blocked[i] = curMapPoints[i] != nullptr;
+    for (int i = 0; i < NK; i++) {
+      MapPoint *p = vpMPs[i];
+      valid[i] = p && !p->isBad() && !sAlreadyFound.count(p);
+      ang[i] = pKF->mvKeysUn[i].angle;
+      if (!p) continue;
+      std::memcpy(&xw[3 * (size_t)i], p->mWorldPos, 12);
+      std::memcpy(&desc[32 * (size_t)i], p->mDescriptor, 32);
+      mx[i] = p->mfMaxDistance; mn[i] = p->mfMinDistance;
+    }
+    std::vector<int32_t> match(N, -1);
+    int32_t n = 0;
+    fb_proj_kf_args a{};
+    a.batch = 1; a.cur_stride = N; a.kf_stride = NK;
+    a.n_cur = &N; a.cur_kps = CurrentFrame.mvKeysUn.data(); a.cur_desc = CurrentFrame.mDescriptors.data();
+    a.cur_cell_start = CurrentFrame.gridStart.data(); a.cur_cell_items = CurrentFrame.gridItems.data(); a.cur_blocked = blocked.data();
+    a.cur_Tcw = CurrentFrame.mTcw; a.n_kf = &NK; a.kf_valid = valid.data(); a.kf_xw = xw.data(); a.kf_desc = desc.data();
+    a.kf_max_dist = mx.data(); a.kf_min_dist = mn.data(); a.kf_angle = ang.data();
+    a.cam = {CurrentFrame.fx, CurrentFrame.fy, CurrentFrame.cx, CurrentFrame.cy, CurrentFrame.mnMinX, CurrentFrame.mnMinY,
+             CurrentFrame.mnMaxX, CurrentFrame.mnMaxY};
+    a.grid = CurrentFrame.frontGrid();
+    for (size_t i = 0; i < CurrentFrame.mvScaleFactors.size() && i < FB_MAX_LEVELS; i++) a.scale_factors[i] = CurrentFrame.mvScaleFactors[i];
+    a.log_scale_factor = CurrentFrame.mvScaleFactors.size() > 1 ? std::log(CurrentFrame.mvScaleFactors[1]) : 1.f;
+    a.n_levels = (int32_t)CurrentFrame.mvScaleFactors.size();
+    a.th = th; a.orb_dist = ORBdist; a.matcher = m_; a.match_cur_to_kf = match.data(); a.nmatches = &n;
+    check(fb_match_projection_keyframe(&a));
+    for (int i = 0; i < N; i++) if (match[i] >= 0) curMapPoints[i] = vpMPs[match[i]];
+    return n;
+  }
+
+  // BirdviewMatch(CurF, vRefKeysBird, DescriptorsBird, vRefMapPointsBird, vDMatches12, isProject = 0, windowSize),
+  // ORBmatcher.cc:1602-1760 (the live form, Tracking.cc:2728).  DMatch = {queryIdx, trainIdx, distance}.
+  struct DMatch { int queryIdx, trainIdx; float distance; };
+  int BirdviewMatch(Frame &CurF, const std::vector<fb_keypoint> &vRefKeysBird, const std::vector<uint8_t> &DescriptorsBird,
+                    std::vector<DMatch> &vDMatches12, int windowSize = 10) const {
+    vDMatches12.clear();
+    const int32_t NC = CurF.Nbird(), NR = (int32_t)vRefKeysBird.size();
+    if (NC == 0 || NR == 0) return 0;
+    std::vector<int32_t> m(NR, -1), dist(NR, 0);
+    int32_t n = 0, nd = 0;
+    fb_birdview_args a{};
+    a.batch = 1; a.cur_stride = NC; a.ref_stride = NR;
+    a.n_cur = &NC; a.cur_kps = CurF.mvKeysBird.data(); a.cur_desc = CurF.mDescriptorsBird.data();
+    a.cur_cell_start = CurF.gridBirdStart.data(); a.cur_cell_items = CurF.gridBirdItems.data();
+    a.n_ref = &NR; a.ref_kps = vRefKeysBird.data(); a.ref_desc = DescriptorsBird.data();
+    a.grid = CurF.birdGrid(); a.window_size = windowSize; a.matcher = m_;
+    a.match_ref_to_cur = m.data(); a.match_dist = dist.data(); a.nmatches = &n; a.n_dmatches = &nd;
+    check(fb_match_birdview(&a));
+    for (int i = 0; i < NR; i++) if (m[i] > 0) vDMatches12.push_back({i, m[i], (float)dist[i]});  // sic: index 0 is dropped (:1755)
+    return n;
+  }
+
  private:
+  // flat views of the host containers for the C-ABI
+  struct FvFlat {
+    std::vector<uint32_t> ids;
+    std::vector<int32_t> start, items;
+    int32_t n = 0;
+    explicit FvFlat(const FeatureVector &fv) {
+      start.push_back(0);
+      for (FeatureVector::const_iterator it = fv.begin(); it != fv.end(); ++it) {
+        ids.push_back(it->first);
+        for (size_t k = 0; k < it->second.size(); k++) items.push_back((int32_t)it->second[k]);
+        start.push_back((int32_t)items.size());
+      }
+      n = (int32_t)ids.size();
+      if (ids.empty()) { ids.push_back(0); start.push_back(0); }
+      if (items.empty()) items.push_back(0);
+    }
+    fb_feature_vector view() const { return {(int32_t)ids.size(), (int32_t)items.size(), &n, ids.data(), start.data(), items.data()}; }
+  };
+  struct KfFlat {
+    int32_t n;
+    fb_kf_target t;
+    explicit KfFlat(KeyFrame *pKF) : n(pKF->N()) {
+      std::memset(&t, 0, sizeof(t));
+      if (pKF->gridStart.empty()) pKF->AssignFeaturesToGrid();
+      t.kf_stride = n; t.n_kf = &n; t.kf_kps = pKF->mvKeysUn.data(); t.kf_desc = pKF->mDescriptors.data();
+      t.kf_cell_start = pKF->gridStart.data(); t.kf_cell_items = pKF->gridItems.data();
+      t.cam = pKF->camera(); t.grid = pKF->gridGeom();
+      for (size_t i = 0; i < pKF->mvScaleFactors.size() && i < FB_MAX_LEVELS; i++) t.scale_factors[i] = pKF->mvScaleFactors[i];
+      for (size_t i = 0; i < pKF->mvInvLevelSigma2.size() && i < FB_MAX_LEVELS; i++) t.inv_level_sigma2[i] = pKF->mvInvLevelSigma2[i];
+      t.log_scale_factor = pKF->mfLogScaleFactor; t.n_levels = pKF->mnScaleLevels;
+    }
+    KfFlat(const KfFlat &) = delete;
+  };
+  struct MpFlat {
+    int32_t n;
+    std::vector<uint8_t> valid, desc;
+    std::vector<float> xw, normal, mx, mn;
+    template <typename Pred> MpFlat(const std::vector<MapPoint *> &v, Pred ok) : n((int32_t)v.size()) {
+      const size_t m = v.empty() ? 1 : v.size();
+      valid.assign(m, 0); desc.assign(m * 32, 0); xw.assign(m * 3, 0.f); normal.assign(m * 3, 0.f); mx.assign(m, 0.f); mn.assign(m, 0.f);
+      for (size_t i = 0; i < v.size(); i++) {
+        MapPoint *p = v[i];
+        valid[i] = ok(p) ? 1 : 0;
+        if (!p) continue;
+        std::memcpy(&xw[3 * i], p->mWorldPos, 12);
+        std::memcpy(&normal[3 * i], p->mNormalVector, 12);
+        std::memcpy(&desc[32 * i], p->mDescriptor, 32);
+        mx[i] = p->mfMaxDistance; mn[i] = p->mfMinDistance;
+      }
+    }
+    MpFlat(const MpFlat &) = delete;
+    fb_mp_list view() const {
+      return {(int32_t)valid.size(), &n, valid.data(), xw.data(), normal.data(), mx.data(), mn.data(), desc.data()};
+    }
+  };
+
   fb_matcher_params m_;
 };
 

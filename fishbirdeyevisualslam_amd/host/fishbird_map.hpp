@@ -17,6 +17,7 @@
 #include <cstring>
 #include <list>
 #include <map>
+#include <set>
 #include <stdexcept>
 #include <vector>
 
@@ -30,6 +31,8 @@ struct KFIdLess {
   inline bool operator()(const KeyFrame *a, const KeyFrame *b) const;
 };
 typedef std::map<KeyFrame *, size_t, KFIdLess> ObservationMap;
+// DBoW2::FeatureVector (Thirdparty/DBoW2/DBoW2/FeatureVector.h:23): NodeId -> feature indices in addFeature order
+typedef std::map<uint32_t, std::vector<unsigned>> FeatureVector;
 
 // Frame::bHaveBird / bTightCouple / bTightCouple2 (static switches read by the optimiser, Optimizer.cc:2190,2417,2452)
 struct OptimizerSwitches {
@@ -101,6 +104,9 @@ struct MapPoint {
   unsigned long mnBALocalForKF = 0;   // MapPoint.cc:35 initialises these to 0
   float mPosGBA[3] = {0, 0, 0};
   unsigned long mnBAGlobalForKF = 0;
+  uint8_t mDescriptor[32] = {0};      // GetDescriptor()
+  int mnVisible = 1, mnFound = 1;
+  MapPoint *mpReplaced = nullptr;
 
   bool isBad() const { return mbBad; }
   int Observations() const { return nObs; }
@@ -109,7 +115,12 @@ struct MapPoint {
     ObservationMap::const_iterator it = mObservations.find(pKF);
     return it == mObservations.end() ? -1 : (int)it->second;
   }
+  bool IsInKeyFrame(KeyFrame *pKF) const { return mObservations.count(pKF) != 0; }
+  void IncreaseVisible(int n = 1) { mnVisible += n; }
+  void IncreaseFound(int n = 1) { mnFound += n; }
   void SetWorldPos(const float p[3]) { std::memcpy(mWorldPos, p, 12); }
+  inline void Replace(MapPoint *pMP);                          // MapPoint.cc:172-217
+  inline void ComputeDistinctiveDescriptors();                 // MapPoint.cc:242-307, through fb_distinctive_descriptors
   inline void AddObservation(KeyFrame *pKF, size_t idx);      // MapPoint.cc:98-110
   inline void EraseObservation(KeyFrame *pKF);                 // MapPoint.cc:112-138
   inline void SetBadFlag();                                    // MapPoint.cc:152-170
@@ -167,6 +178,42 @@ struct KeyFrame {
   std::vector<KeyFrame *> mvpOrderedConnectedKeyFrames;  // maintained by the caller (KeyFrame::UpdateBestCovisibles)
   unsigned long mnBALocalForKF = 0, mnBAFixedForKF = 0, mnBAGlobalForKF = 0;
   float mTcwGBA[12] = {0};
+  // matcher side (KeyFrame.h:170-213): descriptors, BoW feature vector, the feature grid copied from the Frame
+  std::vector<uint8_t> mDescriptors;  // N x 32
+  FeatureVector mFeatVec;
+  std::vector<float> mvLevelSigma2;
+  float mfLogScaleFactor = 0;
+  int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;  // const int in the reference (truncated Frame bounds)
+  int mnGridCols = 64, mnGridRows = 48;
+  float mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+  float mnFrameMinX = 0, mnFrameMinY = 0;  // the Frame's float bounds the grid was built with (Frame.cc:381-411)
+  std::vector<int32_t> gridStart, gridItems;  // mGrid as CSR, cell id = ix*rows+iy
+
+  int N() const { return (int)mvKeysUn.size(); }
+  MapPoint *GetMapPoint(size_t idx) const { return mvpMapPoints[idx]; }
+  inline std::set<MapPoint *> GetMapPoints() const;  // KeyFrame.cc:337-350: the non-NULL, non-bad ones
+  void AddMapPoint(MapPoint *pMP, size_t idx) { mvpMapPoints[idx] = pMP; }
+  void ReplaceMapPointMatch(size_t idx, MapPoint *pMP) { mvpMapPoints[idx] = pMP; }
+  fb_grid_geom gridGeom() const {
+    return {mnFrameMinX, mnFrameMinY, mfGridElementWidthInv, mfGridElementHeightInv, mnGridCols, mnGridRows};
+  }
+  fb_camera camera() const { return {fx, fy, cx, cy, (float)mnMinX, (float)mnMinY, (float)mnMaxX, (float)mnMaxY}; }
+  // Frame::AssignFeaturesToGrid (Frame.cc:381-411; the KeyFrame copies F.mGrid, KeyFrame.cc:51-57)
+  void AssignFeaturesToGrid() {
+    const fb_grid_geom g = gridGeom();
+    const int ncell = g.cols * g.rows;
+    std::vector<std::vector<int32_t>> cells(ncell);
+    for (size_t i = 0; i < mvKeysUn.size(); i++) {
+      const int px = (int)std::round((mvKeysUn[i].x - g.min_x) * g.inv_w), py = (int)std::round((mvKeysUn[i].y - g.min_y) * g.inv_h);
+      if (px < 0 || px >= g.cols || py < 0 || py >= g.rows) continue;
+      cells[px * g.rows + py].push_back((int32_t)i);
+    }
+    gridStart.assign(ncell + 1, 0);
+    gridItems.assign(mvKeysUn.size() ? mvKeysUn.size() : 1, 0);
+    int off = 0;
+    for (int c = 0; c < ncell; c++) { gridStart[c] = off; for (int32_t i : cells[c]) gridItems[off++] = i; }
+    gridStart[ncell] = off;
+  }
 
   bool isBad() const { return mbBad; }
   const float *GetPose() const { return Tcw; }
@@ -192,6 +239,12 @@ struct KeyFrame {
     if (idx >= 0) mvpMapPointsBird[idx] = nullptr;
   }
 };
+inline std::set<MapPoint *> KeyFrame::GetMapPoints() const {
+  std::set<MapPoint *> s;
+  for (size_t i = 0; i < mvpMapPoints.size(); i++)
+    if (mvpMapPoints[i] && !mvpMapPoints[i]->isBad()) s.insert(mvpMapPoints[i]);
+  return s;
+}
 inline bool KFIdLess::operator()(const KeyFrame *a, const KeyFrame *b) const { return a->mnId < b->mnId; }
 
 // ---- Map (include/Map.h) ------------------------------------------------------------------------------------------
@@ -228,6 +281,44 @@ inline void MapPoint::SetBadFlag() {
   obs.swap(mObservations);
   for (ObservationMap::iterator it = obs.begin(); it != obs.end(); ++it) it->first->EraseMapPointMatch(it->second);
   if (mpMap) mpMap->EraseMapPoint(this);
+}
+inline void MapPoint::Replace(MapPoint *pMP) {
+  if (pMP->mnId == this->mnId) return;
+  ObservationMap obs;
+  obs.swap(mObservations);
+  mbBad = true;
+  const int nvisible = mnVisible, nfound = mnFound;
+  mpReplaced = pMP;
+  for (ObservationMap::iterator mit = obs.begin(); mit != obs.end(); ++mit) {
+    KeyFrame *pKF = mit->first;
+    if (!pMP->IsInKeyFrame(pKF)) {
+      pKF->ReplaceMapPointMatch(mit->second, pMP);
+      pMP->AddObservation(pKF, mit->second);
+    } else {
+      pKF->EraseMapPointMatch(mit->second);
+    }
+  }
+  pMP->IncreaseFound(nfound);
+  pMP->IncreaseVisible(nvisible);
+  pMP->ComputeDistinctiveDescriptors();
+  if (mpMap) mpMap->EraseMapPoint(this);
+}
+// The descriptor with the least median distance to the other observations (MapPoint.cc:242-307).  One point per call
+// here as in the reference; a caller that touches many points batches them into one fb_distinctive_descriptors call.
+inline void MapPoint::ComputeDistinctiveDescriptors() {
+  if (mbBad || mObservations.empty()) return;
+  std::vector<uint8_t> desc;
+  for (ObservationMap::iterator mit = mObservations.begin(); mit != mObservations.end(); ++mit) {
+    KeyFrame *pKF = mit->first;
+    if (pKF->isBad()) continue;
+    const uint8_t *d = &pKF->mDescriptors[32 * mit->second];
+    desc.insert(desc.end(), d, d + 32);
+  }
+  if (desc.empty()) return;
+  const int32_t start[2] = {0, (int32_t)(desc.size() / 32)};
+  int32_t best = -1;
+  if (fb_distinctive_descriptors(start, desc.data(), 1, &best) != FB_OK) throw std::runtime_error(fb_last_error());
+  if (best >= 0) std::memcpy(mDescriptor, &desc[32 * (size_t)best], 32);
 }
 inline void MapPoint::UpdateNormalAndDepth() {
   if (mbBad || mObservations.empty() || !mpRefKF) return;
