@@ -49,6 +49,7 @@ struct LevelInfo {
 struct OrbK {
   int nlevels, iniTh, minTh, totalCells, outStride, capOut;
   int fastTileBytes, fastMaxOut, fastMaxPix;  // LDS carve of k_fast
+  int fastTP;                                 // tile pitch instantiation of k_fast (44 / 56 / 72)
   int dbg;  // FB_FAST_DBG ablation switch (0 = normal)
   int cellBase[FB_MAX_LEVELS + 1];  // first FAST cell of each level (contiguous copy for one scalar load)
   long long pyrStride;   // bytes per image of levels >= 1
@@ -272,6 +273,9 @@ constexpr int FAST_MAX_TILE = 72;  // cell window <= wCell+6 <= 65 px, +3 alignm
 //  4. if none survived at iniThFAST the cell is redone at minThFAST (ORBextractor.cc:809-816);
 //  5. ONE global atomic per cell reserves the output slots; candidate order is irrelevant downstream
 //     (the quadtree breaks response ties with an order key derived from x,y).
+// TP = tile pitch in bytes, a compile-time constant so that every LDS access of the sweep / score / NMS is
+// base + immediate offset (44 covers cells up to 35 px wide, i.e. every level of the usual image sizes).
+template <int TP>
 __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__ img0, long long imgStride, int pitch0,
                                              const uint8_t *__restrict__ pyr, uint32_t *__restrict__ cand,
                                              int *__restrict__ candCount) {
@@ -308,10 +312,10 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
   // stage the window: tile column 0 = image column xa (4-byte aligned when the image allows it)
   const bool aligned = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch) & 3) == 0;
   const int xa = aligned ? (x0 & ~3) : x0;
-  const int tp = aligned ? (((x1 - xa) + 3) & ~3) : cw;  // tile pitch
+  constexpr int tp = TP;  // tile pitch
   const int ox = x0 - xa;
   if (aligned) {
-    const int wpr = tp >> 2;
+    const int wpr = ((x1 - xa) + 3) >> 2;  // dwords per window row
     const float inv_wpr = 1.0f / (float)wpr;
     for (int i = lane; i < wpr * ch; i += 64) {
       const int yy = (int)(((float)i + 0.5f) * inv_wpr), xw = i - yy * wpr;
@@ -374,11 +378,17 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
       const int strength = h2 == 0 ? s0 : s1;
       const int offp = off + h2 * tp;
       const bool c9i = strength > K.iniTh, c9 = strength > K.minTh;
-      const unsigned long long mA = __ballot(c9i), mB = __ballot(c9 && !c9i);
-      if (c9i) s_list[nlA + __popcll(mA & lt)] = (unsigned short)offp;
-      else if (c9) s_list[cap - 1 - (nlB + __popcll(mB & lt))] = (unsigned short)offp;
-      nlA += __popcll(mA);
-      nlB += __popcll(mB);
+      // branch-free two-ended compaction: rank among the ini-threshold lanes (front) / among the others (back)
+      const unsigned long long mA = __ballot(c9i), mAB = __ballot(c9);
+      const int pA = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u));
+      const int pAB = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mAB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mAB, 0u));
+      const int idxA = nlA + pA, idxB = cap - 1 - nlB - (pAB - pA);
+      int idx;  // plain select on the ballot mask (the compiler turns the ternary into two divergent branches)
+      asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(idx) : "v"(idxB), "v"(idxA), "s"(mA));
+      if (c9) s_list[idx] = (unsigned short)offp;
+      const int cA = __popcll(mA);
+      nlA += cA;
+      nlB += __popcll(mAB) - cA;
     }
   }
   __syncthreads();
@@ -1068,16 +1078,18 @@ int prepare(fb_orb *o, int w, int h, int batch) {
   for (int l = 0; l <= FB_MAX_LEVELS; l++) K.cellBase[l] = l < p.nlevels ? K.L[l].cellBase : cells;
   K.dbg = getenv("FB_FAST_DBG") ? atoi(getenv("FB_FAST_DBG")) : 0;
   {
-    int tileB = 0, maxOut = 0, maxPix = 0;
+    int tileB = 0, maxOut = 0, maxPix = 0, tpNeed = 0;
     for (int l = 0; l < p.nlevels; l++) {
       const LevelInfo &L = K.L[l];
       if (L.nCols * L.nRows == 0) continue;
       const int tpMax = (L.wCell + 6 + 3 + 3) & ~3, chMax = L.hCell + 6;
-      tileB = std::max(tileB, tpMax * chMax);
+      tpNeed = std::max(tpNeed, tpMax);
+      tileB = std::max(tileB, chMax);
       maxOut = std::max(maxOut, ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2));
       maxPix = std::max(maxPix, L.wCell * L.hCell);
     }
-    K.fastTileBytes = (tileB + 15) & ~15;
+    K.fastTP = tpNeed <= 44 ? 44 : tpNeed <= 56 ? 56 : FAST_MAX_TILE;
+    K.fastTileBytes = (K.fastTP * tileB + 15) & ~15;
     K.fastMaxOut = (maxOut + 3) & ~3;
     K.fastMaxPix = (maxPix + 7) & ~7;
   }
@@ -1188,8 +1200,14 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
   }
   if (K.totalCells > 0) {
     fb::ProfScope prof_(fb::P_FAST, s);
-    k_fast<<<dim3((K.totalCells + 7) / 8 * 8, batch), 64, (size_t)2 * K.fastTileBytes + 4 * K.fastMaxOut + 2 * K.fastMaxPix, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
-                                                      o->cand.as<uint32_t>(), candCount);
+    const dim3 grdF((K.totalCells + 7) / 8 * 8, batch);
+    const size_t ldsF = (size_t)2 * K.fastTileBytes + 4 * K.fastMaxOut + 2 * K.fastMaxPix;
+    if (K.fastTP == 44)
+      k_fast<44><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cand.as<uint32_t>(), candCount);
+    else if (K.fastTP == 56)
+      k_fast<56><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cand.as<uint32_t>(), candCount);
+    else
+      k_fast<FAST_MAX_TILE><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cand.as<uint32_t>(), candCount);
   }
   {
     fb::ProfScope prof_(fb::P_BLUR, s);
