@@ -225,18 +225,23 @@ __device__ __forceinline__ int fast_score16(const uint8_t *__restrict__ c, int t
   d[4] = v - c[3];           d[5] = v - c[-tp + 3];      d[6] = v - c[-2 * tp + 2];  d[7] = v - c[-3 * tp + 1];
   d[8] = v - c[-3 * tp];     d[9] = v - c[-3 * tp - 1];  d[10] = v - c[-2 * tp - 2]; d[11] = v - c[-tp - 3];
   d[12] = v - c[-3];         d[13] = v - c[tp - 3];      d[14] = v - c[2 * tp - 2];  d[15] = v - c[3 * tp - 1];
-  int mn2[16], mx2[16], mn4[16], mx4[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) { mn2[i] = min(d[i], d[(i + 1) & 15]); mx2[i] = max(d[i], d[(i + 1) & 15]); }
-#pragma unroll
-  for (int i = 0; i < 16; i++) { mn4[i] = min(mn2[i], mn2[(i + 2) & 15]); mx4[i] = max(mx2[i], mx2[(i + 2) & 15]); }
-  int A = -256, Bm = 256;
+  // sliding min / max over the 16 arcs of 9 in three-operand form (v_min3_i32 / v_max3_i32):
+  // arc of 3 -> arc of 9 = three arcs of 3 -> reduction, 40 instructions per polarity
+  int mn3[16], mx3[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    const int mn9 = min(min(mn4[i], mn4[(i + 4) & 15]), d[(i + 8) & 15]);
-    const int mx9 = max(max(mx4[i], mx4[(i + 4) & 15]), d[(i + 8) & 15]);
-    A = max(A, mn9);
-    Bm = min(Bm, mx9);
+    mn3[i] = min(min(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
+    mx3[i] = max(max(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
+  }
+  int A = -256, Bm = 256;
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) {
+    const int a0 = min(min(mn3[i], mn3[(i + 3) & 15]), mn3[(i + 6) & 15]);
+    const int a1 = min(min(mn3[i + 1], mn3[(i + 4) & 15]), mn3[(i + 7) & 15]);
+    const int b0 = max(max(mx3[i], mx3[(i + 3) & 15]), mx3[(i + 6) & 15]);
+    const int b1 = max(max(mx3[i + 1], mx3[(i + 4) & 15]), mx3[(i + 7) & 15]);
+    A = max(max(A, a0), a1);
+    Bm = min(min(Bm, b0), b1);
   }
   return max(A, -Bm) - 1;
 }
@@ -279,12 +284,14 @@ template <int TP>
 __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__ img0, long long imgStride, int pitch0,
                                              const uint8_t *__restrict__ pyr, uint32_t *__restrict__ cand,
                                              int *__restrict__ candCount) {
-  // LDS carve (sized on the host for the largest cell of this image size): tile | sc | out | slot
+  // LDS carve (sized on the host for the largest cell of this image size): tile (later: survivors) | sc | list
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
   uint8_t *tile = fsm;
   uint8_t *sc = fsm + K.fastTileBytes;
-  uint32_t *s_out = reinterpret_cast<uint32_t *>(fsm + 2 * K.fastTileBytes);
-  unsigned short *s_list = reinterpret_cast<unsigned short *>(fsm + 2 * K.fastTileBytes + 4 * K.fastMaxOut);  // [fastMaxPix]
+  // the NMS survivors overlay the image tile: the first survivor is written only after the last read of the tile
+  // (a pass that keeps anything is the final pass; 4 * fastMaxOut <= fastTileBytes)
+  uint32_t *s_out = reinterpret_cast<uint32_t *>(fsm);
+  unsigned short *s_list = reinterpret_cast<unsigned short *>(fsm + 2 * K.fastTileBytes);  // [fastMaxPix]
   const int b = blockIdx.y, lane = threadIdx.x;
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one), so give each
   // XCD a contiguous run of cells -- neighbouring cells overlap by 6 px and share 64-B lines in that XCD's L2
@@ -315,12 +322,15 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
   constexpr int tp = TP;  // tile pitch
   const int ox = x0 - xa;
   if (aligned) {
-    const int wpr = ((x1 - xa) + 3) >> 2;  // dwords per window row
-    const float inv_wpr = 1.0f / (float)wpr;
-    for (int i = lane; i < wpr * ch; i += 64) {
-      const int yy = (int)(((float)i + 0.5f) * inv_wpr), xw = i - yy * wpr;
-      *reinterpret_cast<uint32_t *>(&tile[yy * tp + xw * 4]) =
-          *reinterpret_cast<const uint32_t *>(img + (long long)(y0 + yy) * pitch + xa + xw * 4);
+    // fixed lane -> (row within a group, dword) mapping: the global address and the LDS index advance by constants
+    constexpr int DW = TP / 4, RPI = 64 / DW;  // dwords per tile row, rows per iteration
+    const int wpr = ((x1 - xa) + 3) >> 2;      // dwords per window row (<= DW)
+    const int r0 = lane / DW, dwc = lane - r0 * DW;
+    if (r0 < RPI && dwc < wpr) {
+      const uint8_t *src = img + (long long)(y0 + r0) * pitch + xa + dwc * 4;
+      const long long step = (long long)RPI * pitch;
+      uint32_t *dst = reinterpret_cast<uint32_t *>(&tile[r0 * tp + dwc * 4]);
+      for (int yy = r0; yy < ch; yy += RPI, src += step, dst += RPI * DW) *dst = *reinterpret_cast<const uint32_t *>(src);
     }
   } else {
     for (int i = lane; i < cw * ch; i += 64) {
@@ -332,8 +342,6 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
   __syncthreads();
   if (K.dbg == 1) { if (tile[lane] == 255 && sc[lane] == 7) cand[0] = 1; return; }
   const int dwid = cw - 6, dhei = ch - 6, npix = dwid * dhei;
-  const unsigned long long lt = (1ull << lane) - 1;
-  const float inv_dwid = 1.0f / (float)dwid;  // p / dwid == (int)((p + 0.5f) * inv_dwid) for p < 4096, dwid < 64
   // ---- ONE sweep over the cell: compact every pixel that can be a corner (necessary compass test) into two lists
   //      sharing one array: from the front the pixels that pass at iniThFAST, from the back those that only pass
   //      at minThFAST (needed only when the cell has to be redone at the lower threshold)
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
   // adjacent pixels at once in packed 16-bit arithmetic (v_pk_sub/min/max_i16).  The compass test for ANY threshold T
   // is "strength > T" with strength = max(max over adjacent compass pairs of min(d_i, d_j), -(min over adjacent pairs
   // of max(d_i, d_j))): two adjacent compass points brighter, or two darker, by more than T.
-  (void)npix; (void)inv_dwid;
+  (void)npix;
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   const int G = dwid <= 32 ? 32 : 64, ppi = dwid <= 32 ? 2 : 1;  // row pairs per iteration
   const int sxx = lane & (G - 1), spr = dwid <= 32 ? (lane >> 5) : 0;
@@ -395,22 +403,19 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
   if (K.dbg == 4) { if (nlA + nlB == 123456) cand[0] = 1; return; }
   for (int pass = 0; pass < 2; pass++) {
     const int T = pass == 0 ? K.iniTh : K.minTh;
-    // ---- scores: pass 0 scores list A, pass 1 list B
-    {
-      const int n = pass == 0 ? nlA : nlB;
-      const unsigned short *lst = pass == 0 ? s_list : s_list + cap - nlB;
-      for (int i = lane; i < n; i += 64) {
-        const int o = lst[i];
-        sc[o] = (uint8_t)max(fast_score16(&tile[o], tp), 0);
-      }
+    // ---- scores, stored thresholded (below T = 0) so that the NMS compares raw bytes: pass 0 scores list A at
+    //      iniThFAST, pass 1 (cells without a corner at iniThFAST) scores A again and B at minThFAST
+    const int nl = pass == 0 ? nlA : nlA + nlB;  // pass 1 visits A then B
+    for (int i = lane; i < nl; i += 64) {
+      const int o = i < nlA ? s_list[i] : s_list[cap - nlB + (i - nlA)];
+      const int scv = fast_score16(&tile[o], tp);
+      sc[o] = (uint8_t)(scv >= T ? scv : 0);
     }
     __syncthreads();
     if (K.dbg == 2) { if (sc[lane] == 255) cand[0] = 1; return; }
     // ---- 3x3 strict non-max suppression over the candidate list (only listed pixels can hold a score >= T);
-    //      neighbours below T count as 0, the rim holds 0
+    //      neighbours below T were stored as 0, the rim holds 0
     int total = 0;
-    const float inv_tp = 1.0f / (float)tp;
-    const int nl = pass == 0 ? nlA : nlA + nlB;  // pass 1 visits A then B
     for (int base = 0; base < nl; base += 64) {
       const int i = base + lane;
       bool keep = false;
@@ -419,18 +424,16 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
         const int o = i < nlA ? s_list[i] : s_list[cap - nlB + (i - nlA)];
         const uint8_t *q = &sc[o];
         const int sv = q[0];
-        if (sv >= T) {
-          int mx = 0;
-#define NB(o_) { const int n_ = q[o_]; mx = max(mx, n_ >= T ? n_ : 0); }
-          NB(-1) NB(1) NB(-tp - 1) NB(-tp) NB(-tp + 1) NB(tp - 1) NB(tp) NB(tp + 1)
-#undef NB
+        if (sv != 0) {
+          const int mx = max(max(max(max((int)q[-1], (int)q[1]), (int)q[-tp - 1]), max((int)q[-tp], (int)q[-tp + 1])),
+                             max(max((int)q[tp - 1], (int)q[tp]), (int)q[tp + 1]));
           keep = sv > mx;
-          const int yy = (int)(((float)o + 0.5f) * inv_tp), xx = o - yy * tp - ox;
+          const int yy = o / tp, xx = o - yy * tp - ox;
           rec = (uint32_t)(x0 + xx) | ((uint32_t)(y0 + yy) << 12) | ((uint32_t)sv << 24);
         }
       }
       const unsigned long long m = __ballot(keep);
-      if (keep) s_out[total + __popcll(m & lt)] = rec;
+      if (keep) s_out[total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = rec;
       total += __popcll(m);
     }
     if (K.dbg == 3) { if (total == 12345) cand[0] = 1; return; }
@@ -1089,7 +1092,7 @@ int prepare(fb_orb *o, int w, int h, int batch) {
       maxPix = std::max(maxPix, L.wCell * L.hCell);
     }
     K.fastTP = tpNeed <= 44 ? 44 : tpNeed <= 56 ? 56 : FAST_MAX_TILE;
-    K.fastTileBytes = (K.fastTP * tileB + 15) & ~15;
+    K.fastTileBytes = (std::max(K.fastTP * tileB, 4 * ((maxOut + 3) & ~3)) + 15) & ~15;
     K.fastMaxOut = (maxOut + 3) & ~3;
     K.fastMaxPix = (maxPix + 7) & ~7;
   }
@@ -1201,7 +1204,7 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
   if (K.totalCells > 0) {
     fb::ProfScope prof_(fb::P_FAST, s);
     const dim3 grdF((K.totalCells + 7) / 8 * 8, batch);
-    const size_t ldsF = (size_t)2 * K.fastTileBytes + 4 * K.fastMaxOut + 2 * K.fastMaxPix;
+    const size_t ldsF = (size_t)2 * K.fastTileBytes + 2 * K.fastMaxPix;
     if (K.fastTP == 44)
       k_fast<44><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cand.as<uint32_t>(), candCount);
     else if (K.fastTP == 56)
