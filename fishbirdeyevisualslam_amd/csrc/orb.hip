@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256) void k_blur(OrbK K, const uint8_t *__restrict_
     const int yo = y0 + r - 6;  // destination row completed by this source row
     if (r >= 6 && yo >= h) break;
     const int ys = reflect101(min(y0 + r - 3, h + 2), h);
-    const uint8_t *row = img + (long long)ys * pitch;
+    const uint8_t *row = img + (uint32_t)__mul24(ys, pitch);  // 32-bit offset: 64-bit multiplies are quarter rate
     const uint32_t *pw = reinterpret_cast<const uint32_t *>(row + base);
     uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
     if (anyEdge) {
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256) void k_blur(OrbK K, const uint8_t *__restrict_
         const int sum = __mul24(18, c0 + c6) + __mul24(34, c1 + c5) + __mul24(49, c2 + c4) + __mul24(55, c3);
         packed |= (uint32_t)min((sum + (1 << 15)) >> 16, 255) << (8 * k);
       }
-      *reinterpret_cast<uint32_t *>(out + (long long)yo * L.pitch + x0) = packed;
+      *reinterpret_cast<uint32_t *>(out + (uint32_t)(__mul24(yo, L.pitch) + x0)) = packed;
     }
   }
 }
@@ -787,127 +787,185 @@ __global__ __launch_bounds__(256) void k_blur(OrbK K, const uint8_t *__restrict_
 constexpr int DP_RAW_DW = 9, DP_RAW_ROWS = 31;    // 31 rows x 36 B  (x-15 .. x+15 after dword alignment)
 constexpr int DP_BL_DW = 10, DP_BL_ROWS = 37;     // 37 rows x 40 B  (x-18 .. x+18 after dword alignment)
 
-__global__ __launch_bounds__(64) void k_describe(OrbK K, const uint8_t *__restrict__ img0, long long imgStride,
+constexpr int DESC_WPB = 4;  // waves per workgroup (they never talk to each other)
+constexpr int DESC_KPW = 1;  // consecutive key points per wave (measured: 8 with prefetch of the next patch is SLOWER, see below)
+
+// A wave owns DESC_KPW consecutive key points.  What does not depend on the key point (level counts, sampling
+// pattern, orientation tables) is fetched once per wave, the DESC_KPW records with one load, and with DESC_KPW > 1 the
+// patch loads of key point j+1 are in flight while key point j is processed out of LDS.  The kernel is bound by the
+// latency of its ~70 cache lines per key point (ablation: 37 % record + table fetch, 53 % patch staging + moments,
+// 10 % the 256 tests), i.e. by the number of loads in flight per SIMD = waves x 12.  Measured at B=256: DESC_KPW = 8
+// with prefetch needs 115 VGPRs (4 waves) and is 1.5x SLOWER than DESC_KPW = 1 at 8 waves, which is what ships.
+__global__ __launch_bounds__(64 * DESC_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_describe(OrbK K, const uint8_t *__restrict__ img0, long long imgStride,
                                                  int pitch0, const uint8_t *__restrict__ pyr,
                                                  const uint8_t *__restrict__ blur, const uint4 *__restrict__ angTab,
                                                  const uint32_t *__restrict__ lvlOut, const int *__restrict__ lvlCount,
                                                  fb_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                  int32_t *__restrict__ nOut) {
-  __shared__ __attribute__((aligned(16))) uint32_t rawp[DP_RAW_ROWS * DP_RAW_DW + 4];
-  __shared__ __attribute__((aligned(16))) uint32_t blp[DP_BL_ROWS * DP_BL_DW];
-  const int b = blockIdx.y, lane = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) uint32_t rawp_all[DESC_WPB][DP_RAW_ROWS * DP_RAW_DW + 4];
+  __shared__ __attribute__((aligned(16))) uint32_t blp_all[DESC_WPB][DP_BL_ROWS * DP_BL_DW + 2];
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t *rawp = rawp_all[wv], *blp = blp_all[wv];
   // XCD-aware mapping (as in k_fast): consecutive workgroups go to different XCDs; give each XCD a contiguous run of
   // key points (neighbours in the quadtree order overlap in the image) so that their patches share lines in one L2
-  const int idx = (int)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (int)(blockIdx.x >> 3);
+  const int first = (((int)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (int)(blockIdx.x >> 3)) * DESC_WPB + wv) * DESC_KPW;
   const int *cnts = lvlCount + b * K.nlevels;
-  int total = 0, myl = -1, myidx = 0;
-  for (int l = 0; l < K.nlevels; l++) {
-    const int c = cnts[l];
-    if (myl < 0 && idx < total + c) { myl = l; myidx = idx - total; }
-    total += c;
-  }
-  if (blockIdx.x == 0 && lane == 0) nOut[b] = min(total, K.capOut);
-  if (myl < 0 || idx >= K.capOut) return;
-  const LevelInfo &Lv = K.L[myl];
-  const uint32_t rec = lvlOut[(long long)b * K.outStride + Lv.outBase + myidx];
-  const int cx = rec & 0xFFF, cy = (rec >> 12) & 0xFFF, resp = rec >> 24;
-  const uint8_t *img;
-  int pitch;
-  if (myl == 0) { img = img0 + (long long)b * imgStride; pitch = pitch0; }
-  else { img = pyr + (long long)b * K.pyrStride + Lv.off; pitch = Lv.pitch; }
-  // stage both patches (key points sit >= 19 px inside the level, so neither patch leaves the image)
-  // fixed lane -> (row within a group, dword) mapping: 6 rows x 10 dwords (7 x 9 for the raw patch) per pass, so the
-  // global address and the LDS index advance by constants (no per-element division)
-  const int bxa = (cx - 18) & ~3, box = (cx - 18) - bxa;
+  int lstart[FB_MAX_LEVELS + 1];
+  lstart[0] = 0;
+#pragma unroll
+  for (int l = 0; l < FB_MAX_LEVELS; l++) lstart[l + 1] = lstart[l] + (l < K.nlevels ? cnts[l] : 0);
+  const int nk = min(lstart[FB_MAX_LEVELS], K.capOut);
+  if (blockIdx.x == 0 && threadIdx.x == 0) nOut[b] = nk;
+  if (first >= nk) return;
+  const int nmine = min(DESC_KPW, nk - first);
+  // lanes 0..nmine-1 fetch the records of the wave's key points (level = the run of the per-level counts they fall in)
+  int kl = 0;
+  uint32_t recv;
   {
-    const int r0 = lane / DP_BL_DW, dwc = lane - r0 * DP_BL_DW;
-    const uint8_t *src = blur + (long long)b * K.blurStride + Lv.boff + (long long)(cy - 18 + r0) * Lv.pitch + bxa + dwc * 4;
-    const long long stepB = 6ll * Lv.pitch;
+    const int ki = first + min(lane, nmine - 1);
+    int adj = K.L[0].outBase;
+#pragma unroll
+    for (int l = 1; l < FB_MAX_LEVELS; l++)
+      if (l < K.nlevels && ki >= lstart[l]) { kl = l; adj = K.L[l].outBase - lstart[l]; }
+    recv = lvlOut[(long long)b * K.outStride + adj + ki];
+  }
+  int4 pp[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) pp[t] = reinterpret_cast<const int4 *>(c_pattern)[lane * 4 + t];
+  const uint4 angW = angTab[(lane < 62 ? lane : 0) * 2], angK = angTab[(lane < 62 ? lane : 0) * 2 + 1];
+  if (K.dbg == 11) { if (pp[0].x + pp[1].y + pp[2].z + pp[3].w + (int)angW.x + (int)angK.y + (int)recv == 1234567) nOut[0] = 1; return; }
+  // fixed lane -> (row within a group, dword) mapping: 6 rows x 10 dwords (7 x 9 for the raw patch) per pass, so the
+  // global offsets and the LDS indices are constants per lane (32-bit offsets from wave-uniform bases, 24-bit
+  // multiplies: 64/32-bit integer multiplies are quarter rate)
+  constexpr int NB_IT = (DP_BL_ROWS + 5) / 6, NR_IT = (DP_RAW_ROWS + 6) / 7;
+  const int rb0 = (lane * 205) >> 11, dwb = lane - rb0 * DP_BL_DW;   // lane / 10
+  const int rr0 = (lane * 57) >> 9, dwr = lane - rr0 * DP_RAW_DW;    // lane / 9
+  struct KP {  // wave-uniform description of one key point
+    int cx, cy, resp, myl, pitch, bpitch, bxa, box, rxa, rox, patchSize;
+    float scale;
+    const uint8_t *img, *bbase;
+    bool rawAligned;
+  };
+  auto decode = [&](int j) {
+    KP k;
+    const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)recv, j);
+    k.myl = __builtin_amdgcn_readlane(kl, j);
+    k.cx = rec & 0xFFF; k.cy = (rec >> 12) & 0xFFF; k.resp = rec >> 24;
+    const LevelInfo &Lv = K.L[k.myl];
+    if (k.myl == 0) { k.img = img0 + (long long)b * imgStride; k.pitch = pitch0; }
+    else { k.img = pyr + (long long)b * K.pyrStride + Lv.off; k.pitch = Lv.pitch; }
+    k.bbase = blur + (long long)b * K.blurStride + Lv.boff;
+    k.bpitch = Lv.pitch; k.scale = Lv.scale; k.patchSize = Lv.patchSize;
+    k.bxa = (k.cx - 18) & ~3; k.box = (k.cx - 18) - k.bxa;
+    k.rawAligned = ((reinterpret_cast<uintptr_t>(k.img) | (uintptr_t)k.pitch) & 3) == 0;
+    k.rxa = (k.cx - 15) & ~3;
+    k.rox = k.rawAligned ? (k.cx - 15) - k.rxa : 0;
+    return k;
+  };
+  uint32_t vb[NB_IT], vr[NR_IT];
+  // All global loads of both patches are issued together (rows past a patch are clamped and their data dropped; key
+  // points sit >= 19 px inside the level, so neither patch leaves the image)
+  auto issue = [&](const KP &k) {
+#pragma unroll
+    for (int it = 0; it < NB_IT; it++)
+      vb[it] = *reinterpret_cast<const uint32_t *>(k.bbase + (uint32_t)(__mul24(k.cy - 18 + min(it * 6 + rb0, DP_BL_ROWS - 1), k.bpitch) + k.bxa + min(dwb, DP_BL_DW - 1) * 4));
+    if (k.rawAligned) {
+#pragma unroll
+      for (int it = 0; it < NR_IT; it++)
+        vr[it] = *reinterpret_cast<const uint32_t *>(k.img + (uint32_t)(__mul24(k.cy - 15 + min(it * 7 + rr0, DP_RAW_ROWS - 1), k.pitch) + k.rxa + min(dwr, DP_RAW_DW - 1) * 4));
+    }
+  };
+  auto stage = [&](const KP &k) {
     if (lane < 6 * DP_BL_DW) {
 #pragma unroll
-      for (int it = 0; it < (DP_BL_ROWS + 5) / 6; it++) {
-        if (it * 6 + r0 < DP_BL_ROWS) blp[it * 6 * DP_BL_DW + lane] = *reinterpret_cast<const uint32_t *>(src);
-        src += stepB;
+      for (int it = 0; it < NB_IT; it++)
+        if (it * 6 + rb0 < DP_BL_ROWS) blp[it * 6 * DP_BL_DW + lane] = vb[it];
+    }
+    if (k.rawAligned) {
+      if (lane < 7 * DP_RAW_DW) {
+#pragma unroll
+        for (int it = 0; it < NR_IT; it++)
+          if (it * 7 + rr0 < DP_RAW_ROWS) rawp[it * 7 * DP_RAW_DW + lane] = vr[it];
+      }
+    } else {  // caller's level-0 image with an odd stride: byte loads
+      uint8_t *rb = reinterpret_cast<uint8_t *>(rawp);
+      for (int i = lane; i < DP_RAW_ROWS * 31; i += 64) {
+        const int yy = i / 31, xx = i - yy * 31;
+        rb[yy * (DP_RAW_DW * 4) + xx] = k.img[(long long)(k.cy - 15 + yy) * k.pitch + k.cx - 15 + xx];
       }
     }
-  }
-  int rox;
-  if (((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch) & 3) == 0) {
-    const int rxa = (cx - 15) & ~3;
-    rox = (cx - 15) - rxa;
-    const int r0 = lane / DP_RAW_DW, dwc = lane - r0 * DP_RAW_DW;
-    const uint8_t *src = img + (long long)(cy - 15 + r0) * pitch + rxa + dwc * 4;
-    const long long stepR = 7ll * pitch;
-    if (lane < 7 * DP_RAW_DW) {
-#pragma unroll
-      for (int it = 0; it < (DP_RAW_ROWS + 6) / 7; it++) {
-        if (it * 7 + r0 < DP_RAW_ROWS) rawp[it * 7 * DP_RAW_DW + lane] = *reinterpret_cast<const uint32_t *>(src);
-        src += stepR;
-      }
+    // each wave reads back only what it wrote itself: LDS operations of one wave complete in order, so a wave-level
+    // fence (no s_barrier across the workgroup) is all that is needed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  KP cur = decode(0);
+  issue(cur);
+  for (int j = 0; j < nmine; j++) {
+    stage(cur);
+    KP nxt = cur;
+    if (j + 1 < nmine) { nxt = decode(j + 1); issue(nxt); }
+    // IC_Angle (ORBextractor.cc:77-104): lanes 2*(v+15) and 2*(v+15)+1 sum the left (u < 0) and right (u >= 0) part
+    // of row v of the circular patch.  Each half row is 16 bytes read as dwords; |u| weights and the circular mask
+    // (|u| <= umax[|v|]) come from a per-lane table (angTab[lane] = 4 weight dwords + 4 mask dwords) and the sums
+    // are v_dot4_u32_u8.
+    int m10 = 0, m01 = 0;
+    if (lane < 62) {
+      const int r = lane >> 1, half = lane & 1;
+      const int sb = cur.rox + (half ? 15 : 0);  // left half: u = -15..0 at bytes rox..rox+15, right half: u = 0..15 at rox+15..
+      const uint32_t *rowd = rawp + r * DP_RAW_DW + (sb >> 2);
+      const uint32_t sh = (uint32_t)(sb & 3);
+      const uint32_t d0 = rowd[0], d1 = rowd[1], d2 = rowd[2], d3 = rowd[3], d4 = rowd[4];
+      const uint32_t q0 = __builtin_amdgcn_alignbyte(d1, d0, sh), q1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+      const uint32_t q2 = __builtin_amdgcn_alignbyte(d3, d2, sh), q3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+      const uint4 W = angW, Km = angK;
+      const uint32_t a10 = __builtin_amdgcn_udot4(q0, W.x, __builtin_amdgcn_udot4(q1, W.y, __builtin_amdgcn_udot4(q2, W.z, __builtin_amdgcn_udot4(q3, W.w, 0u, false), false), false), false);
+      const uint32_t rs = __builtin_amdgcn_udot4(q0, Km.x, __builtin_amdgcn_udot4(q1, Km.y, __builtin_amdgcn_udot4(q2, Km.z, __builtin_amdgcn_udot4(q3, Km.w, 0u, false), false), false), false);
+      m10 = half ? (int)a10 : -(int)a10;
+      m01 = __mul24(r - 15, (int)rs);
     }
-  } else {  // caller's level-0 image with an odd stride: byte loads
-    rox = 0;
-    uint8_t *rb = reinterpret_cast<uint8_t *>(rawp);
-    for (int i = lane; i < DP_RAW_ROWS * 31; i += 64) {
-      const int yy = i / 31, xx = i - yy * 31;
-      rb[yy * (DP_RAW_DW * 4) + xx] = img[(long long)(cy - 15 + yy) * pitch + cx - 15 + xx];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
+    if (K.dbg == 12) { if (m10 + m01 == 12345678 && pp[0].x + pp[1].y + pp[2].z + pp[3].w == 77777) nOut[0] = 1; cur = nxt; continue; }
+    const float angle = fb_fast_atan2((float)m01, (float)m10);
+    // computeOrbDescriptor (ORBextractor.cc:107-147): lane computes tests 4*lane .. 4*lane+3
+    const float factorPI = 0x1.1df46ap-6f;
+    float sa, ca;
+    fb_sincos_f(angle * factorPI, &sa, &ca);
+    const float a = ca, bb = sa;
+    const uint8_t *centre = reinterpret_cast<const uint8_t *>(blp) + 18 * (DP_BL_DW * 4) + cur.box + 18;
+    int nib = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const float x0 = (float)pp[t].x, y0 = (float)pp[t].y, x1 = (float)pp[t].z, y1 = (float)pp[t].w;
+      const int t0 = centre[__mul24(fb_cvround(x0 * bb + y0 * a), DP_BL_DW * 4) + fb_cvround(x0 * a - y0 * bb)];
+      const int t1 = centre[__mul24(fb_cvround(x1 * bb + y1 * a), DP_BL_DW * 4) + fb_cvround(x1 * a - y1 * bb)];
+      nib |= (t0 < t1) << t;
     }
-  }
-  __syncthreads();
-  // IC_Angle (ORBextractor.cc:77-104): lanes 2*(v+15) and 2*(v+15)+1 sum the left (u < 0) and right (u >= 0) part
-  // of row v of the circular patch
-  // Each half row is 16 bytes read as dwords; |u| weights and the circular mask (|u| <= umax[|v|]) come from a per-lane
-  // table (angTab[lane] = 4 weight dwords + 4 mask dwords) and the sums are v_dot4_u32_u8.
-  int m10 = 0, m01 = 0;
-  if (lane < 62) {
-    const int r = lane >> 1, half = lane & 1;
-    const int sb = rox + (half ? 15 : 0);  // left half: u = -15..0 at bytes rox..rox+15, right half: u = 0..15 at rox+15..
-    const uint32_t *rowd = rawp + r * DP_RAW_DW + (sb >> 2);
-    const uint32_t sh = (uint32_t)(sb & 3);
-    const uint32_t d0 = rowd[0], d1 = rowd[1], d2 = rowd[2], d3 = rowd[3], d4 = rowd[4];
-    const uint32_t q0 = __builtin_amdgcn_alignbyte(d1, d0, sh), q1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    const uint32_t q2 = __builtin_amdgcn_alignbyte(d3, d2, sh), q3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
-    const uint4 W = angTab[lane * 2], Km = angTab[lane * 2 + 1];
-    const uint32_t a10 = __builtin_amdgcn_udot4(q0, W.x, __builtin_amdgcn_udot4(q1, W.y, __builtin_amdgcn_udot4(q2, W.z, __builtin_amdgcn_udot4(q3, W.w, 0u, false), false), false), false);
-    const uint32_t rs = __builtin_amdgcn_udot4(q0, Km.x, __builtin_amdgcn_udot4(q1, Km.y, __builtin_amdgcn_udot4(q2, Km.z, __builtin_amdgcn_udot4(q3, Km.w, 0u, false), false), false), false);
-    m10 = half ? (int)a10 : -(int)a10;
-    m01 = (r - 15) * (int)rs;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
-  const float angle = fb_fast_atan2((float)m01, (float)m10);
-  // computeOrbDescriptor (ORBextractor.cc:107-147): lane computes tests 4*lane .. 4*lane+3
-  const float factorPI = 0x1.1df46ap-6f;
-  float sa, ca;
-  fb_sincos_f(angle * factorPI, &sa, &ca);
-  const float a = ca, bb = sa;
-  const uint8_t *centre = reinterpret_cast<const uint8_t *>(blp) + 18 * (DP_BL_DW * 4) + box + 18;
-  int nib = 0;
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    const int4 pp = reinterpret_cast<const int4 *>(c_pattern)[lane * 4 + t];
-    const float x0 = (float)pp.x, y0 = (float)pp.y, x1 = (float)pp.z, y1 = (float)pp.w;
-    const int t0 = centre[fb_cvround(x0 * bb + y0 * a) * (DP_BL_DW * 4) + fb_cvround(x0 * a - y0 * bb)];
-    const int t1 = centre[fb_cvround(x1 * bb + y1 * a) * (DP_BL_DW * 4) + fb_cvround(x1 * a - y1 * bb)];
-    nib |= (t0 < t1) << t;
-  }
-  // lane 2j holds the low nibble of descriptor byte j, lane 2j+1 the high nibble; lanes 8j assemble dword j
-  const int hi = __shfl_down(nib, 1, 64);
-  const int byteVal = nib | (hi << 4);
-  const int b1 = __shfl_down(byteVal, 2, 64), b2 = __shfl_down(byteVal, 4, 64), b3 = __shfl_down(byteVal, 6, 64);
-  const uint32_t dw = (uint32_t)byteVal | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16) | ((uint32_t)b3 << 24);
-  const long long o = (long long)b * K.capOut + idx;
-  if ((lane & 7) == 0) reinterpret_cast<uint32_t *>(desc + o * 32)[lane >> 3] = dw;
-  if (lane == 0) {
-    fb_keypoint kp;
-    kp.x = (float)cx;
-    kp.y = (float)cy;
-    if (myl != 0) { kp.x *= Lv.scale; kp.y *= Lv.scale; }  // ORBextractor.cc:1095-1101
-    kp.size = (float)Lv.patchSize;
-    kp.angle = angle;
-    kp.response = (float)resp;
-    kp.octave = myl;
-    kps[o] = kp;
+    // lane 2j holds the low nibble of descriptor byte j, lane 2j+1 the high nibble; lanes 8j assemble dword j
+    const int hi = __shfl_down(nib, 1, 64);
+    const int byteVal = nib | (hi << 4);
+    const int b1 = __shfl_down(byteVal, 2, 64), b2 = __shfl_down(byteVal, 4, 64), b3 = __shfl_down(byteVal, 6, 64);
+    const uint32_t dw = (uint32_t)byteVal | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16) | ((uint32_t)b3 << 24);
+    const long long o = (long long)b * K.capOut + first + j;
+    if ((lane & 7) == 0) reinterpret_cast<uint32_t *>(desc + o * 32)[lane >> 3] = dw;
+    if (lane == 0) {
+      fb_keypoint kp;
+      kp.x = (float)cur.cx;
+      kp.y = (float)cur.cy;
+      if (cur.myl != 0) { kp.x *= cur.scale; kp.y *= cur.scale; }  // ORBextractor.cc:1095-1101
+      kp.size = (float)cur.patchSize;
+      kp.angle = angle;
+      kp.response = (float)cur.resp;
+      kp.octave = cur.myl;
+      kps[o] = kp;
+    }
+    // the LDS reads of this key point are ordered before the writes of the next one (same wave, in-order LDS)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    cur = nxt;
   }
 }
 
@@ -1225,7 +1283,7 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
   }
   {
   fb::ProfScope prof_(fb::P_DESCRIBE, s);
-  k_describe<<<dim3((K.capOut + 7) / 8 * 8, batch), 64, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
+  k_describe<<<dim3(((K.capOut + DESC_WPB * DESC_KPW - 1) / (DESC_WPB * DESC_KPW) + 7) / 8 * 8, batch), 64 * DESC_WPB, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
                                                    o->blur.as<uint8_t>(), o->angTab.as<uint4>(), o->lvlOut.as<uint32_t>(), lvlCount, d_keypoints,
                                                    d_descriptors, d_n);
   }
