@@ -248,7 +248,7 @@ EXPORTS = [
     "fb_abi_version", "fb_last_error", "fb_device_count", "fb_set_device",
     "fb_prof_enable", "fb_prof_only", "fb_prof_reset", "fb_prof_report",
     "fb_orb_create", "fb_orb_destroy", "fb_orb_get_tables", "fb_orb_capacity", "fb_orb_extract", "fb_orb_extract_batch_dev",
-    "fb_orb_get_level", "fb_orb_get_blurred_level", "fb_orb_debug_candidates", "fb_grid_build_batch_dev", "fb_bird_keys_to_cam_dev",
+    "fb_orb_get_level", "fb_orb_get_blurred_level", "fb_orb_debug_candidates", "fb_orb_debug_timers", "fb_grid_build_batch_dev", "fb_bird_keys_to_cam_dev",
     "fb_descriptor_distance_dev", "fb_descriptor_distance",
     "fb_match_projection_frame_dev", "fb_match_projection_frame",
     "fb_match_bird_mappoints_dev", "fb_match_bird_mappoints",

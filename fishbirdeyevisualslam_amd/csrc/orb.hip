@@ -38,6 +38,7 @@ struct LevelInfo {
   int N;                 // mnFeaturesPerLevel
   long long candBase;    // element offset into one image's candidate array
   int candCap;
+  int slotCap;           // candidate slots per FAST cell (k_fast writes cell c's survivors at candBase + c * slotCap)
   int outBase, outCap;   // element offset / capacity in one image's per-level keypoint array
   int nIni;
   float hX;
@@ -51,6 +52,7 @@ struct OrbK {
   int fastTileBytes, fastMaxOut, fastMaxPix;  // LDS carve of k_fast
   int fastTP;                                 // tile pitch instantiation of k_fast (44 / 56 / 72)
   int dbg;  // FB_FAST_DBG ablation switch (0 = normal)
+  unsigned long long *timers;  // FB_FAST_DBG=20: per-phase wave time of k_fast (fb_orb_debug_timers)
   int cellBase[FB_MAX_LEVELS + 1];  // first FAST cell of each level (contiguous copy for one scalar load)
   long long pyrStride;   // bytes per image of levels >= 1
   long long blurStride;  // bytes per image of the blurred pyramid (all levels)
@@ -283,7 +285,7 @@ constexpr int FAST_MAX_TILE = 72;  // cell window <= wCell+6 <= 65 px, +3 alignm
 template <int TP>
 __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__ img0, long long imgStride, int pitch0,
                                              const uint8_t *__restrict__ pyr, uint32_t *__restrict__ cand,
-                                             int *__restrict__ candCount) {
+                                             int *__restrict__ cellCount) {
   // LDS carve (sized on the host for the largest cell of this image size): tile (later: survivors) | sc | list
   extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
   uint8_t *tile = fsm;
@@ -293,6 +295,12 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
   uint32_t *s_out = reinterpret_cast<uint32_t *>(fsm);
   unsigned short *s_list = reinterpret_cast<unsigned short *>(fsm + 2 * K.fastTileBytes);  // [fastMaxPix]
   const int b = blockIdx.y, lane = threadIdx.x;
+  // FB_FAST_DBG=20: one workgroup in 16 accumulates its phase times in registers and adds them once, at the end
+  const bool timed = K.dbg == 20 && (blockIdx.x & 15) == 0;
+  unsigned long long t_mark = 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (timed) { __builtin_amdgcn_sched_barrier(0); t_mark = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+  const unsigned long long t_start = t_mark;
+#define FAST_TICK(slot_) if (timed) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); t_acc[slot_] += t_ - t_mark; t_mark = t_; }
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one), so give each
   // XCD a contiguous run of cells -- neighbouring cells overlap by 6 px and share 64-B lines in that XCD's L2
   int cell, l = 0;
@@ -304,6 +312,7 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
 #pragma unroll
   for (int i = 1; i < FB_MAX_LEVELS; i++) l += (i < K.nlevels && cell >= K.cellBase[i]) ? 1 : 0;
   const LevelInfo &Lv = K.L[l];
+  const int cellAll = cell;
   cell -= Lv.cellBase;
   const int ci = cell / Lv.nCols, cj = cell % Lv.nCols;
   const int maxBX = Lv.w - BORDER, maxBY = Lv.h - BORDER;
@@ -312,6 +321,8 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
   const int x1 = min(x0 + Lv.wCell + 6, maxBX), y1 = min(y0 + Lv.hCell + 6, maxBY);
   const int cw = x1 - x0, ch = y1 - y0;
   if (cw < 7 || ch < 7) return;
+  if (timed) { if (cw + ch + x0 + y0 == 123456789) cand[0] = 1; }  // forces the kernel-argument loads to have landed
+  FAST_TICK(9)  // cell decode (scalar loads of the level tables)
   const uint8_t *img;
   int pitch;
   if (l == 0) { img = img0 + (long long)b * imgStride; pitch = pitch0; }
@@ -322,15 +333,34 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
   constexpr int tp = TP;  // tile pitch
   const int ox = x0 - xa;
   if (aligned) {
-    // fixed lane -> (row within a group, dword) mapping: the global address and the LDS index advance by constants
+    // fixed lane -> (row within a group, dword) mapping: the global address and the LDS index advance by constants.
+    // ALL loads of a batch are issued before the first LDS write (rows past the window are clamped, their data is
+    // dropped): a load -> wait -> write loop serialises one memory latency per RPI rows -- measured with the phase
+    // timers (FB_FAST_DBG=20) that loop was half of a wave's life time.
     constexpr int DW = TP / 4, RPI = 64 / DW;  // dwords per tile row, rows per iteration
+    constexpr int NIT1 = (40 + RPI - 1) / RPI, NIT2 = (FAST_MAX_TILE + RPI - 1) / RPI - NIT1;  // usual windows: <= 40 rows
     const int wpr = ((x1 - xa) + 3) >> 2;      // dwords per window row (<= DW)
     const int r0 = lane / DW, dwc = lane - r0 * DW;
     if (r0 < RPI && dwc < wpr) {
-      const uint8_t *src = img + (long long)(y0 + r0) * pitch + xa + dwc * 4;
-      const long long step = (long long)RPI * pitch;
-      uint32_t *dst = reinterpret_cast<uint32_t *>(&tile[r0 * tp + dwc * 4]);
-      for (int yy = r0; yy < ch; yy += RPI, src += step, dst += RPI * DW) *dst = *reinterpret_cast<const uint32_t *>(src);
+      const uint8_t *src = img + (long long)y0 * pitch + xa;  // wave-uniform base + 32-bit lane offsets
+      const uint32_t lo = (uint32_t)dwc * 4u;
+      uint32_t *dst = reinterpret_cast<uint32_t *>(&tile[dwc * 4]);
+      uint32_t v[NIT1 > NIT2 ? NIT1 : NIT2];
+#pragma unroll
+      for (int it = 0; it < NIT1; it++) {
+        if (K.dbg == 21 && (it & 1)) { v[it] = 0; continue; }  // experiment: half of the row requests (results are wrong)
+        v[it] = *reinterpret_cast<const uint32_t *>(src + ((uint32_t)__mul24(min(r0 + it * RPI, ch - 1), pitch) + lo));
+      }
+#pragma unroll
+      for (int it = 0; it < NIT1; it++)
+        if (r0 + it * RPI < ch) dst[(r0 + it * RPI) * DW] = v[it];
+      if (ch > NIT1 * RPI) {  // tall cells of small levels
+#pragma unroll
+        for (int it = 0; it < NIT2; it++) v[it] = *reinterpret_cast<const uint32_t *>(src + ((uint32_t)__mul24(min(r0 + (NIT1 + it) * RPI, ch - 1), pitch) + lo));
+#pragma unroll
+        for (int it = 0; it < NIT2; it++)
+          if (r0 + (NIT1 + it) * RPI < ch) dst[(r0 + (NIT1 + it) * RPI) * DW] = v[it];
+      }
     }
   } else {
     for (int i = lane; i < cw * ch; i += 64) {
@@ -338,8 +368,11 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
       tile[yy * tp + xx] = img[(long long)(y0 + yy) * pitch + x0 + xx];
     }
   }
+  FAST_TICK(0)  // address set-up + load issue
   for (int i = lane; i < (tp * ch + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(sc)[i] = 0;
   __syncthreads();
+  if (timed) { if (tile[lane] == 255 && sc[lane] == 7) cand[0] = 1; }  // forces the wait for the staged tile
+  FAST_TICK(1)  // wait for the tile
   if (K.dbg == 1) { if (tile[lane] == 255 && sc[lane] == 7) cand[0] = 1; return; }
   const int dwid = cw - 6, dhei = ch - 6, npix = dwid * dhei;
   // ---- ONE sweep over the cell: compact every pixel that can be a corner (necessary compass test) into two lists
@@ -400,6 +433,7 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
     }
   }
   __syncthreads();
+  FAST_TICK(2)  // sweep
   if (K.dbg == 4) { if (nlA + nlB == 123456) cand[0] = 1; return; }
   for (int pass = 0; pass < 2; pass++) {
     const int T = pass == 0 ? K.iniTh : K.minTh;
@@ -412,6 +446,7 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
       sc[o] = (uint8_t)(scv >= T ? scv : 0);
     }
     __syncthreads();
+    if (pass == 0) { FAST_TICK(3) } else { FAST_TICK(6) }  // score
     if (K.dbg == 2) { if (sc[lane] == 255) cand[0] = 1; return; }
     // ---- 3x3 strict non-max suppression over the candidate list (only listed pixels can hold a score >= T);
     //      neighbours below T were stored as 0, the rim holds 0
@@ -436,16 +471,26 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
       if (keep) s_out[total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = rec;
       total += __popcll(m);
     }
+    if (pass == 0) { FAST_TICK(4) } else { FAST_TICK(7) }  // NMS
     if (K.dbg == 3) { if (total == 12345) cand[0] = 1; return; }
     if (total == 0) continue;  // wave-uniform: retry with minThFAST
     __syncthreads();
-    int gbase = 0;
-    if (lane == 0) gbase = atomicAdd(&candCount[b * K.nlevels + l], total);
-    gbase = __shfl(gbase, 0, 64);
-    uint32_t *out = cand + (long long)b * K.candStride + Lv.candBase + gbase;
+    // Every cell owns a fixed run of slotCap candidate slots and a count (pre-zeroed by the host); k_octree packs the
+    // runs of a level.  (One returning atomic per cell on a per-level counter was a third of a wave's life time: the
+    // ~900 cells of a level queue up on one address.)
+    uint32_t *out = cand + (long long)b * K.candStride + Lv.candBase + (long long)cell * Lv.slotCap;
     for (int i = lane; i < total; i += 64) out[i] = s_out[i];
+    if (lane == 0) cellCount[(long long)b * K.totalCells + cellAll] = total;
+    if (pass == 0) { FAST_TICK(5) } else { FAST_TICK(8) }  // emission
     break;
   }
+  if (timed && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) atomicAdd(&K.timers[i], t_acc[i]);
+    atomicAdd(&K.timers[10], t_mark - t_start);
+    atomicAdd(&K.timers[11], 1ull);
+  }
+#undef FAST_TICK
 }
 
 // ------------------------------------------------------------------------------------------
@@ -478,8 +523,8 @@ __device__ __forceinline__ ONode child_of(const ONode &n, int q, int cnt) {
   return c;
 }
 
-__global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restrict__ cand,
-                                                const int *__restrict__ candCount, uint16_t *__restrict__ nodeOf,
+__global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restrict__ cellCand, const int *__restrict__ cellCount,
+                                                uint32_t *__restrict__ cand, int *__restrict__ candCount, uint16_t *__restrict__ nodeOf,
                                                 uint32_t *__restrict__ lvlOut, int *__restrict__ lvlCount, int maxNodes) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -494,8 +539,50 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
   unsigned char *split = reinterpret_cast<unsigned char *>(order + M);  // [M] node is split this round
   unsigned long long *best = reinterpret_cast<unsigned long long *>(smem + (((size_t)(split + M - smem)) + 7 & ~(size_t)7));
   __shared__ int s_w[4], s_S, s_nexp, s_jstar;
-  const int n = candCount[b * K.nlevels + l];
-  const uint32_t *cd = cand + (long long)b * K.candStride + Lv.candBase;
+  // ---- pack the per-cell candidate runs of k_fast into one dense list (order is irrelevant downstream: the quadtree
+  //      breaks response ties with an order key derived from x, y).  offs[] aliases the node lists, not yet in use.
+  uint32_t *cdw = cand + (long long)b * K.candStride + Lv.candBase;
+  int n;
+  {
+    int *offs = reinterpret_cast<int *>(smem);  // [ncell + 1]
+    const int ncell = Lv.nCols * Lv.nRows;
+    const int *cc = cellCount + (long long)b * K.totalCells + Lv.cellBase;
+    const uint32_t *sp = cellCand + (long long)b * K.candStride + Lv.candBase;
+    int run = 0;
+    for (int c0 = 0; c0 < ncell; c0 += 256) {
+      const int c = c0 + tid;
+      const int v = c < ncell ? cc[c] : 0;
+      int tot;
+      const int ex = block_excl_scan256(v, s_w, &tot);
+      if (c < ncell) offs[c] = run + ex;
+      run += tot;
+      __syncthreads();  // s_w is reused by the next chunk
+    }
+    n = run;
+    if (tid == 0) { offs[ncell] = n; candCount[b * K.nlevels + l] = n; }
+    __syncthreads();
+    // dense index -> cell by binary search over the offsets; 4 independent copies per thread and step so that the
+    // loads are in flight together
+    for (int k0 = tid; k0 < n; k0 += 256 * 4) {
+      uint32_t val[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = min(k0 + u * 256, n - 1);
+        int lo = 0, hi = ncell;  // offs[lo] <= k < offs[hi]
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (offs[mid] <= k) lo = mid; else hi = mid;
+        }
+        val[u] = sp[(long long)lo * Lv.slotCap + (k - offs[lo])];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (k0 + u * 256 < n) cdw[k0 + u * 256] = val[u];
+    }
+    __threadfence_block();
+    __syncthreads();  // the lists below overwrite offs[]; the dense list is read back by this block only
+  }
+  const uint32_t *cd = cdw;
   uint16_t *nof = nodeOf + (long long)b * K.candStride + Lv.candBase;
   int *outCount = lvlCount + b * K.nlevels + l;
   uint32_t *out = lvlOut + (long long)b * K.outStride + Lv.outBase;
@@ -982,7 +1069,7 @@ struct fb_orb {
   OrbK K;
   int maxNodes = 0;
   size_t octreeLds = 0;
-  fb::DevBuf pyr, blur, cand, nodeOf, counts, lvlOut, tabs, angTab;
+  fb::DevBuf pyr, blur, cand, cellCand, cellCount, nodeOf, counts, lvlOut, tabs, angTab, timers;
   ResizeTabs rt[FB_MAX_LEVELS];
   bool rowsOK[FB_MAX_LEVELS] = {};  // k_resize_rows' 12-byte window covers every 4-pixel group of the level
   // last call (for fb_orb_get_level)
@@ -1089,7 +1176,8 @@ int prepare(fb_orb *o, int w, int h, int batch) {
     // NMS worst case: one survivor per 2x2 block of each cell's detection area
     const int dw = std::max(L.w - 2 * EDGE_THRESHOLD, 0), dh = std::max(L.h - 2 * EDGE_THRESHOLD, 0);
     L.candBase = candOff;
-    L.candCap = L.nCols * L.nRows * (((L.wCell + 1) / 2) * ((L.hCell + 1) / 2)) + 16;
+    L.slotCap = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);  // strict 3x3 maxima: at most one per 2x2 pixels
+    L.candCap = L.nCols * L.nRows * L.slotCap + 16;
     (void)dw; (void)dh;
     if (L.candCap >= (1 << 24)) { fb::set_error("level %d: more than 2^24 FAST candidates possible", l); return FB_ERR_CAPACITY; }
     candOff += (L.candCap + 3) & ~3;
@@ -1164,6 +1252,11 @@ int prepare(fb_orb *o, int w, int h, int batch) {
   const size_t M = maxNodes;
   size_t lds = 2 * M * sizeof(ONode) + 4 * M * 4 + 4 * M * 2 + M * 2 + M * 2 + M;
   lds = ((lds + 7) & ~(size_t)7) + M * 8 + 16;
+  {
+    size_t maxCells = 0;
+    for (int l = 0; l < p.nlevels; l++) maxCells = std::max(maxCells, (size_t)K.L[l].nCols * K.L[l].nRows);
+    lds = std::max(lds, (maxCells + 1) * 4 + 16);  // the per-cell offsets of the packing prologue alias the node lists
+  }
   if (lds > 160 * 1024) { fb::set_error("nfeatures too large for the LDS quadtree (%zu B)", lds); return FB_ERR_CAPACITY; }
   o->octreeLds = lds;
   FB_TRY(o->tabs.upload(tabBytes.data(), tabBytes.size()));
@@ -1193,8 +1286,13 @@ int prepare(fb_orb *o, int w, int h, int batch) {
   FB_TRY(o->pyr.alloc(B * K.pyrStride + 256));
   FB_TRY(o->blur.alloc(B * K.blurStride + 256));
   FB_TRY(o->cand.alloc(B * K.candStride * 4 + 16));
+  FB_TRY(o->cellCand.alloc(B * K.candStride * 4 + 16));
+  FB_TRY(o->cellCount.alloc(B * (size_t)K.totalCells * 4 + 16));
   FB_TRY(o->nodeOf.alloc(B * K.candStride * 2 + 16));
   FB_TRY(o->counts.alloc(B * p.nlevels * 4 * 2));  // candCount | lvlCount
+  FB_TRY(o->timers.alloc(16 * 8));
+  FB_HIP(hipMemset(o->timers.p, 0, 16 * 8));
+  K.timers = o->timers.as<unsigned long long>();
   FB_TRY(o->lvlOut.alloc(B * K.outStride * 4 + 16));
   o->w = w; o->h = h; o->batchCap = batch;
   return FB_OK;
@@ -1242,7 +1340,7 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
   const int nl = K.nlevels;
   int *candCount = o->counts.as<int>();
   int *lvlCount = candCount + (size_t)o->batchCap * nl;
-  FB_HIP(hipMemsetAsync(candCount, 0, (size_t)batch * nl * 4, s));
+  FB_HIP(hipMemsetAsync(o->cellCount.p, 0, (size_t)batch * K.totalCells * 4, s));
   // pyramid
   for (int l = 1; l < nl; l++) {
     const LevelInfo &D = K.L[l], &S = K.L[l - 1];
@@ -1264,11 +1362,11 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
     const dim3 grdF((K.totalCells + 7) / 8 * 8, batch);
     const size_t ldsF = (size_t)2 * K.fastTileBytes + 2 * K.fastMaxPix;
     if (K.fastTP == 44)
-      k_fast<44><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cand.as<uint32_t>(), candCount);
+      k_fast<44><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cellCand.as<uint32_t>(), o->cellCount.as<int>());
     else if (K.fastTP == 56)
-      k_fast<56><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cand.as<uint32_t>(), candCount);
+      k_fast<56><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cellCand.as<uint32_t>(), o->cellCount.as<int>());
     else
-      k_fast<FAST_MAX_TILE><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cand.as<uint32_t>(), candCount);
+      k_fast<FAST_MAX_TILE><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cellCand.as<uint32_t>(), o->cellCount.as<int>());
   }
   {
     fb::ProfScope prof_(fb::P_BLUR, s);
@@ -1278,7 +1376,7 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->octreeLds));
   {
   fb::ProfScope prof_(fb::P_OCTREE, s);
-  k_octree<<<dim3(nl, batch), 256, o->octreeLds, s>>>(K, o->cand.as<uint32_t>(), candCount, o->nodeOf.as<uint16_t>(),
+  k_octree<<<dim3(nl, batch), 256, o->octreeLds, s>>>(K, o->cellCand.as<uint32_t>(), o->cellCount.as<int>(), o->cand.as<uint32_t>(), candCount, o->nodeOf.as<uint16_t>(),
                                                        o->lvlOut.as<uint32_t>(), lvlCount, o->maxNodes);
   }
   {
@@ -1313,6 +1411,15 @@ int fb_orb_extract(fb_orb *o, const uint8_t *image, int width, int height, int s
   if (*n_out > cap) { fb::set_error("keypoint capacity exceeded"); return FB_ERR_CAPACITY; }
   FB_TRY(dk.download(keypoints, (size_t)*n_out * sizeof(fb_keypoint)));
   return dd.download(descriptors, (size_t)*n_out * 32);
+}
+
+int fb_orb_debug_timers(fb_orb *o, uint64_t *dst16) {
+  FB_TRY(fb::check_device());
+  FB_ARG(o && dst16 && o->timers.p);
+  FB_HIP(hipDeviceSynchronize());
+  FB_HIP(hipMemcpy(dst16, o->timers.p, 16 * 8, hipMemcpyDeviceToHost));
+  FB_HIP(hipMemset(o->timers.p, 0, 16 * 8));
+  return FB_OK;
 }
 
 int fb_orb_debug_candidates(fb_orb *o, int b, int level, uint32_t *dst, int cap) {

@@ -120,6 +120,10 @@ int fb_orb_get_blurred_level(fb_orb *h, int b, int level, uint8_t *dst);
  * DistributeOctTree (vToDistributeKeys, ORBextractor.cc:822-824), packed
  * x | y<<12 | response<<24 in level coordinates, unordered.  Returns the count (>=0). */
 int fb_orb_debug_candidates(fb_orb *h, int b, int level, uint32_t *dst, int cap);
+/* profiling aid: with FB_FAST_DBG=20 one k_fast workgroup in 16 accumulates shader-clock cycles per phase
+ * (0 address set-up + load issue, 1 tile wait, 2 sweep, 3/4/5 score/NMS/slot reservation at iniThFAST, 6/7/8 the same
+ * at minThFAST, 9 cell decode, 10 whole wave, 11 number of timed waves); reading resets the counters.          */
+int fb_orb_debug_timers(fb_orb *h, uint64_t *dst16);
 
 /* ======================================================================== */
 /* Frame grid (src/Frame.cc:381-411, 548-570; include/Frame.h:38-40)         */
