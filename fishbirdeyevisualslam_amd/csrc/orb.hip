@@ -54,6 +54,8 @@ struct OrbK {
   int dbg;  // FB_FAST_DBG ablation switch (0 = normal)
   unsigned long long *timers;  // FB_FAST_DBG=20: per-phase wave time of k_fast (fb_orb_debug_timers)
   int cellBase[FB_MAX_LEVELS + 1];  // first FAST cell of each level (contiguous copy for one scalar load)
+  int grpBase[FB_MAX_LEVELS + 1];   // first k_fast wave of each level (a wave = FAST_CPW consecutive cells)
+  int totalGroups;
   long long pyrStride;   // bytes per image of levels >= 1
   long long blurStride;  // bytes per image of the blurred pyramid (all levels)
   int blurStrips[FB_MAX_LEVELS + 1];  // first k_blur strip of each level
@@ -282,8 +284,9 @@ constexpr int FAST_MAX_TILE = 72;  // cell window <= wCell+6 <= 65 px, +3 alignm
 //     (the quadtree breaks response ties with an order key derived from x,y).
 // TP = tile pitch in bytes, a compile-time constant so that every LDS access of the sweep / score / NMS is
 // base + immediate offset (44 covers cells up to 35 px wide, i.e. every level of the usual image sizes).
-template <int TP>
-__global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__ img0, long long imgStride, int pitch0,
+constexpr int FAST_CPW = 4;  // consecutive cells per wave; the tile of cell i+1 is in flight while cell i is processed
+template <int TP, bool TIMED>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_fast(OrbK K, const uint8_t *__restrict__ img0, long long imgStride, int pitch0,
                                              const uint8_t *__restrict__ pyr, uint32_t *__restrict__ cand,
                                              int *__restrict__ cellCount) {
   // LDS carve (sized on the host for the largest cell of this image size): tile (later: survivors) | sc | list
@@ -296,195 +299,222 @@ __global__ __launch_bounds__(64) void k_fast(OrbK K, const uint8_t *__restrict__
   unsigned short *s_list = reinterpret_cast<unsigned short *>(fsm + 2 * K.fastTileBytes);  // [fastMaxPix]
   const int b = blockIdx.y, lane = threadIdx.x;
   // FB_FAST_DBG=20: one workgroup in 16 accumulates its phase times in registers and adds them once, at the end
-  const bool timed = K.dbg == 20 && (blockIdx.x & 15) == 0;
+  const bool timed = TIMED && (blockIdx.x & 15) == 0;  // the TIMED instantiation is launched for FB_FAST_DBG=20 only
   unsigned long long t_mark = 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (timed) { __builtin_amdgcn_sched_barrier(0); t_mark = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
   const unsigned long long t_start = t_mark;
-#define FAST_TICK(slot_) if (timed) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); t_acc[slot_] += t_ - t_mark; t_mark = t_; }
+#define FAST_TICK(slot_) if (TIMED && timed) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); t_acc[slot_] += t_ - t_mark; t_mark = t_; }
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one), so give each
-  // XCD a contiguous run of cells -- neighbouring cells overlap by 6 px and share 64-B lines in that XCD's L2
-  int cell, l = 0;
+  // XCD a contiguous run of cell groups -- neighbouring cells overlap by 6 px and share lines in that XCD's L2
+  int grp, l = 0;
   {
     const int nb = gridDim.x, per = (nb + 7) >> 3;
-    cell = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (cell >= K.totalCells) return;  // grid is padded to a multiple of 8
+    grp = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (grp >= K.totalGroups) return;  // grid is padded to a multiple of 8
   }
 #pragma unroll
-  for (int i = 1; i < FB_MAX_LEVELS; i++) l += (i < K.nlevels && cell >= K.cellBase[i]) ? 1 : 0;
+  for (int i = 1; i < FB_MAX_LEVELS; i++) l += (i < K.nlevels && grp >= K.grpBase[i]) ? 1 : 0;
   const LevelInfo &Lv = K.L[l];
-  const int cellAll = cell;
-  cell -= Lv.cellBase;
-  const int ci = cell / Lv.nCols, cj = cell % Lv.nCols;
+  const int cFirst = (grp - K.grpBase[l]) * FAST_CPW, cEnd = min(cFirst + FAST_CPW, Lv.nCols * Lv.nRows);
   const int maxBX = Lv.w - BORDER, maxBY = Lv.h - BORDER;
-  const int x0 = BORDER + cj * Lv.wCell, y0 = BORDER + ci * Lv.hCell;
-  if (y0 >= maxBY - 3 || x0 >= maxBX - 6) return;  // ORBextractor.cc:794,802
-  const int x1 = min(x0 + Lv.wCell + 6, maxBX), y1 = min(y0 + Lv.hCell + 6, maxBY);
-  const int cw = x1 - x0, ch = y1 - y0;
-  if (cw < 7 || ch < 7) return;
-  if (timed) { if (cw + ch + x0 + y0 == 123456789) cand[0] = 1; }  // forces the kernel-argument loads to have landed
-  FAST_TICK(9)  // cell decode (scalar loads of the level tables)
   const uint8_t *img;
   int pitch;
   if (l == 0) { img = img0 + (long long)b * imgStride; pitch = pitch0; }
   else { img = pyr + (long long)b * K.pyrStride + Lv.off; pitch = Lv.pitch; }
-  // stage the window: tile column 0 = image column xa (4-byte aligned when the image allows it)
+  // the window is staged with tile column 0 = image column xa (4-byte aligned when the image allows it)
   const bool aligned = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch) & 3) == 0;
-  const int xa = aligned ? (x0 & ~3) : x0;
   constexpr int tp = TP;  // tile pitch
-  const int ox = x0 - xa;
-  if (aligned) {
-    // fixed lane -> (row within a group, dword) mapping: the global address and the LDS index advance by constants.
-    // ALL loads of a batch are issued before the first LDS write (rows past the window are clamped, their data is
-    // dropped): a load -> wait -> write loop serialises one memory latency per RPI rows -- measured with the phase
-    // timers (FB_FAST_DBG=20) that loop was half of a wave's life time.
-    constexpr int DW = TP / 4, RPI = 64 / DW;  // dwords per tile row, rows per iteration
-    constexpr int NIT1 = (40 + RPI - 1) / RPI, NIT2 = (FAST_MAX_TILE + RPI - 1) / RPI - NIT1;  // usual windows: <= 40 rows
-    const int wpr = ((x1 - xa) + 3) >> 2;      // dwords per window row (<= DW)
-    const int r0 = lane / DW, dwc = lane - r0 * DW;
-    if (r0 < RPI && dwc < wpr) {
-      const uint8_t *src = img + (long long)y0 * pitch + xa;  // wave-uniform base + 32-bit lane offsets
+  // fixed lane -> (row within a group, dword) mapping: the global offsets and the LDS indices are constants per lane.
+  // ALL loads of a tile are issued together (rows past the window are clamped, their data is dropped): a load -> wait
+  // -> write loop serialises one memory latency per RPI rows.
+  constexpr int DW = TP / 4, RPI = 64 / DW;  // dwords per tile row, rows per iteration
+  constexpr int NIT1 = (40 + RPI - 1) / RPI, NIT2 = (FAST_MAX_TILE + RPI - 1) / RPI - NIT1;  // usual windows: <= 40 rows
+  const int r0 = lane / DW, dwc = lane - r0 * DW;
+  struct Geo { int x0, y0, x1, y1, cw, ch, xa, ox, wpr; bool ok; };  // wave-uniform
+  auto geo = [&](int cell) {
+    Geo g;
+    const int ci = cell / Lv.nCols, cj = cell - ci * Lv.nCols;
+    g.x0 = BORDER + cj * Lv.wCell; g.y0 = BORDER + ci * Lv.hCell;
+    g.x1 = min(g.x0 + Lv.wCell + 6, maxBX); g.y1 = min(g.y0 + Lv.hCell + 6, maxBY);
+    g.cw = g.x1 - g.x0; g.ch = g.y1 - g.y0;
+    g.ok = !(g.y0 >= maxBY - 3 || g.x0 >= maxBX - 6) && g.cw >= 7 && g.ch >= 7;  // ORBextractor.cc:794,802
+    g.xa = aligned ? (g.x0 & ~3) : g.x0;
+    g.ox = g.x0 - g.xa;
+    g.wpr = ((g.x1 - g.xa) + 3) >> 2;  // dwords per window row (<= DW)
+    return g;
+  };
+  uint32_t v[NIT1];
+  auto issue = [&](const Geo &g) {  // the first NIT1 * RPI rows of the window -> registers
+    if (r0 < RPI && dwc < g.wpr) {
+      const uint8_t *src = img + (long long)g.y0 * pitch + g.xa;  // wave-uniform base + 32-bit lane offsets
       const uint32_t lo = (uint32_t)dwc * 4u;
-      uint32_t *dst = reinterpret_cast<uint32_t *>(&tile[dwc * 4]);
-      uint32_t v[NIT1 > NIT2 ? NIT1 : NIT2];
-#pragma unroll
-      for (int it = 0; it < NIT1; it++) {
-        if (K.dbg == 21 && (it & 1)) { v[it] = 0; continue; }  // experiment: half of the row requests (results are wrong)
-        v[it] = *reinterpret_cast<const uint32_t *>(src + ((uint32_t)__mul24(min(r0 + it * RPI, ch - 1), pitch) + lo));
-      }
 #pragma unroll
       for (int it = 0; it < NIT1; it++)
-        if (r0 + it * RPI < ch) dst[(r0 + it * RPI) * DW] = v[it];
-      if (ch > NIT1 * RPI) {  // tall cells of small levels
+        v[it] = *reinterpret_cast<const uint32_t *>(src + ((uint32_t)__mul24(min(r0 + it * RPI, g.ch - 1), pitch) + lo));
+    }
+  };
+  auto stage = [&](const Geo &g) {  // registers (+ the rows of a tall window) -> LDS tile, score tile cleared
+    if (aligned) {
+      if (r0 < RPI && dwc < g.wpr) {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&tile[dwc * 4]);
 #pragma unroll
-        for (int it = 0; it < NIT2; it++) v[it] = *reinterpret_cast<const uint32_t *>(src + ((uint32_t)__mul24(min(r0 + (NIT1 + it) * RPI, ch - 1), pitch) + lo));
+        for (int it = 0; it < NIT1; it++)
+          if (r0 + it * RPI < g.ch) dst[(r0 + it * RPI) * DW] = v[it];
+        if (g.ch > NIT1 * RPI) {  // tall cells of small levels
+          const uint8_t *src = img + (long long)g.y0 * pitch + g.xa;
+          const uint32_t lo = (uint32_t)dwc * 4u;
+          uint32_t w[NIT2];
 #pragma unroll
-        for (int it = 0; it < NIT2; it++)
-          if (r0 + (NIT1 + it) * RPI < ch) dst[(r0 + (NIT1 + it) * RPI) * DW] = v[it];
-      }
-    }
-  } else {
-    for (int i = lane; i < cw * ch; i += 64) {
-      const int yy = i / cw, xx = i - yy * cw;
-      tile[yy * tp + xx] = img[(long long)(y0 + yy) * pitch + x0 + xx];
-    }
-  }
-  FAST_TICK(0)  // address set-up + load issue
-  for (int i = lane; i < (tp * ch + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(sc)[i] = 0;
-  __syncthreads();
-  if (timed) { if (tile[lane] == 255 && sc[lane] == 7) cand[0] = 1; }  // forces the wait for the staged tile
-  FAST_TICK(1)  // wait for the tile
-  if (K.dbg == 1) { if (tile[lane] == 255 && sc[lane] == 7) cand[0] = 1; return; }
-  const int dwid = cw - 6, dhei = ch - 6, npix = dwid * dhei;
-  // ---- ONE sweep over the cell: compact every pixel that can be a corner (necessary compass test) into two lists
-  //      sharing one array: from the front the pixels that pass at iniThFAST, from the back those that only pass
-  //      at minThFAST (needed only when the cell has to be redone at the lower threshold)
-  int nlA = 0, nlB = 0;
-  const int cap = K.fastMaxPix;
-  // Lanes map to (row-pair, column): 32 columns x 2 row pairs per iteration for the usual <= 32 px wide cells, 64 x 1
-  // otherwise, so the LDS offset advances by a constant and no index division is needed.  A lane tests TWO vertically
-  // adjacent pixels at once in packed 16-bit arithmetic (v_pk_sub/min/max_i16).  The compass test for ANY threshold T
-  // is "strength > T" with strength = max(max over adjacent compass pairs of min(d_i, d_j), -(min over adjacent pairs
-  // of max(d_i, d_j))): two adjacent compass points brighter, or two darker, by more than T.
-  (void)npix;
-  typedef short s16x2 __attribute__((ext_vector_type(2)));
-  const int G = dwid <= 32 ? 32 : 64, ppi = dwid <= 32 ? 2 : 1;  // row pairs per iteration
-  const int sxx = lane & (G - 1), spr = dwid <= 32 ? (lane >> 5) : 0;
-  const bool colok = sxx < dwid;
-  const int tp3 = 3 * tp, sstep = 2 * ppi * tp;
-  int off = (3 + 2 * spr) * tp + ox + 3 + sxx;  // upper pixel of the lane's pair
-  for (int y = 0; y < dhei; y += 2 * ppi, off += sstep) {
-    const int r0 = y + 2 * spr;
-    int s0 = -1, s1 = -1;
-    if (colok && r0 < dhei) {
-      // rows r0 and r0+1 (the lower one may lie below the cell: its reads stay inside the LDS tile + score tile and the
-      // result is discarded)
-      const uint8_t *c = &tile[off];
-      const s16x2 v = {(short)c[0], (short)c[tp]};
-      const s16x2 n0 = {(short)c[tp3], (short)c[tp3 + tp]}, n8 = {(short)c[-tp3], (short)c[-tp3 + tp]};
-      const s16x2 n4 = {(short)c[3], (short)c[tp + 3]}, n12 = {(short)c[-3], (short)c[tp - 3]};
-      const s16x2 d0 = v - n0, d4 = v - n4, d8 = v - n8, d12 = v - n12;
-#define PMIN(a, b) __builtin_elementwise_min(a, b)
-#define PMAX(a, b) __builtin_elementwise_max(a, b)
-      const s16x2 hi = PMAX(PMAX(PMIN(d0, d4), PMIN(d4, d8)), PMAX(PMIN(d8, d12), PMIN(d12, d0)));
-      const s16x2 lo = PMIN(PMIN(PMAX(d0, d4), PMAX(d4, d8)), PMIN(PMAX(d8, d12), PMAX(d12, d0)));
-      const s16x2 zero = {0, 0};
-      const s16x2 st = PMAX(hi, zero - lo);
-#undef PMIN
-#undef PMAX
-      s0 = st.x;
-      s1 = (r0 + 1 < dhei) ? (int)st.y : -1;
-    }
+          for (int it = 0; it < NIT2; it++) w[it] = *reinterpret_cast<const uint32_t *>(src + ((uint32_t)__mul24(min(r0 + (NIT1 + it) * RPI, g.ch - 1), pitch) + lo));
 #pragma unroll
-    for (int h2 = 0; h2 < 2; h2++) {
-      const int strength = h2 == 0 ? s0 : s1;
-      const int offp = off + h2 * tp;
-      const bool c9i = strength > K.iniTh, c9 = strength > K.minTh;
-      // branch-free two-ended compaction: rank among the ini-threshold lanes (front) / among the others (back)
-      const unsigned long long mA = __ballot(c9i), mAB = __ballot(c9);
-      const int pA = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u));
-      const int pAB = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mAB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mAB, 0u));
-      const int idxA = nlA + pA, idxB = cap - 1 - nlB - (pAB - pA);
-      int idx;  // plain select on the ballot mask (the compiler turns the ternary into two divergent branches)
-      asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(idx) : "v"(idxB), "v"(idxA), "s"(mA));
-      if (c9) s_list[idx] = (unsigned short)offp;
-      const int cA = __popcll(mA);
-      nlA += cA;
-      nlB += __popcll(mAB) - cA;
-    }
-  }
-  __syncthreads();
-  FAST_TICK(2)  // sweep
-  if (K.dbg == 4) { if (nlA + nlB == 123456) cand[0] = 1; return; }
-  for (int pass = 0; pass < 2; pass++) {
-    const int T = pass == 0 ? K.iniTh : K.minTh;
-    // ---- scores, stored thresholded (below T = 0) so that the NMS compares raw bytes: pass 0 scores list A at
-    //      iniThFAST, pass 1 (cells without a corner at iniThFAST) scores A again and B at minThFAST
-    const int nl = pass == 0 ? nlA : nlA + nlB;  // pass 1 visits A then B
-    for (int i = lane; i < nl; i += 64) {
-      const int o = i < nlA ? s_list[i] : s_list[cap - nlB + (i - nlA)];
-      const int scv = fast_score16(&tile[o], tp);
-      sc[o] = (uint8_t)(scv >= T ? scv : 0);
-    }
-    __syncthreads();
-    if (pass == 0) { FAST_TICK(3) } else { FAST_TICK(6) }  // score
-    if (K.dbg == 2) { if (sc[lane] == 255) cand[0] = 1; return; }
-    // ---- 3x3 strict non-max suppression over the candidate list (only listed pixels can hold a score >= T);
-    //      neighbours below T were stored as 0, the rim holds 0
-    int total = 0;
-    for (int base = 0; base < nl; base += 64) {
-      const int i = base + lane;
-      bool keep = false;
-      uint32_t rec = 0;
-      if (i < nl) {
-        const int o = i < nlA ? s_list[i] : s_list[cap - nlB + (i - nlA)];
-        const uint8_t *q = &sc[o];
-        const int sv = q[0];
-        if (sv != 0) {
-          const int mx = max(max(max(max((int)q[-1], (int)q[1]), (int)q[-tp - 1]), max((int)q[-tp], (int)q[-tp + 1])),
-                             max(max((int)q[tp - 1], (int)q[tp]), (int)q[tp + 1]));
-          keep = sv > mx;
-          const int yy = o / tp, xx = o - yy * tp - ox;
-          rec = (uint32_t)(x0 + xx) | ((uint32_t)(y0 + yy) << 12) | ((uint32_t)sv << 24);
+          for (int it = 0; it < NIT2; it++)
+            if (r0 + (NIT1 + it) * RPI < g.ch) dst[(r0 + (NIT1 + it) * RPI) * DW] = w[it];
         }
       }
-      const unsigned long long m = __ballot(keep);
-      if (keep) s_out[total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = rec;
-      total += __popcll(m);
+    } else {
+      for (int i = lane; i < g.cw * g.ch; i += 64) {
+        const int yy = i / g.cw, xx = i - yy * g.cw;
+        tile[yy * tp + xx] = img[(long long)(g.y0 + yy) * pitch + g.x0 + xx];
+      }
     }
-    if (pass == 0) { FAST_TICK(4) } else { FAST_TICK(7) }  // NMS
-    if (K.dbg == 3) { if (total == 12345) cand[0] = 1; return; }
-    if (total == 0) continue;  // wave-uniform: retry with minThFAST
+    for (int i = lane; i < (tp * g.ch + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(sc)[i] = 0;
     __syncthreads();
-    // Every cell owns a fixed run of slotCap candidate slots and a count (pre-zeroed by the host); k_octree packs the
-    // runs of a level.  (One returning atomic per cell on a per-level counter was a third of a wave's life time: the
-    // ~900 cells of a level queue up on one address.)
-    uint32_t *out = cand + (long long)b * K.candStride + Lv.candBase + (long long)cell * Lv.slotCap;
-    for (int i = lane; i < total; i += 64) out[i] = s_out[i];
-    if (lane == 0) cellCount[(long long)b * K.totalCells + cellAll] = total;
-    if (pass == 0) { FAST_TICK(5) } else { FAST_TICK(8) }  // emission
-    break;
+  };
+  auto process = [&](const Geo &g, int cell) {
+    const int x0 = g.x0, y0 = g.y0, cw = g.cw, ch = g.ch, ox = g.ox;
+    if (K.dbg == 1) { if (tile[lane] == 255 && sc[lane] == 7) cand[0] = 1; return; }
+    const int dwid = cw - 6, dhei = ch - 6, npix = dwid * dhei;
+    // ---- ONE sweep over the cell: compact every pixel that can be a corner (necessary compass test) into two lists
+    //      sharing one array: from the front the pixels that pass at iniThFAST, from the back those that only pass
+    //      at minThFAST (needed only when the cell has to be redone at the lower threshold)
+    int nlA = 0, nlB = 0;
+    const int cap = K.fastMaxPix;
+    // Lanes map to (row-pair, column): 32 columns x 2 row pairs per iteration for the usual <= 32 px wide cells, 64 x 1
+    // otherwise, so the LDS offset advances by a constant and no index division is needed.  A lane tests TWO vertically
+    // adjacent pixels at once in packed 16-bit arithmetic (v_pk_sub/min/max_i16).  The compass test for ANY threshold T
+    // is "strength > T" with strength = max(max over adjacent compass pairs of min(d_i, d_j), -(min over adjacent pairs
+    // of max(d_i, d_j))): two adjacent compass points brighter, or two darker, by more than T.
+    (void)npix;
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const int G = dwid <= 32 ? 32 : 64, ppi = dwid <= 32 ? 2 : 1;  // row pairs per iteration
+    const int sxx = lane & (G - 1), spr = dwid <= 32 ? (lane >> 5) : 0;
+    const bool colok = sxx < dwid;
+    const int tp3 = 3 * tp, sstep = 2 * ppi * tp;
+    int off = (3 + 2 * spr) * tp + ox + 3 + sxx;  // upper pixel of the lane's pair
+    for (int y = 0; y < dhei; y += 2 * ppi, off += sstep) {
+      const int r0 = y + 2 * spr;
+      int s0 = -1, s1 = -1;
+      if (colok && r0 < dhei) {
+        // rows r0 and r0+1 (the lower one may lie below the cell: its reads stay inside the LDS tile + score tile and the
+        // result is discarded)
+        const uint8_t *c = &tile[off];
+        const s16x2 v = {(short)c[0], (short)c[tp]};
+        const s16x2 n0 = {(short)c[tp3], (short)c[tp3 + tp]}, n8 = {(short)c[-tp3], (short)c[-tp3 + tp]};
+        const s16x2 n4 = {(short)c[3], (short)c[tp + 3]}, n12 = {(short)c[-3], (short)c[tp - 3]};
+        const s16x2 d0 = v - n0, d4 = v - n4, d8 = v - n8, d12 = v - n12;
+  #define PMIN(a, b) __builtin_elementwise_min(a, b)
+  #define PMAX(a, b) __builtin_elementwise_max(a, b)
+        const s16x2 hi = PMAX(PMAX(PMIN(d0, d4), PMIN(d4, d8)), PMAX(PMIN(d8, d12), PMIN(d12, d0)));
+        const s16x2 lo = PMIN(PMIN(PMAX(d0, d4), PMAX(d4, d8)), PMIN(PMAX(d8, d12), PMAX(d12, d0)));
+        const s16x2 zero = {0, 0};
+        const s16x2 st = PMAX(hi, zero - lo);
+  #undef PMIN
+  #undef PMAX
+        s0 = st.x;
+        s1 = (r0 + 1 < dhei) ? (int)st.y : -1;
+      }
+  #pragma unroll
+      for (int h2 = 0; h2 < 2; h2++) {
+        const int strength = h2 == 0 ? s0 : s1;
+        const int offp = off + h2 * tp;
+        const bool c9i = strength > K.iniTh, c9 = strength > K.minTh;
+        // branch-free two-ended compaction: rank among the ini-threshold lanes (front) / among the others (back)
+        const unsigned long long mA = __ballot(c9i), mAB = __ballot(c9);
+        const int pA = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u));
+        const int pAB = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mAB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mAB, 0u));
+        const int idxA = nlA + pA, idxB = cap - 1 - nlB - (pAB - pA);
+        int idx;  // plain select on the ballot mask (the compiler turns the ternary into two divergent branches)
+        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(idx) : "v"(idxB), "v"(idxA), "s"(mA));
+        if (c9) s_list[idx] = (unsigned short)offp;
+        const int cA = __popcll(mA);
+        nlA += cA;
+        nlB += __popcll(mAB) - cA;
+      }
+    }
+    __syncthreads();
+    FAST_TICK(2)  // sweep
+      if (K.dbg == 4) { if (nlA + nlB == 123456) cand[0] = 1; return; }
+    for (int pass = 0; pass < 2; pass++) {
+      const int T = pass == 0 ? K.iniTh : K.minTh;
+      // ---- scores, stored thresholded (below T = 0) so that the NMS compares raw bytes: pass 0 scores list A at
+      //      iniThFAST, pass 1 (cells without a corner at iniThFAST) scores A again and B at minThFAST
+      const int nl = pass == 0 ? nlA : nlA + nlB;  // pass 1 visits A then B
+      for (int i = lane; i < nl; i += 64) {
+        const int o = i < nlA ? s_list[i] : s_list[cap - nlB + (i - nlA)];
+        const int scv = fast_score16(&tile[o], tp);
+        sc[o] = (uint8_t)(scv >= T ? scv : 0);
+      }
+      __syncthreads();
+      if (pass == 0) { FAST_TICK(3) } else { FAST_TICK(6) }  // score
+      if (K.dbg == 2) { if (sc[lane] == 255) cand[0] = 1; return; }
+      // ---- 3x3 strict non-max suppression over the candidate list (only listed pixels can hold a score >= T);
+      //      neighbours below T were stored as 0, the rim holds 0
+      int total = 0;
+      for (int base = 0; base < nl; base += 64) {
+        const int i = base + lane;
+        bool keep = false;
+        uint32_t rec = 0;
+        if (i < nl) {
+          const int o = i < nlA ? s_list[i] : s_list[cap - nlB + (i - nlA)];
+          const uint8_t *q = &sc[o];
+          const int sv = q[0];
+          if (sv != 0) {
+            const int mx = max(max(max(max((int)q[-1], (int)q[1]), (int)q[-tp - 1]), max((int)q[-tp], (int)q[-tp + 1])),
+                               max(max((int)q[tp - 1], (int)q[tp]), (int)q[tp + 1]));
+            keep = sv > mx;
+            const int yy = o / tp, xx = o - yy * tp - ox;
+            rec = (uint32_t)(x0 + xx) | ((uint32_t)(y0 + yy) << 12) | ((uint32_t)sv << 24);
+          }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) s_out[total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = rec;
+        total += __popcll(m);
+      }
+      if (pass == 0) { FAST_TICK(4) } else { FAST_TICK(7) }  // NMS
+      if (K.dbg == 3) { if (total == 12345) cand[0] = 1; return; }
+      if (total == 0) continue;  // wave-uniform: retry with minThFAST
+      __syncthreads();
+      // Every cell owns a fixed run of slotCap candidate slots and a count (pre-zeroed by the host); k_octree packs the
+      // runs of a level.  (One returning atomic per cell on a per-level counter was a third of a wave's life time: the
+      // ~900 cells of a level queue up on one address.)
+      uint32_t *out = cand + (long long)b * K.candStride + Lv.candBase + (long long)cell * Lv.slotCap;
+      for (int i = lane; i < total; i += 64) out[i] = s_out[i];
+      if (lane == 0) cellCount[(long long)b * K.totalCells + Lv.cellBase + cell] = total;
+      if (pass == 0) { FAST_TICK(5) } else { FAST_TICK(8) }  // emission
+      break;
+    }
+  };
+  Geo g = geo(cFirst);
+  if (timed) { if (g.cw + g.ch + g.x0 + g.y0 == 123456789) cand[0] = 1; }  // forces the kernel-argument loads to have landed
+  FAST_TICK(9)  // group decode (scalar loads of the level tables)
+  if (g.ok && aligned) issue(g);
+  for (int cell = cFirst; cell < cEnd; cell++) {
+    const bool haveNext = cell + 1 < cEnd;
+    const Geo gn = geo(haveNext ? cell + 1 : cell);
+    if (g.ok) {
+      stage(g);
+      if (timed) { if (tile[lane] == 255 && sc[lane] == 7) cand[0] = 1; }  // forces the wait for the staged tile
+      FAST_TICK(0)  // wait for the tile + LDS writes
+      if (haveNext && gn.ok && aligned) issue(gn);  // in flight while this cell is processed
+      FAST_TICK(1)  // prefetch issue
+      process(g, cell);
+      __syncthreads();  // the next tile overwrites the survivors / lists
+    } else if (haveNext && gn.ok && aligned) {
+      issue(gn);
+    }
+    g = gn;
   }
-  if (timed && lane == 0) {
+  if (TIMED && timed && lane == 0) {
 #pragma unroll
     for (int i = 0; i < 10; i++) atomicAdd(&K.timers[i], t_acc[i]);
     atomicAdd(&K.timers[10], t_mark - t_start);
@@ -1224,6 +1254,14 @@ int prepare(fb_orb *o, int w, int h, int batch) {
     pw = L.w; ph = L.h;
   }
   K.totalCells = cells;
+  {
+    int gsum = 0;
+    for (int l = 0; l <= FB_MAX_LEVELS; l++) {
+      K.grpBase[l] = gsum;
+      if (l < p.nlevels) gsum += (K.L[l].nCols * K.L[l].nRows + FAST_CPW - 1) / FAST_CPW;
+    }
+    K.totalGroups = gsum;
+  }
   for (int l = 0; l <= FB_MAX_LEVELS; l++) K.cellBase[l] = l < p.nlevels ? K.L[l].cellBase : cells;
   K.dbg = getenv("FB_FAST_DBG") ? atoi(getenv("FB_FAST_DBG")) : 0;
   {
@@ -1359,14 +1397,16 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
   }
   if (K.totalCells > 0) {
     fb::ProfScope prof_(fb::P_FAST, s);
-    const dim3 grdF((K.totalCells + 7) / 8 * 8, batch);
+    const dim3 grdF((K.totalGroups + 7) / 8 * 8, batch);
     const size_t ldsF = (size_t)2 * K.fastTileBytes + 2 * K.fastMaxPix;
+#define FAST_LAUNCH(TP_) { if (K.dbg == 20) k_fast<TP_, true><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cellCand.as<uint32_t>(), o->cellCount.as<int>()); \
+                          else k_fast<TP_, false><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cellCand.as<uint32_t>(), o->cellCount.as<int>()); }
     if (K.fastTP == 44)
-      k_fast<44><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cellCand.as<uint32_t>(), o->cellCount.as<int>());
+      FAST_LAUNCH(44)
     else if (K.fastTP == 56)
-      k_fast<56><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cellCand.as<uint32_t>(), o->cellCount.as<int>());
+      FAST_LAUNCH(56)
     else
-      k_fast<FAST_MAX_TILE><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cellCand.as<uint32_t>(), o->cellCount.as<int>());
+      FAST_LAUNCH(FAST_MAX_TILE)
   }
   {
     fb::ProfScope prof_(fb::P_BLUR, s);
