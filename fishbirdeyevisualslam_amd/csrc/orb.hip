@@ -176,10 +176,13 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t *__restrict__
     sh8[k] = (uint32_t)(o & 3);
     wgt[k] = (uint32_t)(a0 & 0xffff) | ((uint32_t)a1 << 16);
   }
-  auto hpass = [&](int sy, int h[4]) {
+  auto loadWin = [&](int sy, uint32_t (&wv)[3]) {
     sy = sy >= 0 ? (sy < sh ? sy : sh - 1) : 0;
-    const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (long long)sy * spitch + aw);
-    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(src + ((uint32_t)__mul24(sy, spitch) + (uint32_t)aw));
+    wv[0] = p[0]; wv[1] = p[1]; wv[2] = p[2];
+  };
+  auto hpass = [&](const uint32_t (&wv)[3], int h[4]) {
+    const uint32_t w0 = wv[0], w1 = wv[1], w2 = wv[2];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const uint32_t lo = sel[k] == 0 ? w0 : (sel[k] == 1 ? w1 : w2);
@@ -196,16 +199,32 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t *__restrict__
   int h0[4], h1[4];
   int prevS1 = -0x40000000;
   const int dyEnd = min(dyBase + RESIZE_ROWS, dh);
-  for (int dy = dyBase; dy < dyEnd; dy++) {
-    const int sy0 = tb.yofs[dy];
-    const int b0 = tb.ibeta[dy * 2], b1 = tb.ibeta[dy * 2 + 1];
+  // every source window of the RESIZE_ROWS destination rows is requested before the first one is used (a row that two
+  // destination rows share is simply requested twice): load -> wait -> use per row serialises the memory latency
+  int sy0s[RESIZE_ROWS], b0s[RESIZE_ROWS], b1s[RESIZE_ROWS];
+  uint32_t wa[RESIZE_ROWS][3], wb[RESIZE_ROWS][3];
+#pragma unroll
+  for (int j = 0; j < RESIZE_ROWS; j++) {
+    const int dyc = min(dyBase + j, dh - 1);
+    sy0s[j] = tb.yofs[dyc];
+    b0s[j] = tb.ibeta[dyc * 2];
+    b1s[j] = tb.ibeta[dyc * 2 + 1];
+    loadWin(sy0s[j], wa[j]);
+    loadWin(sy0s[j] + 1, wb[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < RESIZE_ROWS; j++) {
+    const int dy = dyBase + j;
+    if (dy >= dyEnd) break;
+    const int sy0 = sy0s[j];
+    const int b0 = b0s[j], b1 = b1s[j];
     if (sy0 == prevS1) {
 #pragma unroll
       for (int k = 0; k < 4; k++) h0[k] = h1[k];
     } else {
-      hpass(sy0, h0);
+      hpass(wa[j], h0);
     }
-    hpass(sy0 + 1, h1);
+    hpass(wb[j], h1);
     prevS1 = sy0 + 1;
     uint32_t packed = 0;
 #pragma unroll
@@ -858,14 +877,24 @@ __global__ __launch_bounds__(256) void k_blur(OrbK K, const uint8_t *__restrict_
   const bool anyEdge = __ballot(edge) != 0ull;
   const uint32_t WA = 18u | (34u << 8) | (49u << 16) | (55u << 24), WB = 49u | (34u << 8) | (18u << 16);
   int ring[7][4];
+  // The source rows run BLUR_PF rows ahead of the arithmetic: a load -> wait -> use per row would serialise one memory
+  // latency per row (22 per wave).  Row indices past the image are reflected, so every prefetch address is valid.
+  constexpr int BLUR_PF = 4;
+  uint32_t q[BLUR_PF][3];
+  auto loadRow = [&](int r, uint32_t (&dst)[3]) {
+    const int ys = reflect101(min(y0 + r - 3, h + 2), h);
+    const uint8_t *row = img + (uint32_t)__mul24(ys, pitch);  // 32-bit offset: 64-bit multiplies are quarter rate
+    const uint32_t *pw = reinterpret_cast<const uint32_t *>(row + base);
+    dst[0] = pw[0]; dst[1] = pw[1]; dst[2] = pw[2];
+  };
+#pragma unroll
+  for (int r = 0; r < BLUR_PF; r++) loadRow(r, q[r]);
 #pragma unroll
   for (int r = 0; r < BLUR_ROWS + 6; r++) {
     const int yo = y0 + r - 6;  // destination row completed by this source row
     if (r >= 6 && yo >= h) break;
-    const int ys = reflect101(min(y0 + r - 3, h + 2), h);
-    const uint8_t *row = img + (uint32_t)__mul24(ys, pitch);  // 32-bit offset: 64-bit multiplies are quarter rate
-    const uint32_t *pw = reinterpret_cast<const uint32_t *>(row + base);
-    uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+    uint32_t w0 = q[r % BLUR_PF][0], w1 = q[r % BLUR_PF][1], w2 = q[r % BLUR_PF][2];
+    if (r + BLUR_PF < BLUR_ROWS + 6) loadRow(r + BLUR_PF, q[r % BLUR_PF]);
     if (anyEdge) {
       const uint32_t e0 = __builtin_amdgcn_perm(w1, w0, m1[0]) | __builtin_amdgcn_perm(w2, w2, m2[0]);
       const uint32_t e1 = __builtin_amdgcn_perm(w1, w0, m1[1]) | __builtin_amdgcn_perm(w2, w2, m2[1]);
