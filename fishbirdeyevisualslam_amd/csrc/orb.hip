@@ -674,12 +674,21 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
     // ---- count children of every expandable node
     for (int i = tid; i < 4 * S; i += 256) ccnt[i] = 0;
     __syncthreads();
-    for (int k = tid; k < n; k += 256) {
-      const int p = nof[k];
-      const ONode nd = cur[p];
-      if (nd.cnt > 1) {
-        const uint32_t c = cd[k];
-        atomicAdd(&ccnt[4 * p + quadrant(nd, (int)(c & 0xFFF) - BORDER, (int)((c >> 12) & 0xFFF) - BORDER)], 1);
+    // candidate passes: 4 candidates per thread and step, all their global loads requested before the first use
+    for (int k0 = tid; k0 < n; k0 += 256 * 4) {
+      int pk[4];
+      uint32_t ck[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int kk = min(k0 + u * 256, n - 1); pk[u] = nof[kk]; ck[u] = cd[kk]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (k0 + u * 256 >= n) break;
+        const int p = pk[u];
+        const ONode nd = cur[p];
+        if (nd.cnt > 1) {
+          const uint32_t c = ck[u];
+          atomicAdd(&ccnt[4 * p + quadrant(nd, (int)(c & 0xFFF) - BORDER, (int)((c >> 12) & 0xFFF) - BORDER)], 1);
+        }
       }
     }
     __syncthreads();
@@ -778,12 +787,21 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
     const int Snew = totalKids + totalKeep;
     __syncthreads();
     // ---- remap keypoints
-    for (int k = tid; k < n; k += 256) {
-      const int p = nof[k];
-      if (split[p]) {
-        const uint32_t c = cd[k];
-        nof[k] = cpos[4 * p + quadrant(cur[p], (int)(c & 0xFFF) - BORDER, (int)((c >> 12) & 0xFFF) - BORDER)];
-      } else nof[k] = npos[p];
+    for (int k0 = tid; k0 < n; k0 += 256 * 4) {
+      int pk[4];
+      uint32_t ck[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int kk = min(k0 + u * 256, n - 1); pk[u] = nof[kk]; ck[u] = cd[kk]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = k0 + u * 256;
+        if (k >= n) break;
+        const int p = pk[u];
+        if (split[p]) {
+          const uint32_t c = ck[u];
+          nof[k] = cpos[4 * p + quadrant(cur[p], (int)(c & 0xFFF) - BORDER, (int)((c >> 12) & 0xFFF) - BORDER)];
+        } else nof[k] = npos[p];
+      }
     }
     // nToExpand of the new list = children with more than one keypoint
     int myExp = 0;
@@ -807,8 +825,16 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
   // ---- best keypoint per node: max response, first in vToDistributeKeys order on ties
   for (int p = tid; p < S; p += 256) best[p] = 0ull;
   __syncthreads();
-  for (int k = tid; k < n; k += 256) {
-    const uint32_t c = cd[k];
+  for (int k0 = tid; k0 < n; k0 += 256 * 4) {
+    int pk[4];
+    uint32_t ck[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int kk = min(k0 + u * 256, n - 1); pk[u] = nof[kk]; ck[u] = cd[kk]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+    const int k = k0 + u * 256;
+    if (k >= n) break;
+    const uint32_t c = ck[u];
     const int x = c & 0xFFF, y = (c >> 12) & 0xFFF, r = c >> 24;
     const int cellI = (y - EDGE_THRESHOLD) / Lv.hCell, cellJ = (x - EDGE_THRESHOLD) / Lv.wCell;
     const int dwid = min(Lv.wCell, Lv.w - 2 * EDGE_THRESHOLD - cellJ * Lv.wCell);
@@ -816,7 +842,8 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
     const unsigned orderKey = (unsigned)(cellI * Lv.nCols + cellJ) * 4096u + (unsigned)inCell;  // < 2^32 (cells < 2^20)
     // response (8 bits) | inverted order key (32 bits) | candidate index (24 bits)
     const unsigned long long key = ((unsigned long long)r << 56) | ((unsigned long long)(0xFFFFFFFFu - orderKey) << 24) | (unsigned)k;
-    atomicMax(&best[nof[k]], key);
+    atomicMax(&best[pk[u]], key);
+    }
   }
   __syncthreads();
   for (int p = tid; p < S; p += 256) out[p] = cd[(unsigned)(best[p] & 0xFFFFFFull)];
