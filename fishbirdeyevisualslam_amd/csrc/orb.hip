@@ -961,15 +961,16 @@ constexpr int DP_RAW_DW = 9, DP_RAW_ROWS = 31;    // 31 rows x 36 B  (x-15 .. x+
 constexpr int DP_BL_DW = 10, DP_BL_ROWS = 37;     // 37 rows x 40 B  (x-18 .. x+18 after dword alignment)
 
 constexpr int DESC_WPB = 4;  // waves per workgroup (they never talk to each other)
-constexpr int DESC_KPW = 1;  // consecutive key points per wave (measured: 8 with prefetch of the next patch is SLOWER, see below)
+constexpr int DESC_KPW = 2;  // consecutive key points per wave, all their patch loads in flight together
 
 // A wave owns DESC_KPW consecutive key points.  What does not depend on the key point (level counts, sampling
-// pattern, orientation tables) is fetched once per wave, the DESC_KPW records with one load, and with DESC_KPW > 1 the
-// patch loads of key point j+1 are in flight while key point j is processed out of LDS.  The kernel is bound by the
-// latency of its ~70 cache lines per key point (ablation: 37 % record + table fetch, 53 % patch staging + moments,
-// 10 % the 256 tests), i.e. by the number of loads in flight per SIMD = waves x 12.  Measured at B=256: DESC_KPW = 8
-// with prefetch needs 115 VGPRs (4 waves) and is 1.5x SLOWER than DESC_KPW = 1 at 8 waves, which is what ships.
-__global__ __launch_bounds__(64 * DESC_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_describe(OrbK K, const uint8_t *__restrict__ img0, long long imgStride,
+// pattern, orientation tables) is fetched once per wave, the DESC_KPW records with one load, and the patch loads of ALL
+// of the wave's key points are requested before the first patch is used.  The kernel is bound by the latency of its
+// ~70 scattered cache lines per key point (ablation: 37 % record + table fetch, 53 % patch staging + moments, 10 % the
+// 256 tests), not by arithmetic.  Measured at B=256 (per step, both images): one key point per wave 0.97 ms; 8 per wave
+// with the NEXT patch prefetched during the tests 1.47 ms (the tests are far too short to cover a patch); 2 per wave
+// with both patches requested together 0.93 ms and the best overlap with the other streams; 4 per wave the same.
+__global__ __launch_bounds__(64 * DESC_WPB) void k_describe(OrbK K, const uint8_t *__restrict__ img0, long long imgStride,
                                                  int pitch0, const uint8_t *__restrict__ pyr,
                                                  const uint8_t *__restrict__ blur, const uint4 *__restrict__ angTab,
                                                  const uint32_t *__restrict__ lvlOut, const int *__restrict__ lvlCount,
@@ -1036,10 +1037,10 @@ __global__ __launch_bounds__(64 * DESC_WPB) __attribute__((amdgpu_waves_per_eu(8
     k.rox = k.rawAligned ? (k.cx - 15) - k.rxa : 0;
     return k;
   };
-  uint32_t vb[NB_IT], vr[NR_IT];
+  uint32_t vb[DESC_KPW][NB_IT], vr[DESC_KPW][NR_IT];
   // All global loads of both patches are issued together (rows past a patch are clamped and their data dropped; key
   // points sit >= 19 px inside the level, so neither patch leaves the image)
-  auto issue = [&](const KP &k) {
+  auto issue = [&](const KP &k, uint32_t (&vb)[NB_IT], uint32_t (&vr)[NR_IT]) {
 #pragma unroll
     for (int it = 0; it < NB_IT; it++)
       vb[it] = *reinterpret_cast<const uint32_t *>(k.bbase + (uint32_t)(__mul24(k.cy - 18 + min(it * 6 + rb0, DP_BL_ROWS - 1), k.bpitch) + k.bxa + min(dwb, DP_BL_DW - 1) * 4));
@@ -1049,7 +1050,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) __attribute__((amdgpu_waves_per_eu(8
         vr[it] = *reinterpret_cast<const uint32_t *>(k.img + (uint32_t)(__mul24(k.cy - 15 + min(it * 7 + rr0, DP_RAW_ROWS - 1), k.pitch) + k.rxa + min(dwr, DP_RAW_DW - 1) * 4));
     }
   };
-  auto stage = [&](const KP &k) {
+  auto stage = [&](const KP &k, const uint32_t (&vb)[NB_IT], const uint32_t (&vr)[NR_IT]) {
     if (lane < 6 * DP_BL_DW) {
 #pragma unroll
       for (int it = 0; it < NB_IT; it++)
@@ -1074,12 +1075,18 @@ __global__ __launch_bounds__(64 * DESC_WPB) __attribute__((amdgpu_waves_per_eu(8
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  KP cur = decode(0);
-  issue(cur);
-  for (int j = 0; j < nmine; j++) {
-    stage(cur);
-    KP nxt = cur;
-    if (j + 1 < nmine) { nxt = decode(j + 1); issue(nxt); }
+  // the patch loads of ALL of the wave's key points are requested before the first patch is used
+  KP kpv[DESC_KPW];
+#pragma unroll
+  for (int j = 0; j < DESC_KPW; j++) {
+    kpv[j] = decode(min(j, nmine - 1));
+    if (j < nmine) issue(kpv[j], vb[j], vr[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < DESC_KPW; j++) {
+    if (j >= nmine) break;
+    const KP &cur = kpv[j];
+    stage(cur, vb[j], vr[j]);
     // IC_Angle (ORBextractor.cc:77-104): lanes 2*(v+15) and 2*(v+15)+1 sum the left (u < 0) and right (u >= 0) part
     // of row v of the circular patch.  Each half row is 16 bytes read as dwords; |u| weights and the circular mask
     // (|u| <= umax[|v|]) come from a per-lane table (angTab[lane] = 4 weight dwords + 4 mask dwords) and the sums
@@ -1101,7 +1108,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) __attribute__((amdgpu_waves_per_eu(8
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
-    if (K.dbg == 12) { if (m10 + m01 == 12345678 && pp[0].x + pp[1].y + pp[2].z + pp[3].w == 77777) nOut[0] = 1; cur = nxt; continue; }
+    if (K.dbg == 12) { if (m10 + m01 == 12345678 && pp[0].x + pp[1].y + pp[2].z + pp[3].w == 77777) nOut[0] = 1; continue; }
     const float angle = fb_fast_atan2((float)m01, (float)m10);
     // computeOrbDescriptor (ORBextractor.cc:107-147): lane computes tests 4*lane .. 4*lane+3
     const float factorPI = 0x1.1df46ap-6f;
@@ -1138,7 +1145,6 @@ __global__ __launch_bounds__(64 * DESC_WPB) __attribute__((amdgpu_waves_per_eu(8
     // the LDS reads of this key point are ordered before the writes of the next one (same wave, in-order LDS)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    cur = nxt;
   }
 }
 
