@@ -1510,7 +1510,17 @@ int fb_orb_extract(fb_orb *o, const uint8_t *image, int width, int height, int s
                                   dk.as<fb_keypoint>(), dd.as<uint8_t>(), dn.as<int32_t>(), nullptr));
   FB_HIP(hipDeviceSynchronize());
   FB_TRY(dn.download(n_out, 4));
-  if (*n_out > cap) { fb::set_error("keypoint capacity exceeded"); return FB_ERR_CAPACITY; }
+  {  // n_out is clamped to the capacity on the device; the per-level counts tell whether anything was cut off (the
+     // quadtree can end a level with up to 4 x its number of root nodes: very wide strips with a tiny feature budget)
+    int lc[FB_MAX_LEVELS] = {0};
+    FB_HIP(hipMemcpy(lc, o->counts.as<int>() + (size_t)o->batchCap * o->p.nlevels, (size_t)o->p.nlevels * 4, hipMemcpyDeviceToHost));
+    int total = 0;
+    for (int l = 0; l < o->p.nlevels; l++) total += lc[l];
+    if (total > cap) {
+      fb::set_error("keypoint capacity exceeded: the quadtree kept %d key points, fb_orb_capacity() is %d", total, cap);
+      return FB_ERR_CAPACITY;
+    }
+  }
   FB_TRY(dk.download(keypoints, (size_t)*n_out * sizeof(fb_keypoint)));
   return dd.download(descriptors, (size_t)*n_out * 32);
 }

@@ -99,13 +99,17 @@ int fb_orb_capacity(const fb_orb_params *params);
 
 /* replaces ORBextractor::operator() (ORBextractor.cc:1043-1105), host buffers.
  * image: u8, row-major, `stride` bytes per row.  keypoints/descriptors must hold
- * cap = fb_orb_capacity() entries (desc: cap*32 bytes).  *n_out <= cap.        */
+ * cap = fb_orb_capacity() entries (desc: cap*32 bytes).  *n_out <= cap.
+ * cap = nfeatures + 8*nlevels covers the quadtree's overshoot of at most 3 per level; a level can also end with up
+ * to 4x its number of root nodes (a strip many times wider than high with a tiny feature budget): if that exceeds cap,
+ * FB_ERR_CAPACITY is returned.                                                  */
 int fb_orb_extract(fb_orb *h, const uint8_t *image, int width, int height, int stride,
                    fb_keypoint *keypoints, uint8_t *descriptors, int32_t *n_out);
 
 /* same, `batch` equally sized images resident in HBM; image b starts at
  * d_images + b*image_stride.  Outputs: d_keypoints[batch][cap],
- * d_descriptors[batch][cap][32], d_n[batch], cap = fb_orb_capacity().          */
+ * d_descriptors[batch][cap][32], d_n[batch], cap = fb_orb_capacity(); d_n[b] is
+ * clamped to cap (asynchronous call: no error channel for the overflow above).  */
 int fb_orb_extract_batch_dev(fb_orb *h, const uint8_t *d_images, int batch, int width, int height,
                              int stride, size_t image_stride, fb_keypoint *d_keypoints,
                              uint8_t *d_descriptors, int32_t *d_n, void *stream);

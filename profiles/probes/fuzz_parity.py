@@ -74,6 +74,8 @@ while time.time() < t_end:
                 desc = "fuse sim3=%s nkf=%d nmp=%d B=%d" % (sim3, ncur, nq, B)
     except Exception as e:  # capacity errors are fine, anything else is reported
         msg = str(e)
+        if isinstance(e, AssertionError) and msg == "-3":  # the oracle's own capacity error (orc_orb_extract)
+            msg = "oracle capacity (-3)"
         ok = any(t in msg.lower() for t in ("capacity", "too large", "exceed", "bad argument", "is empty"))
         desc = "EXC kind=%d %s" % (kind, msg[:160])
         if kind == 0:
