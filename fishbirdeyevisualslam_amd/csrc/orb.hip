@@ -3,18 +3,18 @@
 // Replaces (reference file:line):
 //   ORBextractor::ORBextractor        src/ORBextractor.cc:410-470   (host tables)
 //   ORBextractor::ComputePyramid      :1107-1132   -> k_resize (one launch per level >= 1)
-//   ComputeKeyPointsOctTree cell loop :765-832     -> k_fast   (one workgroup per 30-px cell,
+//   ComputeKeyPointsOctTree cell loop :765-832     -> k_fast   (one wave per run of 30-px cells,
 //        cv::FAST 9-16 score + 3x3 NMS + ini/min threshold fallback on an LDS tile)
 //   DistributeOctTree / DivideNode    :481-763     -> k_octree (one workgroup per image level)
-//   IC_Angle / computeOrbDescriptor   :77-147, GaussianBlur :1086 -> k_describe (one wave per
-//        keypoint: 43x43 raw patch in LDS -> moments, separable 7x7 blur, 256 rBRIEF tests)
+//   GaussianBlur :1086                              -> k_blur   (whole level, separable 7x7, dot4)
+//   IC_Angle / computeOrbDescriptor   :77-147      -> k_describe (one wave per two key points: raw and
+//        blurred patches staged in LDS -> moments, 256 rBRIEF tests)
 //   ORBextractor::operator()          :1043-1105   -> fb_orb_extract*
 //
 // HBM layout per image: level 0 is the caller's image (never copied); levels 1..n-1 live in
-// one pitched buffer (pitch % 64 == 0).  The blurred image is never materialised: each
-// keypoint's wave blurs its own 37x37 footprint out of LDS.  FAST candidates are packed
-// x | y<<12 | score<<24 into a per-level array sized for the NMS worst case, so no kernel
-// can overflow a buffer.
+// one pitched buffer (pitch % 64 == 0), the blurred levels in a second one of the same geometry.
+// FAST candidates are packed x | y<<12 | score<<24 into per-cell runs of a per-level array sized
+// for the NMS worst case, so no kernel can overflow a buffer.
 //
 // OpenCV semantics (not vendored in the reference -> "parity unpinned") are
 // those of oracle/orb_oracle.cpp; this file must agree with it bit for bit.
@@ -293,14 +293,17 @@ __device__ __forceinline__ int block_excl_scan256(int v, int *s_w /*[4]*/, int *
 
 constexpr int FAST_MAX_TILE = 72;  // cell window <= wCell+6 <= 65 px, +3 alignment slack
 
-// One WAVE per cell (64-thread workgroups): no cross-wave barriers, ~11 cells resident per CU.
-//  1. the cell window is staged in LDS with 4-byte loads;
-//  2. per 64 pixels: a necessary corner test on the 4 compass pixels (any 9-arc holds two consecutive compass
-//     points), ballot-compaction of the survivors, full score only for those;
-//  3. 3x3 strict NMS over the score tile, survivors staged in LDS;
+// One WAVE per run of FAST_CPW consecutive cells (64-thread workgroups, no cross-wave barriers, up to 31 waves per CU).
+// Per cell:
+//  1. the cell window is staged in LDS with 4-byte loads, all issued before the first LDS write; the window of the
+//     NEXT cell is requested before this one is processed;
+//  2. per 128 pixels: a necessary corner test on the 4 compass pixels (any 9-arc holds two consecutive compass
+//     points), two pixels per lane in packed 16-bit arithmetic, ballot-compaction of the survivors into an
+//     iniThFAST list and a minThFAST list; full score only for listed pixels;
+//  3. 3x3 strict NMS over the thresholded score tile, survivors staged in LDS (over the image tile);
 //  4. if none survived at iniThFAST the cell is redone at minThFAST (ORBextractor.cc:809-816);
-//  5. ONE global atomic per cell reserves the output slots; candidate order is irrelevant downstream
-//     (the quadtree breaks response ties with an order key derived from x,y).
+//  5. the survivors go to the cell's own run of output slots + a per-cell count (no atomics; k_octree packs the runs).
+//     Candidate order is irrelevant downstream (the quadtree breaks response ties with an order key derived from x,y).
 // TP = tile pitch in bytes, a compile-time constant so that every LDS access of the sweep / score / NMS is
 // base + immediate offset (44 covers cells up to 35 px wide, i.e. every level of the usual image sizes).
 constexpr int FAST_CPW = 4;  // consecutive cells per wave; the tile of cell i+1 is in flight while cell i is processed
