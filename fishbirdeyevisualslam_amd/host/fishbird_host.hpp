@@ -54,7 +54,8 @@ struct Frame {
   // front
   std::vector<fb_keypoint> mvKeysUn;
   std::vector<uint8_t> mDescriptors;          // N x 32
-  FeatureVector mFeatVec;                     // Frame::ComputeBoW (fb_bow_transform)
+  BowVector mBowVec;                          // Frame::ComputeBoW (ORBVocabulary::ComputeBoW below)
+  FeatureVector mFeatVec;
   std::vector<int32_t> mvpMapPoints;          // index into the caller's map-point table, -1 = NULL
   std::vector<uint8_t> mvpMapPointHasObs;     // Observations()>0 of the point currently in slot i
   std::vector<uint8_t> mvbOutlier;
@@ -91,6 +92,22 @@ struct Frame {
   void AssignFeaturesToGrid() {
     assignToGrid(mvKeysUn, frontGrid(), gridStart, gridItems);
     if (birdviewCols > 0) assignToGrid(mvKeysBird, birdGrid(), gridBirdStart, gridBirdItems);
+  }
+
+  // Frame::UndistortKeyPoints (Frame.cc:636-669): mvKeys -> mvKeysUn through cv::fisheye::undistortPoints(K, D, R=I, P=K);
+  // DistCoef[0] == 0 copies.  K4 = fx, fy, cx, cy; D4 = k1..k4.
+  void UndistortKeyPoints(const std::vector<fb_keypoint> &mvKeys, const float D4[4]) {
+    mvKeysUn.resize(mvKeys.size());
+    if (mvKeys.empty()) return;
+    const float K4[4] = {fx, fy, cx, cy};
+    check(fb_undistort_keypoints(mvKeys.data(), (int)mvKeys.size(), K4, D4, mvKeysUn.data()));
+  }
+  // Frame::ComputeImageBounds (Frame.cc:741-795), including its numeric_limits<float>::min() quirk: sets mnMinX..mnMaxY
+  void ComputeImageBounds(int cols, int rows, const float D4[4]) {
+    const float K4[4] = {fx, fy, cx, cy};
+    float bnd[4];
+    check(fb_image_bounds(cols, rows, K4, D4, bnd));
+    mnMinX = bnd[0]; mnMaxX = bnd[1]; mnMinY = bnd[2]; mnMaxY = bnd[3];
   }
 
   // Frame::isInFrustum(pMP, viewingCosLimit) (Frame.cc:435-491) over the whole local map in one call, the loop of
@@ -177,7 +194,6 @@ class ORBextractor {
 // ---- ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>, TemplatedVocabulary.h) ------------------
 // The tree as flat arrays (fb_vocabulary).  transform() is Frame::ComputeBoW / KeyFrame::ComputeBoW (Frame.cc:628-635):
 // mBowVec as word id -> value, mFeatVec as NodeId -> feature indices.
-typedef std::map<uint32_t, double> BowVector;
 class ORBVocabulary {
  public:
   int L = 0;
@@ -208,6 +224,9 @@ class ORBVocabulary {
       for (int j = nstart[k]; j < nstart[k + 1]; j++) dst.push_back((unsigned)items[j]);
     }
   }
+  // Frame::ComputeBoW / KeyFrame::ComputeBoW (Frame.cc:628-635, KeyFrame.cc:76-86): only when mBowVec is still empty
+  void ComputeBoW(Frame &F) const { if (F.mBowVec.empty()) transform(F.mDescriptors, F.mBowVec, F.mFeatVec, 4); }
+  void ComputeBoW(KeyFrame &K) const { if (K.mBowVec.empty()) transform(K.mDescriptors, K.mBowVec, K.mFeatVec, 4); }
 };
 
 // ---- ORBmatcher --------------------------------------------------------------------------------------------------

@@ -33,6 +33,8 @@ struct KFIdLess {
 typedef std::map<KeyFrame *, size_t, KFIdLess> ObservationMap;
 // DBoW2::FeatureVector (Thirdparty/DBoW2/DBoW2/FeatureVector.h:23): NodeId -> feature indices in addFeature order
 typedef std::map<uint32_t, std::vector<unsigned>> FeatureVector;
+// DBoW2::BowVector (BowVector.h): WordId -> value
+typedef std::map<uint32_t, double> BowVector;
 
 // Frame::bHaveBird / bTightCouple / bTightCouple2 (static switches read by the optimiser, Optimizer.cc:2190,2417,2452)
 struct OptimizerSwitches {
@@ -180,6 +182,7 @@ struct KeyFrame {
   float mTcwGBA[12] = {0};
   // matcher side (KeyFrame.h:170-213): descriptors, BoW feature vector, the feature grid copied from the Frame
   std::vector<uint8_t> mDescriptors;  // N x 32
+  BowVector mBowVec;
   FeatureVector mFeatVec;
   std::vector<float> mvLevelSigma2;
   float mfLogScaleFactor = 0;

@@ -70,10 +70,21 @@ int main(int argc, char **argv) {
     std::printf("N=%d nmatches=%d self=%d inliers=%d tx=%.6f dist00=%d inview=%d local=%d selflocal=%d\n", N, nmatches, self, ninl,
                 F.mTcw[3], fishbird::ORBmatcher::DescriptorDistance(F.mDescriptors.data(), F.mDescriptors.data()), inView, nLocal,
                 selfLocal);
+    // Frame::ComputeImageBounds + UndistortKeyPoints with the fisheye model (Frame.cc:636-669,741-795)
+    fishbird::Frame U;
+    U.fx = 650.f; U.fy = 648.f; U.cx = 640.f; U.cy = 360.f;
+    const float D0[4] = {0, 0, 0, 0}, D1[4] = {-0.02f, 0.004f, -0.001f, 0.0002f};
+    U.UndistortKeyPoints(F.mvKeysUn, D0);
+    int same = 0;
+    for (int i = 0; i < N; i++) same += U.mvKeysUn[i].x == F.mvKeysUn[i].x && U.mvKeysUn[i].y == F.mvKeysUn[i].y;
+    U.ComputeImageBounds(1280, 720, D1);
+    U.UndistortKeyPoints(F.mvKeysUn, D1);
+    std::printf("undist same=%d bounds=%.6f,%.6f,%.6f,%.6f\n", same, U.mnMinX, U.mnMaxX, U.mnMinY, U.mnMaxY);
     FILE *o = std::fopen(argv[4], "wb");
     std::fwrite(&N, 4, 1, o);
     std::fwrite(F.mvKeysUn.data(), sizeof(fb_keypoint), N, o);
     std::fwrite(F.mDescriptors.data(), 32, N, o);
+    std::fwrite(U.mvKeysUn.data(), sizeof(fb_keypoint), N, o);
     std::fclose(o);
   } catch (const std::exception &e) {
     std::fprintf(stderr, "error: %s\n", e.what());

@@ -40,7 +40,8 @@ def test_host_mirror_end_to_end():
     N, nmatches, self_, inl, tx, d00 = int(m[1]), int(m[2]), int(m[3]), int(m[4]), float(m[5]), int(m[6])
     raw = open(os.path.join(d, "out.bin"), "rb").read()
     k = np.frombuffer(raw[4: 4 + 24 * N], cabi.KP_DTYPE)
-    dsc = np.frombuffer(raw[4 + 24 * N:], np.uint8).reshape(N, 32)
+    dsc = np.frombuffer(raw[4 + 24 * N: 4 + 56 * N], np.uint8).reshape(N, 32)
+    kun = np.frombuffer(raw[4 + 56 * N:], cabi.KP_DTYPE)
     ko, do = O.orb_extract(O.orb_params(nfeatures=1000), img)
     assert np.array_equal(k, ko) and np.array_equal(dsc, do)
     assert d00 == 0
@@ -51,3 +52,11 @@ def test_host_mirror_end_to_end():
     in_view, n_local, self_local = int(m2[1]), int(m2[2]), int(m2[3])
     assert in_view > 0.95 * N                                  # isInFrustum: every point of the frame itself is visible
     assert n_local > 0.8 * N and self_local > 0.9 * n_local     # TrackLocalMap re-finds the frame's own points
+    # Frame::UndistortKeyPoints / ComputeImageBounds through the mirror == the oracle on the same key points
+    from fishbirdeyevisualslam_amd import more_problems as M
+    mu = re.search(r"undist same=(\d+) bounds=([-\d.]+),([-\d.]+),([-\d.]+),([-\d.]+)", out)
+    assert mu and int(mu[1]) == N
+    K4 = np.array([650.0, 648.0, 640.0, 360.0], np.float32)
+    D4 = np.array([-0.02, 0.004, -0.001, 0.0002], np.float32)
+    np.testing.assert_array_equal(kun, M.undistort(O.lib(), "orc_", k.copy(), K4=K4, D4=D4))
+    np.testing.assert_allclose([float(mu[i]) for i in range(2, 6)], M.image_bounds(O.lib(), "orc_", 1280, 720, K4=K4, D4=D4), rtol=0, atol=2e-6 * 1280)
