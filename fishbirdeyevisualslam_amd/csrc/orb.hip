@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t *__restrict__
   const int dxf = min(dx4, dw - 1);
   const int a = tb.xofs[dxf] & ~3;
   const int aw = min(a, spitch - 12);  // keep the 12-byte window inside the row (only the zero-padded tail moves)
-  int sel[4];                          // dword index of the first tap inside the window
-  uint32_t sh8[4];                     // byte shift of the first tap inside that dword
+  bool useHi[4];                       // the two taps lie in window dwords 1..2 (else 0..1)
+  uint32_t selw[4];                    // v_perm selector: tap0 -> bits 0..7, tap1 -> bits 16..23 of that dword pair
   uint32_t wgt[4];                     // a0 | a1 << 16
   bool live[4];
 #pragma unroll
@@ -171,9 +171,10 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t *__restrict__
     const int sx = tb.xofs[dxc];
     int a0 = tb.ialpha[dxc * 2], a1 = tb.ialpha[dxc * 2 + 1];
     if (sx + 1 > sw - 1) { a0 += a1; a1 = 0; }  // right border: both taps read sx
-    const int o = sx - aw;
-    sel[k] = o >> 2;
-    sh8[k] = (uint32_t)(o & 3);
+    const int o = sx - aw;             // byte offset of tap0 inside the 12-byte window, 0..10
+    useHi[k] = o >= 7;
+    const uint32_t ob = (uint32_t)(useHi[k] ? o - 4 : o);  // 0..6 inside the chosen 8 bytes
+    selw[k] = ob | (0x0cu << 8) | ((ob + 1u) << 16) | (0x0cu << 24);
     wgt[k] = (uint32_t)(a0 & 0xffff) | ((uint32_t)a1 << 16);
   }
   auto loadWin = [&](int sy, uint32_t (&wv)[3]) {
@@ -185,10 +186,8 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t *__restrict__
     const uint32_t w0 = wv[0], w1 = wv[1], w2 = wv[2];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const uint32_t lo = sel[k] == 0 ? w0 : (sel[k] == 1 ? w1 : w2);
-      const uint32_t hi = sel[k] == 0 ? w1 : w2;
-      const uint32_t two = __builtin_amdgcn_alignbyte(hi, lo, sh8[k]);  // bytes [tap0, tap1, ..]
-      const uint32_t spread = __builtin_amdgcn_perm(0u, two, 0x0c010c00u);  // tap0 | tap1 << 16
+      const uint32_t lo = useHi[k] ? w1 : w0, hi = useHi[k] ? w2 : w1;
+      const uint32_t spread = __builtin_amdgcn_perm(hi, lo, selw[k]);  // tap0 | tap1 << 16
       typedef short short2_t __attribute__((ext_vector_type(2)));
       union { uint32_t u; short2_t s; } A, B;
       A.u = spread;
