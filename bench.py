@@ -119,6 +119,34 @@ def local_ba_leg(L, rank, world_size, local_rank, reps=3):
     return res
 
 
+def match_pair_rate(pipe, world, kern_serial, B, nprob=4, th=15.0):
+    fk, _ = pipe.keypoints_host("front")
+    sf = np.array(list(pipe.tables.scale_factor)[: pipe.params.nlevels], np.float32)
+    pairs = []
+    for b in range(min(nprob, B)):
+        w, k = world[b], fk[b]
+        T = np.asarray(w["Tcw0"], np.float64).reshape(3, 4)
+        X = w["last_xw"].astype(np.float64) @ T[:, :3].T + T[:, 3]
+        ok = X[:, 2] > 0
+        u = pipe.fx * X[:, 0] / X[:, 2] + pipe.cx
+        v = pipe.fy * X[:, 1] / X[:, 2] + pipe.cy
+        ok &= (u >= 0) & (u < pipe.fw) & (v >= 0) & (v < pipe.fh)
+        octv = w["last_octave"]
+        r = th * sf[octv]
+        kx, ky, ko = k["x"].astype(np.float64), k["y"].astype(np.float64), k["octave"]
+        n = 0
+        for q in np.nonzero(ok)[0]:
+            m = (np.abs(kx - u[q]) < r[q]) & (np.abs(ky - v[q]) < r[q]) & (ko >= octv[q] - 1) & (ko <= octv[q] + 1)
+            n += int(m.sum())
+        pairs.append(n)
+    per_problem = float(np.mean(pairs))
+    ms = kern_serial["k_proj_frame"][1] / kern_serial["k_proj_frame"][0] if "k_proj_frame" in kern_serial else None
+    return {"kernel": "k_proj_frame", "descriptor_pairs_per_problem": per_problem, "problems_sampled": len(pairs),
+            "gpairs_per_s_no_overlap": per_problem * B / (ms * 1e-3) / 1e9 if ms else None,
+            "note": "256-bit Hamming distances per second of the front matcher alone (single-stream launch time, per "
+                    "fixed-point round once); window th=15"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,6 +296,13 @@ def main():
                                "front_matches": float(res["nm_front"].mean()), "bird_matches": float(res["nm_bird"].mean()),
                                "pose_inliers": float(res["ninliers"].mean())},
         }
+        # the matchers' integer work = descriptor pairs actually compared.  Counted on the host for the first
+        # problems of the batch with the window rule of SearchByProjection(CurrentFrame, LastFrame) (ORBmatcher.cc:1361-
+        # 1411: radius th * scale[octave], levels octave-1 .. octave+1, |dx|,|dy| < r as GetFeaturesInArea, Frame.cc:498-546)
+        try:
+            out["match"] = match_pair_rate(pipe, world, kern_serial, B)
+        except Exception as e:  # a reporting extra must never cost the bench line
+            out["match"] = {"error": str(e)[:200]}
         out["local_ba"] = ba
         # the CPU leg is timed on rank 0 of the single-GPU run only (N > 1 would stall the other ranks)
         out["cpu_baseline"] = cpu_baseline(front, bird, world, min(a.cpu_sample, B)) if (a.cpu_sample > 0 and world_size == 1) else None

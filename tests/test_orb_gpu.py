@@ -103,3 +103,29 @@ def test_extract_degenerate_pyramid_levels():
             orb.extract(img)
     finally:
         orb.close()
+
+
+def test_fast_phase_timers(monkeypatch):
+    """fb_orb_debug_timers: with FB_FAST_DBG=20 (read when the handle sizes its workspace) the TIMED instantiation of
+    k_fast runs -- same key points, and one workgroup in 16 reports its phase times; reading resets the counters."""
+    img = synth.synth_image(1000, 640, 480)
+    ref = H.Orb(O.orb_params())
+    k0, d0 = ref.extract(img)
+    t = (C.c_uint64 * 16)()
+    fb.check(fb.lib().fb_orb_debug_timers(ref.h, t), "timers")
+    assert list(t)[:12] == [0] * 12          # normal instantiation: nothing is timed
+    ref.close()
+    monkeypatch.setenv("FB_FAST_DBG", "20")
+    orb = H.Orb(O.orb_params())
+    try:
+        k1, d1 = orb.extract(img)
+        np.testing.assert_array_equal(k1, k0)
+        np.testing.assert_array_equal(d1, d0)
+        fb.check(fb.lib().fb_orb_debug_timers(orb.h, t), "timers")
+        waves, total = t[11], t[10]
+        assert waves > 0 and total > 0
+        assert sum(t[i] for i in range(10)) <= total and t[2] > 0      # phases are disjoint parts of the wave; the sweep ran
+        fb.check(fb.lib().fb_orb_debug_timers(orb.h, t), "timers")
+        assert t[11] == 0                                              # reading reset them
+    finally:
+        orb.close()
