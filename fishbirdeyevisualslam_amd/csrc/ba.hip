@@ -551,7 +551,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lam
   const int nb6 = P6 / 6;
   for (int J = 0; J < nb6; J++) {
     const int c0 = 6 * J, c1 = c0 + 6;
-    double Lb[6][6], d[6];
+    double Lb[6][6], d[6], dinv[6];
 #pragma unroll
     for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -565,6 +565,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lam
       if (dc < 0) neg = true;
       d[c] = dc;
       const double inv = dc != 0 ? 1.0 / dc : 0.0;
+      dinv[c] = inv;
 #pragma unroll
       for (int r = c + 1; r < 6; r++) {
         double v = Lb[r][c];
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lam
 #pragma unroll
       for (int c = 0; c < 6; c++) {
         Up[(size_t)i * 6 + c] = u[c];
-        A[(size_t)i * ld + c0 + c] = d[c] != 0 ? u[c] / d[c] : 0.0;
+        A[(size_t)i * ld + c0 + c] = u[c] * dinv[c];  // dinv = 0 for a zero pivot, as the division rule above
       }
     }
     __syncthreads();
@@ -613,41 +614,55 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lam
     }
     __syncthreads();
   }
-  // triangular solves by wave 0: lane owns rows lane, lane+64, ...
-  if (tid < 64) {
-    constexpr int RPL = 4;  // rows per lane, P6 <= 256
-    double y[RPL];
+  // Triangular solves, blocked like the factorisation: per 6-row block every thread solves the 6x6 triangle
+  // redundantly from LDS (no broadcast barrier), then the rows outside the block take their rank-6 update in parallel
+  // -- one barrier per key frame and direction instead of 2 x P6 dependent shuffle steps in a single wave.
+  for (int J = 0; J < nb6; J++) {  // forward: L y = b
+    const int c0 = 6 * J, c1 = c0 + 6;
+    double yJ[6];
 #pragma unroll
-    for (int q = 0; q < RPL; q++) y[q] = (tid + 64 * q < P6) ? rhs[tid + 64 * q] : 0.0;
-    for (int i = 0; i < P6; i++) {  // forward: L y = b
-      const int qi = i >> 6;
-      const double yi = __shfl(qi == 0 ? y[0] : (qi == 1 ? y[1] : (qi == 2 ? y[2] : y[3])), i & 63, 64);  // no dynamic register index
+    for (int r = 0; r < 6; r++) {
+      double v = rhs[c0 + r];
 #pragma unroll
-      for (int q = 0; q < RPL; q++) {
-        const int r = tid + 64 * q;
-        if (r > i && r < P6) y[q] -= A[(size_t)r * ld + i] * yi;
-      }
+      for (int m = 0; m < r; m++) v -= A[(size_t)(c0 + r) * ld + c0 + m] * yJ[m];
+      yJ[r] = v;
     }
+    __syncthreads();  // everyone has read rhs[c0..c1) before it is overwritten / the rows below are updated
+    if (tid < 6) rhs[c0 + tid] = yJ[tid];
+    for (int i = c1 + tid; i < P6; i += SOLVE_THREADS) {
+      double v = rhs[i];
 #pragma unroll
-    for (int q = 0; q < RPL; q++) {  // D^-1
-      const int r = tid + 64 * q;
-      if (r < P6) { const double dd = A[(size_t)r * ld + r]; y[q] = dd != 0 ? y[q] / dd : 0.0; }
+      for (int c = 0; c < 6; c++) v -= A[(size_t)i * ld + c0 + c] * yJ[c];
+      rhs[i] = v;
     }
-    for (int i = P6 - 1; i >= 0; i--) {  // backward: L^T x = y
-      const int qi = i >> 6;
-      const double xi = __shfl(qi == 0 ? y[0] : (qi == 1 ? y[1] : (qi == 2 ? y[2] : y[3])), i & 63, 64);
-#pragma unroll
-      for (int q = 0; q < RPL; q++) {
-        const int r = tid + 64 * q;
-        if (r < i) y[q] -= A[(size_t)i * ld + r] * xi;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < RPL; q++) {
-      const int r = tid + 64 * q;
-      if (r < P6) xp[r] = y[q];
-    }
+    __syncthreads();
   }
+  for (int i = tid; i < P6; i += SOLVE_THREADS) {  // D^-1
+    const double dd = A[(size_t)i * ld + i];
+    rhs[i] = dd != 0 ? rhs[i] / dd : 0.0;
+  }
+  __syncthreads();
+  for (int J = nb6 - 1; J >= 0; J--) {  // backward: L^T x = y
+    const int c0 = 6 * J;
+    double xJ[6];
+#pragma unroll
+    for (int r = 5; r >= 0; r--) {
+      double v = rhs[c0 + r];
+#pragma unroll
+      for (int m = 5; m > r; m--) v -= A[(size_t)(c0 + m) * ld + c0 + r] * xJ[m];
+      xJ[r] = v;
+    }
+    __syncthreads();
+    if (tid < 6) rhs[c0 + tid] = xJ[tid];
+    for (int i = tid; i < c0; i += SOLVE_THREADS) {
+      double v = rhs[i];
+#pragma unroll
+      for (int c = 0; c < 6; c++) v -= A[(size_t)(c0 + c) * ld + i] * xJ[c];
+      rhs[i] = v;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < P6; i += SOLVE_THREADS) xp[i] = rhs[i];
   __syncthreads();
   if (tid == 0) *okFlag = s_ok ? 1.0 : 0.0;
 }
