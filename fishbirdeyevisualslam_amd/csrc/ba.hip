@@ -161,24 +161,41 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BADev D, State S, 
     double H[9], b3[3] = {0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 9; i++) H[i] = 0;
-    for (int c = D.lm_start[l]; c < D.lm_start[l + 1]; c++) {
-      const int e = D.lm_edges[c];
+    // The edges of a landmark are walked in chunks of 4 with the three dependent gathers (edge id -> its scalars and key
+    // frame -> the key frame's pose) each issued for the whole chunk: three memory latencies per chunk, not per edge.
+    const int cBeg = D.lm_start[l], cEnd = D.lm_start[l + 1];
+    for (int c0 = cBeg; c0 < cEnd; c0 += 4) {
+      int ee[4], kfv[4], lvl[4], typ[4];
+      double infov[4], measv[4][3];
+      SE3 Tv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) ee[u] = D.lm_edges[min(c0 + u, cEnd - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        kfv[u] = D.e_kf[ee[u]]; lvl[u] = D.e_level[ee[u]]; typ[u] = D.e_type[ee[u]]; infov[u] = D.e_info[ee[u]];
+        measv[u][0] = D.e_meas[3 * ee[u]]; measv[u][1] = D.e_meas[3 * ee[u] + 1]; measv[u][2] = D.e_meas[3 * ee[u] + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) Tv[u] = S.pose[kfv[u]];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+      if (c0 + u >= cEnd) break;
+      const int e = ee[u];
       double *W = B.W + (size_t)e * 18;
-      const int kf = D.e_kf[e];
-      const int pj = D.poseIdx[kf];
-      if (D.e_level[e] != 0) {
+      const int pj = D.poseIdx[kfv[u]];
+      if (lvl[u] != 0) {
 #pragma unroll
         for (int i = 0; i < 18; i++) W[i] = 0;
         continue;
       }
-      const int type = D.e_type[e];
-      const SE3 T = S.pose[kf];
-      const double meas[3] = {D.e_meas[3 * e], D.e_meas[3 * e + 1], D.e_meas[3 * e + 2]};
+      const int type = typ[u];
+      const SE3 T = Tv[u];
+      const double meas[3] = {measv[u][0], measv[u][1], measv[u][2]};
       double p[3];
       EdgeLin L;
       edge_residual(D, type, T, X, meas, p, L.err);
       edge_jacobians(D, type, T, p, L);
-      const double info = D.e_info[e];
+      const double info = infov[u];
       double chi2 = 0;
 #pragma unroll
       for (int r = 0; r < 3; r++) chi2 += L.err[r] * (info * L.err[r]);
@@ -217,6 +234,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BADev D, State S, 
       } else {
 #pragma unroll
         for (int i = 0; i < 18; i++) W[i] = 0;
+      }
       }
     }
 #pragma unroll
