@@ -27,7 +27,8 @@ constexpr int HALF_PATCH = 15;      // :73
 constexpr int PATCH_SIZE = 31;      // :72
 constexpr int BORDER = EDGE_THRESHOLD - 3;  // minBorderX/Y, :773
 
-__constant__ int c_pattern[1024] = {
+// stored as float (the values are small integers): the rotation below works in float, this saves the conversions
+__constant__ float c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
 
@@ -1006,11 +1007,11 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(OrbK K, const uint8_
       if (l < K.nlevels && ki >= lstart[l]) { kl = l; adj = K.L[l].outBase - lstart[l]; }
     recv = lvlOut[(long long)b * K.outStride + adj + ki];
   }
-  int4 pp[4];
+  float4 pp[4];
 #pragma unroll
-  for (int t = 0; t < 4; t++) pp[t] = reinterpret_cast<const int4 *>(c_pattern)[lane * 4 + t];
+  for (int t = 0; t < 4; t++) pp[t] = reinterpret_cast<const float4 *>(c_pattern)[lane * 4 + t];
   const uint4 angW = angTab[(lane < 62 ? lane : 0) * 2], angK = angTab[(lane < 62 ? lane : 0) * 2 + 1];
-  if (K.dbg == 11) { if (pp[0].x + pp[1].y + pp[2].z + pp[3].w + (int)angW.x + (int)angK.y + (int)recv == 1234567) nOut[0] = 1; return; }
+  if (K.dbg == 11) { if ((int)(pp[0].x + pp[1].y + pp[2].z + pp[3].w) + (int)angW.x + (int)angK.y + (int)recv == 1234567) nOut[0] = 1; return; }
   // fixed lane -> (row within a group, dword) mapping: 6 rows x 10 dwords (7 x 9 for the raw patch) per pass, so the
   // global offsets and the LDS indices are constants per lane (32-bit offsets from wave-uniform bases, 24-bit
   // multiplies: 64/32-bit integer multiplies are quarter rate)
@@ -1110,7 +1111,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(OrbK K, const uint8_
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
-    if (K.dbg == 12) { if (m10 + m01 == 12345678 && pp[0].x + pp[1].y + pp[2].z + pp[3].w == 77777) nOut[0] = 1; continue; }
+    if (K.dbg == 12) { if (m10 + m01 == 12345678 && (int)(pp[0].x + pp[1].y + pp[2].z + pp[3].w) == 77777) nOut[0] = 1; continue; }
     const float angle = fb_fast_atan2((float)m01, (float)m10);
     // computeOrbDescriptor (ORBextractor.cc:107-147): lane computes tests 4*lane .. 4*lane+3
     const float factorPI = 0x1.1df46ap-6f;
@@ -1121,7 +1122,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(OrbK K, const uint8_
     int nib = 0;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      const float x0 = (float)pp[t].x, y0 = (float)pp[t].y, x1 = (float)pp[t].z, y1 = (float)pp[t].w;
+      const float x0 = pp[t].x, y0 = pp[t].y, x1 = pp[t].z, y1 = pp[t].w;
       const int t0 = centre[__mul24(fb_cvround(x0 * bb + y0 * a), DP_BL_DW * 4) + fb_cvround(x0 * a - y0 * bb)];
       const int t1 = centre[__mul24(fb_cvround(x1 * bb + y1 * a), DP_BL_DW * 4) + fb_cvround(x1 * a - y1 * bb)];
       nib |= (t0 < t1) << t;
