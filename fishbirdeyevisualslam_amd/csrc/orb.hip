@@ -1044,13 +1044,19 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(OrbK K, const uint8_
   // All global loads of both patches are issued together (rows past a patch are clamped and their data dropped; key
   // points sit >= 19 px inside the level, so neither patch leaves the image)
   auto issue = [&](const KP &k, uint32_t (&vb)[NB_IT], uint32_t (&vr)[NR_IT]) {
+    {  // row offsets advance by a constant; only the last group can run past the patch and is clamped
+      uint32_t off = (uint32_t)(__mul24(k.cy - 18 + rb0, k.bpitch) + k.bxa + min(dwb, DP_BL_DW - 1) * 4);
+      const uint32_t step = 6u * (uint32_t)k.bpitch;
 #pragma unroll
-    for (int it = 0; it < NB_IT; it++)
-      vb[it] = *reinterpret_cast<const uint32_t *>(k.bbase + (uint32_t)(__mul24(k.cy - 18 + min(it * 6 + rb0, DP_BL_ROWS - 1), k.bpitch) + k.bxa + min(dwb, DP_BL_DW - 1) * 4));
+      for (int it = 0; it < NB_IT - 1; it++, off += step) vb[it] = *reinterpret_cast<const uint32_t *>(k.bbase + off);
+      vb[NB_IT - 1] = *reinterpret_cast<const uint32_t *>(k.bbase + (uint32_t)(__mul24(k.cy - 18 + min((NB_IT - 1) * 6 + rb0, DP_BL_ROWS - 1), k.bpitch) + k.bxa + min(dwb, DP_BL_DW - 1) * 4));
+    }
     if (k.rawAligned) {
+      uint32_t off = (uint32_t)(__mul24(k.cy - 15 + rr0, k.pitch) + k.rxa + min(dwr, DP_RAW_DW - 1) * 4);
+      const uint32_t step = 7u * (uint32_t)k.pitch;
 #pragma unroll
-      for (int it = 0; it < NR_IT; it++)
-        vr[it] = *reinterpret_cast<const uint32_t *>(k.img + (uint32_t)(__mul24(k.cy - 15 + min(it * 7 + rr0, DP_RAW_ROWS - 1), k.pitch) + k.rxa + min(dwr, DP_RAW_DW - 1) * 4));
+      for (int it = 0; it < NR_IT - 1; it++, off += step) vr[it] = *reinterpret_cast<const uint32_t *>(k.img + off);
+      vr[NR_IT - 1] = *reinterpret_cast<const uint32_t *>(k.img + (uint32_t)(__mul24(k.cy - 15 + min((NR_IT - 1) * 7 + rr0, DP_RAW_ROWS - 1), k.pitch) + k.rxa + min(dwr, DP_RAW_DW - 1) * 4));
     }
   };
   auto stage = [&](const KP &k, const uint32_t (&vb)[NB_IT], const uint32_t (&vr)[NR_IT]) {
