@@ -138,8 +138,10 @@ __host__ __device__ inline SE3 se3_exp(const double u[6]) {  // SE3Quat::exp, se
   if (theta < 0.00001) {
     for (int i = 0; i < 9; i++) { R[i] = I[i] + Om[i] + Om2[i]; V[i] = R[i]; }  // sic
   } else {
-    const double s = sin(theta), c = cos(theta);
-    const double a = s / theta, b = (1 - c) / (theta * theta), d = (theta - s) / (theta * theta * theta);
+    double s, c;
+    sincos(theta, &s, &c);
+    const double it = 1.0 / theta, it2 = it * it;  // one division instead of three
+    const double a = s * it, b = (1 - c) * it2, d = (theta - s) * (it2 * it);
     for (int i = 0; i < 9; i++) {
       R[i] = I[i] + a * Om[i] + b * Om2[i];
       V[i] = I[i] + b * Om[i] + d * Om2[i];
@@ -225,7 +227,7 @@ __host__ __device__ inline void huber(double e, double delta, double &rho0, doub
 // Symmetric 6x6 solve, LDL^T without pivoting; false on a negative pivot
 // (LinearSolverDense, solvers/linear_solver_dense.h:65-113: Eigen LDLT::isPositive()).
 __host__ __device__ inline bool ldlt6(const double H[36], double lambda, const double b[6], double x[6]) {
-  double A[36], d[6], y[6];
+  double A[36], d[6], dinv[6], y[6];
 #pragma unroll
   for (int i = 0; i < 36; i++) A[i] = H[i];
 #pragma unroll
@@ -238,12 +240,16 @@ __host__ __device__ inline bool ldlt6(const double H[36], double lambda, const d
     for (int k = 0; k < j; k++) dj -= A[j * 6 + k] * A[j * 6 + k] * d[k];
     if (dj < 0) ok = false;
     d[j] = dj;
+    // one reciprocal per pivot: this routine runs on ONE lane inside every LM trial of k_pose_opt, and an fp64 division is
+    // ~35 dependent instructions (21 of them were a sixth of a trial); s * (1/dj) is within one ulp of s / dj
+    const double inv = dj != 0 ? 1.0 / dj : 0.0;
+    dinv[j] = inv;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
       double s = A[i * 6 + j];
 #pragma unroll
       for (int k = 0; k < j; k++) s -= A[i * 6 + k] * A[j * 6 + k] * d[k];
-      A[i * 6 + j] = dj != 0 ? s / dj : 0;
+      A[i * 6 + j] = s * inv;
     }
   }
   if (!ok) return false;
@@ -255,7 +261,7 @@ __host__ __device__ inline bool ldlt6(const double H[36], double lambda, const d
     y[i] = s;
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) y[i] = d[i] != 0 ? y[i] / d[i] : 0;
+  for (int i = 0; i < 6; i++) y[i] = y[i] * dinv[i];
 #pragma unroll
   for (int i = 5; i >= 0; i--) {
     double s = y[i];
