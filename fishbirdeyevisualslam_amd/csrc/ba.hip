@@ -296,10 +296,13 @@ __global__ __launch_bounds__(POSE_THREADS) void k_ba_pose(BADev D, State S, LinB
       }
     }
   }
+  {
+    double v[32];
 #pragma unroll
-  for (int i = 0; i < 27; i++) {
-    const double s = wave_sum_d(acc[i]);
-    if ((tid & 63) == 0) s_part[tid >> 6][i] = s;
+    for (int i = 0; i < 32; i++) v[i] = i < 27 ? acc[i] : 0.0;
+    const int lane = tid & 63;
+    const double s = fb::wave_column_sums32(v, lane);  // lane L: column L >> 1
+    if ((lane & 1) == 0 && (lane >> 1) < 27) s_part[tid >> 6][lane >> 1] = s;
   }
   __syncthreads();
   if (tid < 27) {

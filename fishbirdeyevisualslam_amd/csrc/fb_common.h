@@ -98,6 +98,25 @@ struct DevBuf {
   template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Column sums of up to 32 per-lane values over the 64 lanes as a reduce-scatter butterfly: at the step with mask m a
+// lane sends one half of its values to lane^m, keeps the other half and adds what it receives, so the value count halves
+// every step (16 + 8 + 4 + 2 + 1 + 1 = 32 fp64 exchanges instead of 6 per value).  On return v[0] of lane L is the sum
+// over all lanes of column L >> 1.  (28 accumulators through plain butterflies were most of an LM evaluation: 168
+// dependent cross-lane exchanges per wave.)
+__device__ __forceinline__ double wave_column_sums32(double (&v)[32], int lane) {
+#pragma unroll
+  for (int half = 16, m = 32; half >= 1; half >>= 1, m >>= 1) {
+    const bool up = (lane & m) != 0;
+#pragma unroll
+    for (int i = 0; i < half; i++) {
+      const double send = up ? v[i] : v[i + half];
+      const double keep = up ? v[i + half] : v[i];
+      v[i] = keep + __shfl_xor(send, m, 64);
+    }
+  }
+  return v[0] + __shfl_xor(v[0], 1, 64);
+}
+
 // 256-bit Hamming distance of two 32-byte rows given as 8 dwords each
 // (DescriptorDistance, ORBmatcher.cc:1951-1967; v_bcnt_u32_b32 instead of the SWAR bithack)
 __device__ __forceinline__ int hamming256(const uint32_t a[8], const uint4 *__restrict__ b) {

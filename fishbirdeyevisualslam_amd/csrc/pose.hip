@@ -41,25 +41,6 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// Column sums of up to 32 per-lane values over the 64 lanes as a reduce-scatter butterfly: at the step with mask m a
-// lane sends one half of its values to lane^m, keeps the other half and adds what it receives, so the value count halves
-// every step (16 + 8 + 4 + 2 + 1 + 1 = 32 fp64 exchanges instead of 6 per value).  On return v[0] of lane L is the sum
-// over all lanes of column L >> 1.  (28 accumulators through plain butterflies were most of an LM evaluation: 168
-// dependent cross-lane exchanges per wave.)
-__device__ __forceinline__ double wave_column_sums32(double (&v)[32], int lane) {
-#pragma unroll
-  for (int half = 16, m = 32; half >= 1; half >>= 1, m >>= 1) {
-    const bool up = (lane & m) != 0;
-#pragma unroll
-    for (int i = 0; i < half; i++) {
-      const double send = up ? v[i] : v[i + half];
-      const double keep = up ? v[i + half] : v[i];
-      v[i] = keep + __shfl_xor(send, m, 64);
-    }
-  }
-  return v[0] + __shfl_xor(v[0], 1, 64);
-}
-
 struct EdgeView {  // staged (LDS) or global float arrays of one problem
   const float *fxw, *fobs, *finf;
   const float *bxw, *bxc, *binf;
@@ -135,7 +116,7 @@ __device__ void eval_pass(const EdgeView &E, const fb::SE3 &T, bool robust, doub
     double v[32];
 #pragma unroll
     for (int i = 0; i < 32; i++) v[i] = i < NACC ? acc[i] : 0.0;
-    const double s = wave_column_sums32(v, lane);
+    const double s = fb::wave_column_sums32(v, lane);
     if ((lane & 1) == 0 && (lane >> 1) < NACC) S->part[wv][lane >> 1] = s;
   }
   __syncthreads();
