@@ -13,6 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libfishbird_hip.so")
 SOURCES = ["runtime.hip", "match.hip", "match_bow.hip", "frame.hip", "bow.hip", "orb.hip", "pose.hip", "ba.hip"]
+# Files whose results are held to a floating-point tolerance (poses: 1e-4 relative), not to bit equality with the
+# oracle: fused multiply-adds are allowed there.  An LM evaluation of k_pose_opt is ~75 % fp64 edge arithmetic that one
+# wave per SIMD issues back to back; mul + add pairs instead of fma made it a quarter longer.
+FMA_OK = {"pose.hip"}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fgpu-rdc=0" if False else "-Wall", "-Wno-unused-function"]
 
@@ -46,7 +50,10 @@ def build(force=False, verbose=True):
                 os.path.getmtime(s), *(os.path.getmtime(os.path.join(CSRC, h)) for h in os.listdir(CSRC) if h.endswith((".h", ".inc"))),
                 os.path.getmtime(os.path.join(HERE, "..", "include", "fishbird.h"))):
             continue
-        cmd = [hipcc()] + FLAGS + ["-c", s, "-o", o]
+        flags = FLAGS
+        if os.path.basename(s) in FMA_OK:
+            flags = [("-ffp-contract=fast" if f == "-ffp-contract=off" else f) for f in FLAGS]
+        cmd = [hipcc()] + flags + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))
