@@ -82,6 +82,46 @@ __device__ __forceinline__ void accumulate_edge(const double (&J)[DIM][6], const
   }
 }
 
+// The same for EdgeSE3ProjectBirdPoint2CamXYZ, whose Jacobian -[-skew(p), I] is mostly structural zeros and -1s: only
+// the non-zero products are formed, in the row order of the generic loop (a product with a structural 0 adds an exact
+// 0, one with -1 is an exact negation), so the sums are the same numbers at a fifth of the arithmetic.
+__device__ __forceinline__ void accumulate_bird_edge(const double (&p)[3], const double (&err)[3], double info, bool robust,
+                                                     double delta, double (&acc)[NACC]) {
+  double chi2 = 0;
+#pragma unroll
+  for (int r = 0; r < 3; r++) chi2 += err[r] * (info * err[r]);
+  double rho0 = chi2, rho1 = 1.;
+  if (robust) fb::huber(chi2, delta, rho0, rho1);
+  acc[0] += rho0;
+  const double w = rho1 * info;
+  const double ie0 = info * err[0], ie1 = info * err[1], ie2 = info * err[2];
+  const double px = p[0], py = p[1], pz = p[2];
+  // b: s_i = sum_r J[r][i] * ie[r]
+  acc[22] -= rho1 * (pz * ie1 + (-py) * ie2);
+  acc[23] -= rho1 * ((-pz) * ie0 + px * ie2);
+  acc[24] -= rho1 * (py * ie0 + (-px) * ie1);
+  acc[25] -= rho1 * (-ie0);
+  acc[26] -= rho1 * (-ie1);
+  acc[27] -= rho1 * (-ie2);
+  // H upper triangle, row-major from acc[1]: h_ij = sum_r (J[r][i] * w) * J[r][j]
+  const double a = pz * w, b = py * w, c = px * w;
+  acc[1] += a * pz + b * py;    // (0,0)
+  acc[2] += -(b * px);          // (0,1)
+  acc[3] += -(a * px);          // (0,2)
+  acc[5] += -a;                 // (0,4)   (0,3) = 0
+  acc[6] += b;                  // (0,5)
+  acc[7] += a * pz + c * px;    // (1,1)
+  acc[8] += -(a * py);          // (1,2)
+  acc[9] += a;                  // (1,3)   (1,4) = 0
+  acc[11] += -c;                // (1,5)
+  acc[12] += b * py + c * px;   // (2,2)
+  acc[13] += -b;                // (2,3)
+  acc[14] += c;                 // (2,4)   (2,5) = 0
+  acc[16] += w;                 // (3,3)   (3,4) = (3,5) = 0
+  acc[19] += w;                 // (4,4)   (4,5) = 0
+  acc[21] += w;                 // (5,5)
+}
+
 // one evaluation: robust chi2 + H + b at pose T over the active edges
 __device__ void eval_pass(const EdgeView &E, const fb::SE3 &T, bool robust, double delta, double fx, double fy,
                           double cx, double cy, PoseLds *S) {
@@ -108,8 +148,7 @@ __device__ void eval_pass(const EdgeView &E, const fb::SE3 &T, bool robust, doub
     double p[3];
     fb::se3_map(T, Xw, p);
     const double err[3] = {(double)E.bxc[k * 3] - p[0], (double)E.bxc[k * 3 + 1] - p[1], (double)E.bxc[k * 3 + 2] - p[2]};
-    const double J[3][6] = {{0, -p[2], p[1], -1, 0, 0}, {p[2], 0, -p[0], 0, -1, 0}, {-p[1], p[0], 0, 0, 0, -1}};  // -[-skew(p), I]
-    accumulate_edge<3>(J, err, (double)E.binf[k] * E.wb, robust, delta, acc);
+    accumulate_bird_edge(p, err, (double)E.binf[k] * E.wb, robust, delta, acc);  // J = -[-skew(p), I]
   }
   const int lane = tid & 63, wv = tid >> 6;
   {
