@@ -51,7 +51,8 @@ struct EdgeView {  // staged (LDS) or global float arrays of one problem
 
 // accumulate one edge (base_unary_edge.hpp:43-72): b -= rho1 * J^T (info e), H += J^T (rho1 info) J.
 // DIM is a compile-time constant and every loop is unrolled so J/err/acc stay in registers.
-template <int DIM>
+// ZMASK: bit r*6+i set = J[r][i] is a structural zero; its products are exact zeros and are not formed.
+template <int DIM, unsigned ZMASK = 0u>
 __device__ __forceinline__ void accumulate_edge(const double (&J)[DIM][6], const double (&err)[DIM], double info,
                                                 bool robust, double delta, double (&acc)[NACC]) {
   double chi2 = 0;
@@ -69,13 +70,15 @@ __device__ __forceinline__ void accumulate_edge(const double (&J)[DIM][6], const
   for (int i = 0; i < 6; i++) {
     double s = 0;
 #pragma unroll
-    for (int r = 0; r < DIM; r++) s += J[r][i] * ie[r];
+    for (int r = 0; r < DIM; r++)
+      if (!((ZMASK >> (r * 6 + i)) & 1u)) s += J[r][i] * ie[r];
     acc[22 + i] -= rho1 * s;
 #pragma unroll
     for (int j = i; j < 6; j++) {
       double h = 0;
 #pragma unroll
-      for (int r = 0; r < DIM; r++) h += J[r][i] * w * J[r][j];
+      for (int r = 0; r < DIM; r++)
+        if (!(((ZMASK >> (r * 6 + i)) | (ZMASK >> (r * 6 + j))) & 1u)) h += J[r][i] * w * J[r][j];
       acc[hidx] += h;
       hidx++;
     }
@@ -140,7 +143,7 @@ __device__ void eval_pass(const EdgeView &E, const fb::SE3 &T, bool robust, doub
     const double err[2] = {(double)E.fobs[e * 2] - ((X * invz) * fx + cx), (double)E.fobs[e * 2 + 1] - ((Y * invz) * fy + cy)};
     const double J[2][6] = {{X * Y * invz_2 * fx, -(1 + (X * X * invz_2)) * fx, Y * invz * fx, -invz * fx, 0, X * invz_2 * fx},
                             {(1 + Y * Y * invz_2) * fy, -X * Y * invz_2 * fy, -X * invz * fy, 0, -invz * fy, Y * invz_2 * fy}};
-    accumulate_edge<2>(J, err, (double)E.finf[e] * E.wf, robust, delta, acc);
+    accumulate_edge<2, (1u << 4) | (1u << 9)>(J, err, (double)E.finf[e] * E.wf, robust, delta, acc);  // J[0][4] = J[1][3] = 0
   }
   for (int k = tid; k < E.nbs; k += POSE_THREADS) {  // EdgeSE3ProjectBirdPoint2CamXYZ
     if (E.blevel[k] != 0) continue;
