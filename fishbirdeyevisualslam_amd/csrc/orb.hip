@@ -1478,6 +1478,7 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
       FAST_LAUNCH(56)
     else
       FAST_LAUNCH(FAST_MAX_TILE)
+#undef FAST_LAUNCH
   }
   {
     fb::ProfScope prof_(fb::P_BLUR, s);
