@@ -421,6 +421,11 @@ int fb_pose_opt_batch_dev(const fb_pose_opt_args *A, void *stream) {
   FB_ARG(A && A->batch >= 0 && A->front_stride >= 0 && A->bird_stride >= 0);
   FB_ARG(A->mode == FB_POSE_FRONT || A->mode == FB_POSE_FRONT_BIRD || A->mode == FB_POSE_BIRD);
   FB_ARG(A->Tcw && A->ninliers);
+  // the edge family a mode optimises must be complete (the kernel reads and writes all of it); the other one is ignored
+  if (A->mode != FB_POSE_BIRD)
+    FB_ARG(A->n_front && A->front_outlier && (A->front_stride == 0 || (A->front_xw && A->front_obs && A->front_inv_sigma2)));
+  if (A->mode != FB_POSE_FRONT)
+    FB_ARG(A->n_bird && A->bird_outlier && (A->bird_stride == 0 || (A->bird_xw && A->bird_xc && A->bird_inv_sigma2)));
   if (A->batch == 0) return FB_OK;
   const size_t flags = ((size_t)((A->front_stride + 15) & ~15)) + ((A->bird_stride + 15) & ~15);
   const size_t stagedBytes = ((size_t)A->front_stride * 6 + (size_t)A->bird_stride * 7) * 4;
@@ -437,7 +442,15 @@ int fb_pose_opt_batch_dev(const fb_pose_opt_args *A, void *stream) {
 
 int fb_pose_opt(const fb_pose_opt_args *H) {
   FB_TRY(fb::check_device());
-  FB_ARG(H && H->batch >= 0);
+  FB_ARG(H && H->batch >= 0 && H->front_stride >= 0 && H->bird_stride >= 0);
+  FB_ARG(H->mode == FB_POSE_FRONT || H->mode == FB_POSE_FRONT_BIRD || H->mode == FB_POSE_BIRD);
+  FB_ARG(H->Tcw && H->ninliers);
+  if (H->mode != FB_POSE_BIRD) FB_ARG(H->n_front && H->front_outlier);
+  if (H->mode != FB_POSE_FRONT) FB_ARG(H->n_bird && H->bird_outlier);
+  for (int b = 0; b < H->batch; b++) {  // a count beyond the stride would run into the next frame's edges
+    if (H->mode != FB_POSE_BIRD) FB_ARG(H->n_front[b] >= 0 && H->n_front[b] <= H->front_stride);
+    if (H->mode != FB_POSE_FRONT) FB_ARG(H->n_bird[b] >= 0 && H->n_bird[b] <= H->bird_stride);
+  }
   fb_pose_opt_args D = *H;
   const size_t B = H->batch, fs = H->front_stride, bs = H->bird_stride;
 #define UPB(buf, field, bytes)                                                                           \
@@ -451,14 +464,7 @@ int fb_pose_opt(const fb_pose_opt_args *H) {
   fb::DevBuf o1;
   FB_TRY(o1.alloc(B * 4));
   D.ninliers = o1.as<int32_t>();
-  // modes that ignore one edge family still need valid (possibly dummy) pointers
-  fb::DevBuf dummy;
-  FB_TRY(dummy.alloc(64));
-  FB_HIP(hipMemset(dummy.p, 0, 64));
-  if (!D.n_front) D.n_front = dummy.as<int32_t>();
-  if (!D.n_bird) D.n_bird = dummy.as<int32_t>();
-  if (!D.front_outlier) D.front_outlier = dummy.as<uint8_t>();
-  if (!D.bird_outlier) D.bird_outlier = dummy.as<uint8_t>();
+  // the family a mode ignores may be absent altogether: the kernel never dereferences it (n = 0 for that family)
   FB_TRY(fb_pose_opt_batch_dev(&D, nullptr));
   FB_HIP(hipDeviceSynchronize());
   FB_TRY(b11.download(H->Tcw, B * 48));

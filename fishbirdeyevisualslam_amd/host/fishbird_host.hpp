@@ -1,12 +1,13 @@
 // fishbird_host.hpp -- C++ host side above the C-ABI (include/fishbird.h), mirroring the reference's
 // operator interface for the hot path: same class names, argument meaning and return values as
 //   ORBextractor  (include/ORBextractor.h:51-85)
-//   ORBmatcher    (include/ORBmatcher.h:41-88)      SearchByProjection x2, BirdMapPointMatch, BirdviewMatch
+//   ORBmatcher    (include/ORBmatcher.h:41-88)      SearchByProjection x2, SearchByBoW(KF, F), SearchForInitialization,
+//                                                   BirdMapPointMatch, BirdviewMatch
 //   Optimizer     (include/Optimizer.h:40-68)       PoseOptimization, PoseOptimizationWithBird, BirdOptimization,
-//                                                   LocalBundleAdjustment[WithOdom] (flat graph, or KeyFrame*/Map* as
-//                                                   in the reference: fishbird_map.hpp collects the graph),
-//                                                   BundleAdjustmentWithOdom / GlobalBundleAdjustemntWithOdom
-// on plain-old-data frames (the reference's Frame/KeyFrame/MapPoint own OpenCV and graph state that stays in the
+//                                                   LocalBundleAdjustment[WithOdom] on a flattened graph
+// on plain-old-data frames.  The key-frame / map side entry points (Fuse, SearchBySim3, ... and the graph collection of
+// the BA functions) walk KeyFrame / MapPoint / Map objects, which are out of scope: INTEGRATION.md shows
+// the gather -> C-ABI call -> scatter shim a maintainer adds inside the reference's own classes (the reference's Frame/KeyFrame/MapPoint own OpenCV and graph state that stays in the
 // host application).  Header only; link with -lfishbird_hip.  Errors throw std::runtime_error(fb_last_error()).
 #ifndef FISHBIRD_HOST_HPP_
 #define FISHBIRD_HOST_HPP_
@@ -14,14 +15,17 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
-#include <set>
+#include <map>
 #include <stdexcept>
 #include <vector>
 
 #include "../../include/fishbird.h"
-#include "fishbird_map.hpp"
 
 namespace fishbird {
+
+// DBoW2::BowVector / FeatureVector (Thirdparty/DBoW2/DBoW2/BowVector.h:54, FeatureVector.h:22): ordered maps
+typedef std::map<unsigned, double> BowVector;
+typedef std::map<unsigned, std::vector<unsigned>> FeatureVector;
 
 inline void check(int rc) {
   if (rc != FB_OK) throw std::runtime_error(fb_last_error());
@@ -224,9 +228,8 @@ class ORBVocabulary {
       for (int j = nstart[k]; j < nstart[k + 1]; j++) dst.push_back((unsigned)items[j]);
     }
   }
-  // Frame::ComputeBoW / KeyFrame::ComputeBoW (Frame.cc:628-635, KeyFrame.cc:76-86): only when mBowVec is still empty
+  // Frame::ComputeBoW (Frame.cc:628-635): only when mBowVec is still empty
   void ComputeBoW(Frame &F) const { if (F.mBowVec.empty()) transform(F.mDescriptors, F.mBowVec, F.mFeatVec, 4); }
-  void ComputeBoW(KeyFrame &K) const { if (K.mBowVec.empty()) transform(K.mDescriptors, K.mBowVec, K.mFeatVec, 4); }
 };
 
 // ---- ORBmatcher --------------------------------------------------------------------------------------------------
@@ -335,183 +338,21 @@ class ORBmatcher {
     return ninl;
   }
 
-  // ================= key-frame side (LocalMapping / LoopClosing / relocalisation / initialisation) =================
-  // SearchByBoW(pKF, F, vpMapPointMatches), ORBmatcher.cc:160-289
-  int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches) const {
-    const std::vector<MapPoint *> vpMapPointsKF = pKF->GetMapPointMatches();
-    const int32_t NK = pKF->N(), NF = F.N();
-    vpMapPointMatches.assign(NF, nullptr);
+  // SearchByBoW(pKF, F, vpMapPointMatches), ORBmatcher.cc:160-289, on POD frames: KF plays the key frame (its mFeatVec and
+  // key points), kfHasMapPoint[i] = vpMapPointsKF[i] && !isBad().  matchFtoKF[iF] = key-frame feature whose MapPoint lands
+  // in vpMapPointMatches[iF] (-1 = NULL); returns nmatches.
+  int SearchByBoW(const Frame &KF, const std::vector<uint8_t> &kfHasMapPoint, Frame &F, std::vector<int32_t> &matchFtoKF) const {
+    const int32_t NK = KF.N(), NF = F.N();
+    matchFtoKF.assign(NF, -1);
     if (NK == 0 || NF == 0) return 0;
-    std::vector<uint8_t> has(NK);
-    for (int i = 0; i < NK; i++) has[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();
-    FvFlat fk(pKF->mFeatVec), ff(F.mFeatVec);
-    std::vector<int32_t> match(NF, -1);
+    FvFlat fk(KF.mFeatVec), ff(F.mFeatVec);
     int32_t n = 0;
     fb_bow_args a{};
     a.batch = 1; a.kf_stride = NK; a.f_stride = NF;
-    a.n_kf = &NK; a.kf_kps = pKF->mvKeysUn.data(); a.kf_desc = pKF->mDescriptors.data(); a.kf_has_mp = has.data(); a.kf_fv = fk.view();
+    a.n_kf = &NK; a.kf_kps = KF.mvKeysUn.data(); a.kf_desc = KF.mDescriptors.data(); a.kf_has_mp = kfHasMapPoint.data(); a.kf_fv = fk.view();
     a.n_f = &NF; a.f_kps = F.mvKeysUn.data(); a.f_desc = F.mDescriptors.data(); a.f_fv = ff.view();
-    a.matcher = m_; a.match_f_to_kf = match.data(); a.nmatches = &n;
+    a.matcher = m_; a.match_f_to_kf = matchFtoKF.data(); a.nmatches = &n;
     check(fb_match_bow(&a));
-    for (int i = 0; i < NF; i++) if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];
-    return n;
-  }
-
-  // SearchByBoW(pKF1, pKF2, vpMatches12), ORBmatcher.cc:523-656
-  int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12) const {
-    const std::vector<MapPoint *> mp1 = pKF1->GetMapPointMatches(), mp2 = pKF2->GetMapPointMatches();
-    const int32_t N1 = pKF1->N(), N2 = pKF2->N();
-    vpMatches12.assign(N1, nullptr);
-    if (N1 == 0 || N2 == 0) return 0;
-    std::vector<uint8_t> h1(N1), h2(N2);
-    for (int i = 0; i < N1; i++) h1[i] = mp1[i] && !mp1[i]->isBad();
-    for (int i = 0; i < N2; i++) h2[i] = mp2[i] && !mp2[i]->isBad();
-    FvFlat f1(pKF1->mFeatVec), f2(pKF2->mFeatVec);
-    std::vector<int32_t> m12(N1, -1);
-    int32_t n = 0;
-    fb_bow_kf_args a{};
-    a.batch = 1; a.kf1_stride = N1; a.kf2_stride = N2;
-    a.n1 = &N1; a.kps1 = pKF1->mvKeysUn.data(); a.desc1 = pKF1->mDescriptors.data(); a.has_mp1 = h1.data(); a.fv1 = f1.view();
-    a.n2 = &N2; a.kps2 = pKF2->mvKeysUn.data(); a.desc2 = pKF2->mDescriptors.data(); a.has_mp2 = h2.data(); a.fv2 = f2.view();
-    a.matcher = m_; a.matches12 = m12.data(); a.nmatches = &n;
-    check(fb_match_bow_kf(&a));
-    for (int i = 0; i < N1; i++) if (m12[i] >= 0) vpMatches12[i] = mp2[m12[i]];
-    return n;
-  }
-
-  // SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo), ORBmatcher.cc:658-824.  F12 row-major 3x3.
-  int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, const float F12[9], std::vector<std::pair<size_t, size_t>> &vMatchedPairs,
-                             bool bOnlyStereo) const {
-    vMatchedPairs.clear();
-    const int32_t N1 = pKF1->N(), N2 = pKF2->N();
-    if (bOnlyStereo || N1 == 0 || N2 == 0) return 0;  // monocular key frames: every candidate fails the stereo test (:701-703)
-    std::vector<uint8_t> h1(N1), h2(N2);
-    for (int i = 0; i < N1; i++) h1[i] = pKF1->GetMapPoint(i) != nullptr;
-    for (int i = 0; i < N2; i++) h2[i] = pKF2->GetMapPoint(i) != nullptr;
-    FvFlat f1(pKF1->mFeatVec), f2(pKF2->mFeatVec);
-    float R2w[9], t2w[3];
-    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R2w[r * 3 + c] = pKF2->Tcw[r * 4 + c]; t2w[r] = pKF2->Tcw[r * 4 + 3]; }
-    std::vector<int32_t> m12(N1, -1);
-    int32_t n = 0;
-    fb_triangulation_args a{};
-    a.batch = 1; a.kf1_stride = N1; a.kf2_stride = N2;
-    a.n1 = &N1; a.kps1 = pKF1->mvKeysUn.data(); a.desc1 = pKF1->mDescriptors.data(); a.has_mp1 = h1.data(); a.fv1 = f1.view();
-    a.n2 = &N2; a.kps2 = pKF2->mvKeysUn.data(); a.desc2 = pKF2->mDescriptors.data(); a.has_mp2 = h2.data(); a.fv2 = f2.view();
-    a.F12 = F12; a.Cw1 = pKF1->GetCameraCenter(); a.R2w = R2w; a.t2w = t2w;
-    a.fx = pKF2->fx; a.fy = pKF2->fy; a.cx = pKF2->cx; a.cy = pKF2->cy;
-    for (size_t i = 0; i < pKF2->mvScaleFactors.size() && i < FB_MAX_LEVELS; i++) a.scale_factors[i] = pKF2->mvScaleFactors[i];
-    for (size_t i = 0; i < pKF2->mvLevelSigma2.size() && i < FB_MAX_LEVELS; i++) a.level_sigma2[i] = pKF2->mvLevelSigma2[i];
-    a.matcher = m_; a.matches12 = m12.data(); a.nmatches = &n;
-    check(fb_match_triangulation(&a));
-    for (int i = 0; i < N1; i++) if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));
-    return n;
-  }
-
-  // Fuse(pKF, vpMapPoints, th), ORBmatcher.cc:826-976: batched search, then the map mutation in list order
-  int Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, float th = 3.f) const {
-    const int32_t nMPs = (int32_t)vpMapPoints.size();
-    if (nMPs == 0 || pKF->N() == 0) return 0;
-    KfFlat kf(pKF);
-    MpFlat mp(vpMapPoints, [&](MapPoint *p) { return p && !p->isBad() && !p->IsInKeyFrame(pKF); });
-    std::vector<int32_t> best(nMPs, -1);
-    fb_fuse_args a{};
-    a.batch = 1; a.kf = kf.t; a.mp = mp.view(); a.pose = pKF->Tcw; a.Ow = pKF->GetCameraCenter(); a.th = th; a.best_idx = best.data();
-    check(fb_fuse_search(&a));
-    int nFused = 0;
-    for (int i = 0; i < nMPs; i++) {
-      MapPoint *pMP = vpMapPoints[i];
-      // re-evaluated in order: an earlier Replace / AddObservation of this loop can have changed it (:846-850)
-      if (!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF) || best[i] < 0) continue;
-      MapPoint *pMPinKF = pKF->GetMapPoint(best[i]);
-      if (pMPinKF) {
-        if (!pMPinKF->isBad()) {
-          if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
-          else pMPinKF->Replace(pMP);
-        }
-      } else {
-        pMP->AddObservation(pKF, best[i]);
-        pKF->AddMapPoint(pMP, best[i]);
-      }
-      nFused++;
-    }
-    return nFused;
-  }
-
-  // Fuse(pKF, Scw, vpPoints, th, vpReplacePoint), ORBmatcher.cc:978-1101.  Scw = rows 0..2 of the 4x4.
-  int Fuse(KeyFrame *pKF, const float Scw[12], const std::vector<MapPoint *> &vpPoints, float th,
-           std::vector<MapPoint *> &vpReplacePoint) const {
-    const int32_t nPoints = (int32_t)vpPoints.size();
-    if (nPoints == 0 || pKF->N() == 0) return 0;
-    const std::set<MapPoint *> spAlreadyFound = pKF->GetMapPoints();
-    KfFlat kf(pKF);
-    MpFlat mp(vpPoints, [&](MapPoint *p) { return p && !p->isBad() && !spAlreadyFound.count(p); });
-    std::vector<int32_t> best(nPoints, -1);
-    fb_fuse_args a{};
-    a.batch = 1; a.kf = kf.t; a.mp = mp.view(); a.pose = Scw; a.Ow = nullptr; a.th = th; a.best_idx = best.data();
-    check(fb_fuse_sim3_search(&a));
-    int nFused = 0;
-    for (int i = 0; i < nPoints; i++) {
-      if (best[i] < 0) continue;
-      MapPoint *pMP = vpPoints[i];
-      MapPoint *pMPinKF = pKF->GetMapPoint(best[i]);
-      if (pMPinKF) {
-        if (!pMPinKF->isBad()) vpReplacePoint[i] = pMPinKF;
-      } else {
-        pMP->AddObservation(pKF, best[i]);
-        pKF->AddMapPoint(pMP, best[i]);
-      }
-      nFused++;
-    }
-    return nFused;
-  }
-
-  // SearchByProjection(pKF, Scw, vpPoints, vpMatched, th), ORBmatcher.cc:291-404
-  int SearchByProjection(KeyFrame *pKF, const float Scw[12], const std::vector<MapPoint *> &vpPoints, std::vector<MapPoint *> &vpMatched,
-                         int th) const {
-    const int32_t N = pKF->N();
-    if (vpPoints.empty() || N == 0) return 0;
-    std::set<MapPoint *> spAlreadyFound(vpMatched.begin(), vpMatched.end());
-    spAlreadyFound.erase(nullptr);
-    KfFlat kf(pKF);
-    MpFlat mp(vpPoints, [&](MapPoint *p) { return p && !p->isBad() && !spAlreadyFound.count(p); });
-    std::vector<uint8_t> matched(N);
-    for (int i = 0; i < N; i++) matched[i] = vpMatched[i] != nullptr;
-    std::vector<int32_t> out(N, -1);
-    int32_t n = 0;
-    fb_proj_sim3_args a{};
-    a.batch = 1; a.kf = kf.t; a.mp = mp.view(); a.Scw = Scw; a.kf_matched = matched.data(); a.th = th;
-    a.match_kf_to_mp = out.data(); a.nmatches = &n;
-    check(fb_match_projection_sim3(&a));
-    for (int i = 0; i < N; i++) if (out[i] >= 0) vpMatched[i] = vpPoints[out[i]];
-    return n;
-  }
-
-  // SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th), ORBmatcher.cc:1103-1327.  R12 row-major 3x3.
-  int SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12, float s12, const float R12[9],
-                   const float t12[3], float th) const {
-    const std::vector<MapPoint *> vp1 = pKF1->GetMapPointMatches(), vp2 = pKF2->GetMapPointMatches();
-    const int N1 = (int)vp1.size(), N2 = (int)vp2.size();
-    if (N1 == 0 || N2 == 0) return 0;
-    std::vector<bool> am1(N1, false), am2(N2, false);
-    for (int i = 0; i < N1; i++) {
-      MapPoint *pMP = vpMatches12[i];
-      if (!pMP) continue;
-      am1[i] = true;
-      const int idx2 = pMP->GetIndexInKeyFrame(pKF2);
-      if (idx2 >= 0 && idx2 < N2) am2[idx2] = true;
-    }
-    KfFlat k1(pKF1), k2(pKF2);
-    int i1 = 0, i2 = 0;
-    MpFlat m1(vp1, [&](MapPoint *p) { const bool ok = p && !am1[i1] && !p->isBad(); i1++; return ok; });
-    MpFlat m2(vp2, [&](MapPoint *p) { const bool ok = p && !am2[i2] && !p->isBad(); i2++; return ok; });
-    std::vector<int32_t> m12(N1, -1);
-    int32_t n = 0;
-    fb_sim3_args a{};
-    a.batch = 1; a.kf1 = k1.t; a.kf2 = k2.t; a.mp1 = m1.view(); a.mp2 = m2.view();
-    a.T1w = pKF1->Tcw; a.T2w = pKF2->Tcw; a.s12 = &s12; a.R12 = R12; a.t12 = t12; a.th = th;
-    a.matches12 = m12.data(); a.nfound = &n;
-    check(fb_match_sim3(&a));
-    for (int i = 0; i < N1; i++) if (m12[i] >= 0) vpMatches12[i] = vp2[m12[i]];
     return n;
   }
 
@@ -533,45 +374,6 @@ class ORBmatcher {
     a.prev_matched = vbPrevMatched.data(); a.matches12 = m12.data(); a.nmatches = &n;
     check(fb_match_initialization(&a));
     for (int i = 0; i < N1; i++) vnMatches12[i] = m12[i];
-    return n;
-  }
-
-  // SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist), ORBmatcher.cc:1473-1600 (relocalisation).
-  // curMapPoints plays CurrentFrame.mvpMapPoints (pointer form).
-  int SearchByProjection(Frame &CurrentFrame, std::vector<MapPoint *> &curMapPoints, KeyFrame *pKF,
-                         const std::set<MapPoint *> &sAlreadyFound, float th, int ORBdist) const {
-    const std::vector<MapPoint *> vpMPs = pKF->GetMapPointMatches();
-    const int32_t N = CurrentFrame.N(), NK = (int32_t)vpMPs.size();
-    if (N == 0 || NK == 0) return 0;
-    std::vector<uint8_t> blocked(N), valid(NK), desc((size_t)NK * 32);
-    std::vector<float> xw((size_t)NK * 3), mx(NK), mn(NK), ang(NK);
-    for (int i = 0; i < N; i++) blocked[i] = curMapPoints[i] != nullptr;
-    for (int i = 0; i < NK; i++) {
-      MapPoint *p = vpMPs[i];
-      valid[i] = p && !p->isBad() && !sAlreadyFound.count(p);
-      ang[i] = pKF->mvKeysUn[i].angle;
-      if (!p) continue;
-      std::memcpy(&xw[3 * (size_t)i], p->mWorldPos, 12);
-      std::memcpy(&desc[32 * (size_t)i], p->mDescriptor, 32);
-      mx[i] = p->mfMaxDistance; mn[i] = p->mfMinDistance;
-    }
-    std::vector<int32_t> match(N, -1);
-    int32_t n = 0;
-    fb_proj_kf_args a{};
-    a.batch = 1; a.cur_stride = N; a.kf_stride = NK;
-    a.n_cur = &N; a.cur_kps = CurrentFrame.mvKeysUn.data(); a.cur_desc = CurrentFrame.mDescriptors.data();
-    a.cur_cell_start = CurrentFrame.gridStart.data(); a.cur_cell_items = CurrentFrame.gridItems.data(); a.cur_blocked = blocked.data();
-    a.cur_Tcw = CurrentFrame.mTcw; a.n_kf = &NK; a.kf_valid = valid.data(); a.kf_xw = xw.data(); a.kf_desc = desc.data();
-    a.kf_max_dist = mx.data(); a.kf_min_dist = mn.data(); a.kf_angle = ang.data();
-    a.cam = {CurrentFrame.fx, CurrentFrame.fy, CurrentFrame.cx, CurrentFrame.cy, CurrentFrame.mnMinX, CurrentFrame.mnMinY,
-             CurrentFrame.mnMaxX, CurrentFrame.mnMaxY};
-    a.grid = CurrentFrame.frontGrid();
-    for (size_t i = 0; i < CurrentFrame.mvScaleFactors.size() && i < FB_MAX_LEVELS; i++) a.scale_factors[i] = CurrentFrame.mvScaleFactors[i];
-    a.log_scale_factor = CurrentFrame.mvScaleFactors.size() > 1 ? std::log(CurrentFrame.mvScaleFactors[1]) : 1.f;
-    a.n_levels = (int32_t)CurrentFrame.mvScaleFactors.size();
-    a.th = th; a.orb_dist = ORBdist; a.matcher = m_; a.match_cur_to_kf = match.data(); a.nmatches = &n;
-    check(fb_match_projection_keyframe(&a));
-    for (int i = 0; i < N; i++) if (match[i] >= 0) curMapPoints[i] = vpMPs[match[i]];
     return n;
   }
 
@@ -616,43 +418,6 @@ class ORBmatcher {
     }
     fb_feature_vector view() const { return {(int32_t)ids.size(), (int32_t)items.size(), &n, ids.data(), start.data(), items.data()}; }
   };
-  struct KfFlat {
-    int32_t n;
-    fb_kf_target t;
-    explicit KfFlat(KeyFrame *pKF) : n(pKF->N()) {
-      std::memset(&t, 0, sizeof(t));
-      if (pKF->gridStart.empty()) pKF->AssignFeaturesToGrid();
-      t.kf_stride = n; t.n_kf = &n; t.kf_kps = pKF->mvKeysUn.data(); t.kf_desc = pKF->mDescriptors.data();
-      t.kf_cell_start = pKF->gridStart.data(); t.kf_cell_items = pKF->gridItems.data();
-      t.cam = pKF->camera(); t.grid = pKF->gridGeom();
-      for (size_t i = 0; i < pKF->mvScaleFactors.size() && i < FB_MAX_LEVELS; i++) t.scale_factors[i] = pKF->mvScaleFactors[i];
-      for (size_t i = 0; i < pKF->mvInvLevelSigma2.size() && i < FB_MAX_LEVELS; i++) t.inv_level_sigma2[i] = pKF->mvInvLevelSigma2[i];
-      t.log_scale_factor = pKF->mfLogScaleFactor; t.n_levels = pKF->mnScaleLevels;
-    }
-    KfFlat(const KfFlat &) = delete;
-  };
-  struct MpFlat {
-    int32_t n;
-    std::vector<uint8_t> valid, desc;
-    std::vector<float> xw, normal, mx, mn;
-    template <typename Pred> MpFlat(const std::vector<MapPoint *> &v, Pred ok) : n((int32_t)v.size()) {
-      const size_t m = v.empty() ? 1 : v.size();
-      valid.assign(m, 0); desc.assign(m * 32, 0); xw.assign(m * 3, 0.f); normal.assign(m * 3, 0.f); mx.assign(m, 0.f); mn.assign(m, 0.f);
-      for (size_t i = 0; i < v.size(); i++) {
-        MapPoint *p = v[i];
-        valid[i] = ok(p) ? 1 : 0;
-        if (!p) continue;
-        std::memcpy(&xw[3 * i], p->mWorldPos, 12);
-        std::memcpy(&normal[3 * i], p->mNormalVector, 12);
-        std::memcpy(&desc[32 * i], p->mDescriptor, 32);
-        mx[i] = p->mfMaxDistance; mn[i] = p->mfMinDistance;
-      }
-    }
-    MpFlat(const MpFlat &) = delete;
-    fb_mp_list view() const {
-      return {(int32_t)valid.size(), &n, valid.data(), xw.data(), normal.data(), mx.data(), mn.data(), desc.data()};
-    }
-  };
 
   fb_matcher_params m_;
 };
@@ -685,81 +450,6 @@ class Optimizer {
     check(fb_local_ba(&graph));
   }
 
-  // ---- the reference signatures on the map stand-ins of fishbird_map.hpp --------------------------------------------
-  // LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap), Optimizer.cc:838-1165
-  static void LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map * /*pMap*/) {
-    BAGraph G;
-    collectLocalGraph(pKF, false, G);
-    if (pbStopFlag && *pbStopFlag) return;  // :1042-1044
-    fb_local_ba_args a = G.args(pKF, 0, 1.f, 1.f, 3.f, pbStopFlag);
-    check(fb_local_ba(&a));
-    writeBackLocal(G, false);
-  }
-  // LocalBundleAdjustmentWithOdom(pKF, pbStopFlag, pMap, wF, wB, wP), Optimizer.cc:2137-2670
-  static void LocalBundleAdjustmentWithOdom(KeyFrame *pKF, bool *pbStopFlag, Map * /*pMap*/, float wF = 1.f, float wB = 1.f,
-                                            float wP = 3.f) {
-    BAGraph G;
-    collectLocalGraph(pKF, switches().bHaveBird, G);
-    if (switches().bTightCouple) G.addOdometryChain(wP);
-    if (pbStopFlag && *pbStopFlag) return;  // :2497-2499
-    fb_local_ba_args a = G.args(pKF, 1, wF, wB, wP, pbStopFlag);
-    check(fb_local_ba(&a));
-    writeBackLocal(G, switches().bHaveBird);
-  }
-  // BundleAdjustmentWithOdom(vpKFs, vpMP, vpMPB, nIterations, pbStopFlag, nLoopKF, bRobust, wF, wB, wP), Optimizer.cc:1787-2135
-  static void BundleAdjustmentWithOdom(const std::vector<KeyFrame *> &vpKFs, const std::vector<MapPoint *> &vpMP,
-                                       const std::vector<MapPointBird *> &vpMPB, int nIterations = 5, bool *pbStopFlag = nullptr,
-                                       unsigned long nLoopKF = 0, bool bRobust = true, float wF = 1.f, float wB = 1.f,
-                                       float wP = 3.f) {
-    BAGraph G;
-    long maxKFid = 0;
-    const KeyFrame *first = nullptr;
-    for (size_t i = 0; i < vpKFs.size(); i++) {
-      KeyFrame *pKF = vpKFs[i];
-      if (pKF->isBad()) continue;
-      G.addKeyFrame(pKF, pKF->mnId == 0);
-      if (!first) first = pKF;
-      if ((long)pKF->mnId > maxKFid) maxKFid = (long)pKF->mnId;
-    }
-    G.nLocal = G.kfs.size();
-    if (!first) return;
-    std::vector<bool> vbNotIncludedMP(vpMP.size(), true), vbNotIncludedMPBird(vpMPB.size(), true);
-    for (size_t i = 0; i < vpMP.size(); i++) {
-      if (vpMP[i]->isBad()) continue;
-      if (G.addMapPoint(vpMP[i], maxKFid) == 0) G.popMapPoint();
-      else vbNotIncludedMP[i] = false;
-    }
-    if (switches().bHaveBird)
-      for (size_t i = 0; i < vpMPB.size(); i++) {
-        if (vpMPB[i]->isBad()) continue;
-        if (G.addMapPointBird(vpMPB[i]) == 0) G.popMapPointBird();
-        else vbNotIncludedMPBird[i] = false;
-      }
-    fb_local_ba_args a = G.args(first, 1, wF, wB, wP, pbStopFlag);
-    check(fb_global_ba(&a, nIterations, bRobust ? 1 : 0));
-    for (size_t k = 0; k < G.kfs.size(); k++) {
-      KeyFrame *pKF = G.kfs[k];
-      if (nLoopKF == 0) pKF->SetPose(&G.kfTcw[12 * k]);
-      else { std::memcpy(pKF->mTcwGBA, &G.kfTcw[12 * k], 48); pKF->mnBAGlobalForKF = nLoopKF; }
-    }
-    for (size_t j = 0; j < G.mps.size(); j++) {
-      MapPoint *pMP = G.mps[j];
-      if (nLoopKF == 0) { pMP->SetWorldPos(&G.mpXw[3 * j]); pMP->UpdateNormalAndDepth(); }
-      else { std::memcpy(pMP->mPosGBA, &G.mpXw[3 * j], 12); pMP->mnBAGlobalForKF = nLoopKF; }
-    }
-    for (size_t j = 0; j < G.mpbs.size(); j++) {
-      MapPointBird *pMPB = G.mpbs[j];
-      if (nLoopKF == 0) pMPB->SetWorldPos(&G.mpbXw[3 * j]);
-      else { std::memcpy(pMPB->mPosGBA, &G.mpbXw[3 * j], 12); pMPB->mnBAGlobalForKF = nLoopKF; }
-    }
-  }
-  // GlobalBundleAdjustemntWithOdom(pMap, nIterations, pbStopFlag, nLoopKF, bRobust), Optimizer.cc:1778-1785 (sic)
-  static void GlobalBundleAdjustemntWithOdom(Map *pMap, int nIterations = 5, bool *pbStopFlag = nullptr,
-                                             unsigned long nLoopKF = 0, bool bRobust = true) {
-    BundleAdjustmentWithOdom(pMap->GetAllKeyFrames(), pMap->GetAllMapPoints(), pMap->GetAllMapPointsBird(), nIterations,
-                             pbStopFlag, nLoopKF, bRobust);
-  }
-
  private:
   static int run(Frame *f, int mode, const std::vector<MapPointRef> &points, const std::vector<MapPointRef> &birdPoints,
                  float wB, float wF) {
@@ -777,16 +467,20 @@ class Optimizer {
       std::memcpy(&bxw[3 * i], birdPoints[i].Xw, 12);
       binf[i] = f->mvInvLevelSigma2[f->mvKeysBird[i].octave];
     }
-    f->mvbOutlier.resize(N + (N == 0), 0);
-    f->mvBirdOutlier.resize(NB + (NB == 0), 0);
+    // only the edge family the mode optimises is (re)sized: BirdOptimization (Optimizer.cc:708-835) never touches
+    // mvbOutlier, PoseOptimization (:246-475) never touches mvBirdOutlier, and Tracking indexes both right after
+    if (mode != FB_POSE_BIRD) f->mvbOutlier.resize(N, 0);
+    if (mode != FB_POSE_FRONT) f->mvBirdOutlier.resize(NB, 0);
+    uint8_t unusedFamily[4] = {0, 0, 0, 0};
     fb_pose_opt_args a{};
     a.batch = 1; a.mode = mode; a.front_stride = N; a.bird_stride = NB;
     a.fx = f->fx; a.fy = f->fy; a.cx = f->cx; a.cy = f->cy; a.wF = wF; a.wB = wB;
     a.n_front = &N; a.front_xw = fxw.data(); a.front_obs = fobs.data(); a.front_inv_sigma2 = finf.data();
     a.front_valid = fvalid.data();
     a.n_bird = &NB; a.bird_xw = bxw.data(); a.bird_xc = f->mvKeysBirdCamXYZ.empty() ? bxw.data() : f->mvKeysBirdCamXYZ.data();
-    a.bird_inv_sigma2 = binf.data(); a.bird_valid = bvalid.data(); a.bird_outlier = f->mvBirdOutlier.data();
-    a.Tcw = f->mTcw; a.front_outlier = f->mvbOutlier.data();
+    a.bird_inv_sigma2 = binf.data(); a.bird_valid = bvalid.data();
+    a.bird_outlier = (mode == FB_POSE_FRONT || NB == 0) ? unusedFamily : f->mvBirdOutlier.data();
+    a.Tcw = f->mTcw; a.front_outlier = (mode == FB_POSE_BIRD || N == 0) ? unusedFamily : f->mvbOutlier.data();
     int32_t ninl = 0;
     a.ninliers = &ninl;
     check(fb_pose_opt(&a));

@@ -50,6 +50,34 @@ int main(int argc, char **argv) {
     }
     F.mTcw[3] = 0.02f;  // perturb tx; the optimiser must bring it back
     const int ninl = fishbird::Optimizer::PoseOptimization(&F, framePts);
+    // BirdOptimization must leave mvbOutlier alone and PoseOptimization must leave mvBirdOutlier alone (Optimizer.cc:708-835
+    // never touches the front flags; Tracking.cc indexes mvbOutlier[i] for all i < N right after either call)
+    int sizesOk = 0, birdInl = 0;
+    {
+      const int NB = 60;
+      F.mvKeysBird.resize(NB);
+      F.mvKeysBirdCamXYZ.resize((size_t)NB * 3);
+      std::vector<fishbird::MapPointRef> birdPts(NB);
+      for (int i = 0; i < NB; i++) {
+        F.mvKeysBird[i] = fb_keypoint{(float)(20 + 7 * i), (float)(30 + 5 * i), 31.f, 0.f, 20.f, i % 3};
+        birdPts[i].valid = true;
+        birdPts[i].Xw[0] = -3.f + 0.1f * i; birdPts[i].Xw[1] = 1.5f; birdPts[i].Xw[2] = 2.f + 0.05f * i;
+        for (int r = 0; r < 3; r++)
+          F.mvKeysBirdCamXYZ[3 * (size_t)i + r] = F.mTcw[r * 4] * birdPts[i].Xw[0] + F.mTcw[r * 4 + 1] * birdPts[i].Xw[1] +
+                                                  F.mTcw[r * 4 + 2] * birdPts[i].Xw[2] + F.mTcw[r * 4 + 3];
+      }
+      F.mvpMapPointsBird.assign(NB, 0);
+      const std::vector<uint8_t> frontBefore = F.mvbOutlier;
+      F.mvBirdOutlier.assign(NB, 0);
+      birdInl = fishbird::Optimizer::BirdOptimization(&F, birdPts);
+      const bool a = (int)F.mvbOutlier.size() == N && F.mvbOutlier == frontBefore && (int)F.mvBirdOutlier.size() == NB;
+      F.mvBirdOutlier[3] = 1;  // a marker PoseOptimization must not disturb
+      const std::vector<uint8_t> birdBefore = F.mvBirdOutlier;
+      fishbird::Optimizer::PoseOptimization(&F, framePts);
+      const bool b = (int)F.mvBirdOutlier.size() == NB && F.mvBirdOutlier == birdBefore && (int)F.mvbOutlier.size() == N;
+      sizesOk = a && b;
+    }
+    std::printf("sizes_ok=%d bird_inliers=%d\n", sizesOk, birdInl);
     // TrackLocalMap: Frame::isInFrustum over the "local map" (the same points), then SearchByProjection(F, points, th)
     std::vector<fishbird::LocalMapPoint> local(N);
     const std::vector<float> sf = orb.GetScaleFactors();

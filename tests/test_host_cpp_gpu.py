@@ -47,6 +47,8 @@ def test_host_mirror_end_to_end():
     assert d00 == 0
     assert nmatches > 0.9 * N and self_ > 0.9 * nmatches      # a frame matched against itself
     assert inl > 0.9 * nmatches and abs(tx) < 2e-3            # the 2 cm perturbation is optimised away
+    ms = re.search(r"sizes_ok=(\d+) bird_inliers=(\d+)", out)
+    assert ms and int(ms[1]) == 1 and int(ms[2]) == 60, out   # outlier vectors keep their sizes and contents across modes
     m2 = re.search(r"inview=(\d+) local=(\d+) selflocal=(\d+)", out)
     assert m2, out
     in_view, n_local, self_local = int(m2[1]), int(m2[2]), int(m2[3])
