@@ -4,8 +4,8 @@
  * sides are compiled with -ffp-contract=off, so every function here is a pure
  * function of its input bits.
  *
- * The same text lives in oracle/ (CPU restatement, test infrastructure) and in
- * fishbirdeyevisualslam_amd/csrc/ (product); neither includes the other.
+ * Product copy.  The oracle has its OWN, independently written oracle/fb_detmath.h (libm in double rounded to float,
+ * OpenCV's integer rounding formulas): the two can disagree, and tests/test_detmath_independent.py compares them.
  *
  * OpenCV semantics restated here (OpenCV is NOT vendored in the reference, so this
  * is "parity unpinned" -- see DESIGN.md):

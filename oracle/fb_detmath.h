@@ -1,22 +1,23 @@
 /*
- * fb_detmath.h -- scalar helpers whose results must be bit-identical on the host
- * (gcc) and on gfx950 (hipcc).  Only IEEE +,-,*,/ and rint/floor are used and both
- * sides are compiled with -ffp-contract=off, so every function here is a pure
- * function of its input bits.
+ * oracle/fb_detmath.h -- the ORACLE's own statement of the scalar OpenCV / libm semantics on the hot path.
+ * TEST INFRASTRUCTURE.  Written independently of fishbirdeyevisualslam_amd/csrc/fb_detmath.h (the product's
+ * bit-reproducible kernels): different formulations on purpose, so that an error in either shows up as a parity
+ * failure instead of hiding in shared text.  tests/test_detmath_independent.py compiles both into one program and
+ * compares them densely (exhaustively for sin/cos over [0, 2 pi]).
  *
- * The same text lives in oracle/ (CPU restatement, test infrastructure) and in
- * fishbirdeyevisualslam_amd/csrc/ (product); neither includes the other.
- *
- * OpenCV semantics restated here (OpenCV is NOT vendored in the reference, so this
- * is "parity unpinned" -- see DESIGN.md):
- *   cvRound      -> round half to even          (call sites ORBextractor.cc:81,119-120,442,460,1112)
- *   cv::fastAtan2-> 7th-order odd polynomial, degrees (call site ORBextractor.cc:103)
- *   cos/sin      -> ORBextractor.cc:112-113 calls libm cosf/sinf; restated as a
- *                   double-precision polynomial rounded to float (correctly rounded
- *                   in all but ~1e-8 of cases; deterministic on both sides).
+ *   cvRound / cvFloor / cvCeil  OpenCV's own formulas: lrint (current rounding mode = nearest-even) and the
+ *                               "truncate, then correct" integer forms (call sites ORBextractor.cc:81,119-120,442,460,1112)
+ *   cv::fastAtan2               the published polynomial with its decimal coefficients times (float)(180/CV_PI)
+ *                               (call site ORBextractor.cc:103)
+ *   cosf / sinf / logf / tan    what the reference actually calls is libm (ORBextractor.cc:112-113, MapPoint.cc:393,410,
+ *                               cv::fisheye::undistortPoints): here the DOUBLE libm function rounded once to float -- correctly
+ *                               rounded except where the double result lies within ~1e-16 relative of a float rounding
+ *                               boundary.  The product uses its own polynomial kernels; the two agree on every float angle in
+ *                               [0, 2 pi] (exhaustive run recorded in DESIGN.md section 2).
+ * OpenCV is not vendored in the reference: all of this is "parity unpinned" (DESIGN.md section 2).
  */
-#ifndef FB_DETMATH_H_
-#define FB_DETMATH_H_
+#ifndef FB_ORACLE_DETMATH_H_
+#define FB_ORACLE_DETMATH_H_
 
 #ifndef FB_HD
 #define FB_HD
@@ -24,27 +25,24 @@
 
 #include <math.h>
 
-FB_HD static inline int fb_cvround(float v) { return (int)rintf(v); }
-FB_HD static inline int fb_cvround_d(double v) { return (int)rint(v); }
-FB_HD static inline int fb_cvfloor(float v) { return (int)floorf(v); }
-FB_HD static inline int fb_cvceil(float v) { return (int)ceilf(v); }
+FB_HD static inline int fb_cvround(float v) { return (int)lrintf(v); }
+FB_HD static inline int fb_cvround_d(double v) { return (int)lrint(v); }
+FB_HD static inline int fb_cvfloor(float v) { const int i = (int)v; return i - (i > v); }
+FB_HD static inline int fb_cvceil(float v) { const int i = (int)v; return i + (i < v); }
 
-/* cv::fastAtan2(y, x) in degrees, [0,360) */
+/* cv::fastAtan2(y, x), degrees in [0, 360) */
 FB_HD static inline float fb_fast_atan2(float y, float x) {
-  const float p1 = 0x1.ca44dep+5f;  /* 0.9997878412794807f*(float)(180/CV_PI) */
-  const float p3 = -0x1.2aaddcp+4f; /* -0.3258083974640975f*... */
-  const float p5 = 0x1.1d3f7ep+3f;  /* 0.1555786518463281f*... */
-  const float p7 = -0x1.4515b2p+1f; /* -0.04432655554792128f*... */
-  const float eps = 0x1p-52f;       /* (float)DBL_EPSILON */
-  float ax = fabsf(x), ay = fabsf(y);
-  float a, c, c2;
+  const float deg = (float)(180.0 / 3.1415926535897932384626433832795);
+  const float p1 = 0.9997878412794807f * deg, p3 = -0.3258083974640975f * deg;
+  const float p5 = 0.1555786518463281f * deg, p7 = -0.04432655554792128f * deg;
+  const float tiny = (float)2.2204460492503131e-16; /* (float)DBL_EPSILON */
+  const float ax = x < 0 ? -x : x, ay = y < 0 ? -y : y;
+  float a;
   if (ax >= ay) {
-    c = ay / (ax + eps);
-    c2 = c * c;
+    const float c = ay / (ax + tiny), c2 = c * c;
     a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
   } else {
-    c = ax / (ay + eps);
-    c2 = c * c;
+    const float c = ax / (ay + tiny), c2 = c * c;
     a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
   }
   if (x < 0) a = 180.f - a;
@@ -52,130 +50,36 @@ FB_HD static inline float fb_fast_atan2(float y, float x) {
   return a;
 }
 
-/* sin and cos of a float angle in radians (|x| < ~10), computed in double with
- * plain mul/add only, rounded to float. */
-FB_HD static inline void fb_sincos_f(float xf, float *s_out, float *c_out) {
-  const double x = (double)xf;
-  const double two_over_pi = 0x1.45f306dc9c883p-1;
-  const double pio2_hi = 0x1.921fb54442d18p+0;
-  const double pio2_lo = 0x1.1a62633145c07p-54;
-  const double kd = rint(x * two_over_pi);
-  const int k = (int)kd;
-  double r = x - kd * pio2_hi;
-  r = r - kd * pio2_lo;
-  const double r2 = r * r;
-  /* Taylor, |r| <= pi/4 (+tiny): sin to r^17, cos to r^18 */
-  double ps = -1.0 / 355687428096000.0;            /* -1/17! */
-  ps = ps * r2 + 1.0 / 1307674368000.0;            /* 1/15! */
-  ps = ps * r2 - 1.0 / 6227020800.0;               /* -1/13! */
-  ps = ps * r2 + 1.0 / 39916800.0;                 /* 1/11! */
-  ps = ps * r2 - 1.0 / 362880.0;                   /* -1/9! */
-  ps = ps * r2 + 1.0 / 5040.0;                     /* 1/7! */
-  ps = ps * r2 - 1.0 / 120.0;                      /* -1/5! */
-  ps = ps * r2 + 1.0 / 6.0;                        /* 1/3!, sign folded below */
-  const double sr = r - (r * r2) * ps;
-  double pc = 1.0 / 6402373705728000.0;            /* 1/18! */
-  pc = pc * r2 - 1.0 / 20922789888000.0;           /* -1/16! */
-  pc = pc * r2 + 1.0 / 87178291200.0;              /* 1/14! */
-  pc = pc * r2 - 1.0 / 479001600.0;                /* -1/12! */
-  pc = pc * r2 + 1.0 / 3628800.0;                  /* 1/10! */
-  pc = pc * r2 - 1.0 / 40320.0;                    /* -1/8! */
-  pc = pc * r2 + 1.0 / 720.0;                      /* 1/6! */
-  pc = pc * r2 - 1.0 / 24.0;                       /* -1/4! */
-  pc = pc * r2 + 0.5;                              /* 1/2! */
-  const double cr = 1.0 - r2 * pc;
-  double s, c;
-  switch (k & 3) {
-    case 0: s = sr; c = cr; break;
-    case 1: s = cr; c = -sr; break;
-    case 2: s = -sr; c = -cr; break;
-    default: s = -cr; c = sr; break;
-  }
-  *s_out = (float)s;
-  *c_out = (float)c;
+FB_HD static inline void fb_sincos_f(float x, float *s_out, float *c_out) {
+  *s_out = (float)sin((double)x);
+  *c_out = (float)cos((double)x);
 }
 
-/* natural logarithm of a positive finite float, computed in double with +,-,*,/ only and rounded to float
- * (MapPoint::PredictScale calls libm logf, MapPoint.cc:393,410; restated like fb_sincos_f so that the CPU and the
- * GPU agree on every bit).  x = m * 2^e, m in [sqrt(1/2), sqrt(2)): ln x = e ln2 + 2 atanh((m-1)/(m+1)). */
-FB_HD static inline float fb_log_f(float xf) {
-  double x = (double)xf;
-  int e = 0;
-  /* exact scaling by powers of two */
-  for (int it = 0; it < 400 && x >= 1.4142135623730951; it++) { x *= 0.5; e++; }
-  for (int it = 0; it < 400 && x < 0.7071067811865476; it++) { x *= 2.0; e--; }
-  const double z = (x - 1.0) / (x + 1.0), z2 = z * z;
-  double p = 1.0 / 23.0;
-  p = p * z2 + 1.0 / 21.0;
-  p = p * z2 + 1.0 / 19.0;
-  p = p * z2 + 1.0 / 17.0;
-  p = p * z2 + 1.0 / 15.0;
-  p = p * z2 + 1.0 / 13.0;
-  p = p * z2 + 1.0 / 11.0;
-  p = p * z2 + 1.0 / 9.0;
-  p = p * z2 + 1.0 / 7.0;
-  p = p * z2 + 1.0 / 5.0;
-  p = p * z2 + 1.0 / 3.0;
-  p = p * z2 + 1.0;
-  const double ln2_hi = 0x1.62e42fefa39efp-1;
-  return (float)((double)e * ln2_hi + 2.0 * z * p);
-}
+FB_HD static inline float fb_log_f(float x) { return (float)log((double)x); }
 
-/* tan of a double in (-pi/2, pi/2) from the deterministic sin/cos kernels above (cv::fisheye::undistortPoints
- * calls std::tan); only used through fb_fisheye_undistort. */
-FB_HD static inline double fb_tan_d(double x) {
-  /* reduce with the same scheme as fb_sincos_f but keep doubles */
-  const double two_over_pi = 0x1.45f306dc9c883p-1;
-  const double pio2_hi = 0x1.921fb54442d18p+0;
-  const double pio2_lo = 0x1.1a62633145c07p-54;
-  const double kd = rint(x * two_over_pi);
-  const int k = (int)kd;
-  double r = x - kd * pio2_hi;
-  r = r - kd * pio2_lo;
-  const double r2 = r * r;
-  double ps = -1.0 / 355687428096000.0;
-  ps = ps * r2 + 1.0 / 1307674368000.0;
-  ps = ps * r2 - 1.0 / 6227020800.0;
-  ps = ps * r2 + 1.0 / 39916800.0;
-  ps = ps * r2 - 1.0 / 362880.0;
-  ps = ps * r2 + 1.0 / 5040.0;
-  ps = ps * r2 - 1.0 / 120.0;
-  ps = ps * r2 + 1.0 / 6.0;
-  const double sr = r - (r * r2) * ps;
-  double pc = 1.0 / 6402373705728000.0;
-  pc = pc * r2 - 1.0 / 20922789888000.0;
-  pc = pc * r2 + 1.0 / 87178291200.0;
-  pc = pc * r2 - 1.0 / 479001600.0;
-  pc = pc * r2 + 1.0 / 3628800.0;
-  pc = pc * r2 - 1.0 / 40320.0;
-  pc = pc * r2 + 1.0 / 720.0;
-  pc = pc * r2 - 1.0 / 24.0;
-  pc = pc * r2 + 0.5;
-  const double cr = 1.0 - r2 * pc;
-  return (k & 1) ? -cr / sr : sr / cr;
-}
+FB_HD static inline double fb_tan_d(double x) { return tan(x); }
 
-/* cv::fisheye::undistortPoints(src, dst, K, D, R = I, P = K) for one point, OpenCV 3.0-3.3 semantics
- * (10 fixed-point iterations), call sites Frame.cc:657,754.  K = (fx, fy, cx, cy) and D = k1..k4 as float. */
+/* cv::fisheye::undistortPoints(src, dst, K, D, R = I, P = K), one point, OpenCV 3.0-3.3: ten fixed-point iterations of
+ * theta <- theta_d / (1 + k1 theta^2 + k2 theta^4 + k3 theta^6 + k4 theta^8) (call sites Frame.cc:657,754). */
 FB_HD static inline void fb_fisheye_undistort(float px, float py, const float K4[4], const float D4[4], float *ox, float *oy) {
-  const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
-  const double k0 = D4[0], k1 = D4[1], k2 = D4[2], k3 = D4[3];
-  const double pwx = ((double)px - cx) / fx, pwy = ((double)py - cy) / fy;
+  const double f[2] = {K4[0], K4[1]}, c[2] = {K4[2], K4[3]};
+  const double k[4] = {D4[0], D4[1], D4[2], D4[3]};
+  const double pw[2] = {((double)px - c[0]) / f[0], ((double)py - c[1]) / f[1]};
   double scale = 1.0;
-  const double theta_d = sqrt(pwx * pwx + pwy * pwy);
+  const double theta_d = sqrt(pw[0] * pw[0] + pw[1] * pw[1]);
   if (theta_d > 1e-8) {
     double theta = theta_d;
     for (int j = 0; j < 10; j++) {
       const double theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta6 * theta2;
-      theta = theta_d / (1 + k0 * theta2 + k1 * theta4 + k2 * theta6 + k3 * theta8);
+      theta = theta_d / (1 + k[0] * theta2 + k[1] * theta4 + k[2] * theta6 + k[3] * theta8);
     }
-    scale = fb_tan_d(theta) / theta_d;
+    scale = tan(theta) / theta_d;
   }
-  const double pux = pwx * scale, puy = pwy * scale;
-  /* pr = K * (pu, 1): pr.z = 1 */
-  const double prx = fx * pux + 0.0 * puy + cx * 1.0, pry = 0.0 * pux + fy * puy + cy * 1.0, prz = 0.0 * pux + 0.0 * puy + 1.0;
-  *ox = (float)(prx / prz);
-  *oy = (float)(pry / prz);
+  const double pu[2] = {pw[0] * scale, pw[1] * scale};
+  /* P = K as a 3x3 product with (pu, 1), then the perspective division by pr.z = 1 */
+  const double pr[3] = {f[0] * pu[0] + 0.0 * pu[1] + c[0] * 1.0, 0.0 * pu[0] + f[1] * pu[1] + c[1] * 1.0, 0.0 * pu[0] + 0.0 * pu[1] + 1.0};
+  *ox = (float)(pr[0] / pr[2]);
+  *oy = (float)(pr[1] / pr[2]);
 }
 
-#endif /* FB_DETMATH_H_ */
+#endif /* FB_ORACLE_DETMATH_H_ */
