@@ -52,7 +52,9 @@ def build(force=False, verbose=True):
             continue
         flags = FLAGS
         if os.path.basename(s) in FMA_OK:
-            flags = [("-ffp-contract=fast" if f == "-ffp-contract=off" else f) for f in FLAGS]
+            # fast-honor-pragmas, not fast: "fast" lets the backend fuse everything and ignores the
+            # `#pragma clang fp contract(off)` that keeps the inlier / outlier decision of k_pose_opt unfused
+            flags = [("-ffp-contract=fast-honor-pragmas" if f == "-ffp-contract=off" else f) for f in FLAGS]
         cmd = [hipcc()] + flags + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -56,6 +56,13 @@ class GridGeom(C.Structure):
     _fields_ = [("min_x", _f32), ("min_y", _f32), ("inv_w", _f32), ("inv_h", _f32), ("cols", _i32), ("rows", _i32)]
 
 
+class BirdGuidanceArgs(C.Structure):
+    _fields_ = [("batch", _i32), ("kp_stride", _i32), ("cols", _i32), ("rows", _i32), ("pitch", _i32),
+                ("contour", _vp), ("mask", _vp), ("n_in", _vp), ("kps_in", _vp), ("desc_in", _vp),
+                ("n_out", _vp), ("kps_out", _vp), ("desc_out", _vp), ("keep", _vp),
+                ("edge_cap", _i32), ("n_edge_sign", _vp), ("n_edge_free", _vp), ("edge_sign", _vp), ("edge_free", _vp)]
+
+
 class MatcherParams(C.Structure):
     _fields_ = [("nnratio", _f32), ("check_orientation", _i32)]
 
@@ -248,7 +255,7 @@ EXPORTS = [
     "fb_abi_version", "fb_last_error", "fb_device_count", "fb_set_device",
     "fb_prof_enable", "fb_prof_only", "fb_prof_reset", "fb_prof_report",
     "fb_orb_create", "fb_orb_destroy", "fb_orb_get_tables", "fb_orb_capacity", "fb_orb_extract", "fb_orb_extract_batch_dev",
-    "fb_orb_get_level", "fb_orb_get_blurred_level", "fb_orb_debug_candidates", "fb_orb_debug_timers", "fb_grid_build_batch_dev", "fb_bird_keys_to_cam_dev",
+    "fb_orb_get_level", "fb_orb_get_blurred_level", "fb_orb_debug_candidates", "fb_orb_debug_timers", "fb_grid_build_batch_dev", "fb_bird_keys_to_cam_dev", "fb_bird_guidance", "fb_bird_guidance_dev",
     "fb_descriptor_distance_dev", "fb_descriptor_distance",
     "fb_match_projection_frame_dev", "fb_match_projection_frame",
     "fb_match_bird_mappoints_dev", "fb_match_bird_mappoints",

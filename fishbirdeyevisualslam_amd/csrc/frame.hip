@@ -4,6 +4,7 @@
 //   Frame::isInFrustum            src/Frame.cc:435-491 (loop: Tracking::SearchLocalPoints, src/Tracking.cc:1071-1091)
 //   Frame::UndistortKeyPoints     src/Frame.cc:636-669 (cv::fisheye::undistortPoints, R = I, P = K)
 //   Frame::ComputeImageBounds     src/Frame.cc:741-795
+//   Frame::GuidenceKeyBirdPts     src/Frame.cc:671-684 with nearEdges :717-739 and genEdgesPC :686-715 (bird key point filter)
 //
 // Both kernels are one-lane-per-element streaming maps (28-44 B in, 1-21 B out per element): HBM-bound by
 // construction, no LDS needed.  Per-problem constants (pose, camera centre) sit in SGPRs via uniform loads.
@@ -112,9 +113,196 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_undistort(const fb_keypoint *
   out[e] = kp;
 }
 
+
+// ---- Frame::GuidenceKeyBirdPts (Frame.cc:671-739) ------------------------------------------------------------------
+constexpr int GUIDE_THREADS = 1024;
+
+__device__ __forceinline__ int wave_incl_scan_i(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+// exclusive scan of one int per thread over the 1024-thread block (s_w: 16 ints); *total = block sum
+__device__ __forceinline__ int block_excl_scan1024(int v, int *s_w, int *total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int inc = wave_incl_scan_i(v);
+  __syncthreads();
+  if (lane == 63) s_w[wv] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < GUIDE_THREADS / 64; w++) { const int x = s_w[w]; if (w < wv) base += x; tot += x; }
+  *total = tot;
+  return base + inc - v;
+}
+
+// One workgroup per bird image.  Phase A: 32 lanes per key point, one lane per contour ROW of its box (the box has at
+// most 21 rows: trunc(x-10) .. ceil(x+10)-1), each lane walks its <= 21 contiguous bytes; the verdict is the OR over the
+// half wave.  Phase B: stable compaction (push_back order) with one block scan; descriptors move as two 16-byte words.
+__global__ __launch_bounds__(GUIDE_THREADS) void k_bird_guidance(fb_bird_guidance_args A) {
+  extern __shared__ uint8_t s_keep[];  // [kp_stride]
+  __shared__ int s_w[GUIDE_THREADS / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = A.n_in[b];
+  const size_t ko = (size_t)b * A.kp_stride;
+  const uint8_t *icp = A.contour + (size_t)b * A.rows * A.pitch;
+  const uint8_t *mask = A.mask ? A.mask + (size_t)b * A.rows * A.pitch : nullptr;
+  const int sub = tid & 31;
+  for (int base = 0; base < n; base += GUIDE_THREADS / 32) {
+    const int i = base + (tid >> 5);
+    bool hit = false, ok = true;
+    if (i < n) {
+      const fb_keypoint kpt = A.kps_in[ko + i];
+      const int r = 10;
+      const float pt1x = (kpt.x - r) > 0 ? (kpt.x - r) : 0;
+      const float pt1y = (kpt.y - r) > 0 ? (kpt.y - r) : 0;
+      const float pt2x = (kpt.x + r) < A.cols ? (kpt.x + r) : A.cols;
+      const float pt2y = (kpt.y + r) < A.rows ? (kpt.y + r) : A.rows;
+      const size_t row = (size_t)pt1x + sub;       // size_t row = pt1x; row < pt2x; row++
+      if ((float)row < pt2x && row < (size_t)A.rows) {
+        const uint8_t *src = icp + row * (size_t)A.pitch;
+        for (size_t col = (size_t)pt1y; (float)col < pt2y && col < (size_t)A.cols; col++)
+          if (src[col] >= 10) { hit = true; break; }
+      }
+      if (mask) {
+        const int my = (int)(kpt.y + 0.5f), mx = (int)(kpt.x + 0.5f);
+        ok = my >= 0 && my < A.rows && mx >= 0 && mx < A.cols && mask[(size_t)my * A.pitch + mx] != 0;
+      }
+    }
+    const unsigned long long bal = __ballot(hit);
+    const unsigned int mine = (unsigned int)(bal >> (tid & 32));
+    if (sub == 0 && i < n) {
+      const uint8_t k = (ok && mine != 0u) ? 1 : 0;
+      s_keep[i] = k;
+      if (A.keep) A.keep[ko + i] = k;
+    }
+  }
+  __syncthreads();
+  const int per = (n + GUIDE_THREADS - 1) / GUIDE_THREADS;
+  const int i0 = tid * per, i1 = min(n, i0 + per);
+  int cnt = 0;
+  for (int i = i0; i < i1; i++) cnt += s_keep[i];
+  int total;
+  int o = block_excl_scan1024(cnt, s_w, &total);
+  for (int i = i0; i < i1; i++) {
+    if (!s_keep[i]) continue;
+    A.kps_out[ko + o] = A.kps_in[ko + i];
+    if (A.desc_in) {
+      const uint4 *src = reinterpret_cast<const uint4 *>(A.desc_in + (ko + i) * 32);
+      uint4 *dst = reinterpret_cast<uint4 *>(A.desc_out + (ko + o) * 32);
+      dst[0] = src[0]; dst[1] = src[1];
+    }
+    o++;
+  }
+  if (tid == 0) A.n_out[b] = total;
+}
+
+// genEdgesPC: raster-order compaction of the contour pixels into the "sign" ([10,150)) and "free" (>= 150) point lists.
+// A thread owns a contiguous run of the raster, two block scans give its output offsets.
+__global__ __launch_bounds__(GUIDE_THREADS) void k_bird_edges(fb_bird_guidance_args A) {
+  __shared__ int s_w[GUIDE_THREADS / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const uint8_t *icp = A.contour + (size_t)b * A.rows * A.pitch;
+  const int total = A.rows * A.cols;
+  const int per = (total + GUIDE_THREADS - 1) / GUIDE_THREADS;
+  const int p0 = min(total, tid * per), p1 = min(total, p0 + per);
+  int ns = 0, nf = 0;
+  {
+    int row = p0 / A.cols, col = p0 - row * A.cols;
+    for (int p = p0; p < p1; p++) {
+      const uint8_t v = icp[(size_t)row * A.pitch + col];
+      ns += v >= 10 && v < 150;
+      nf += v >= 150;
+      if (++col == A.cols) { col = 0; row++; }
+    }
+  }
+  int ts, tf;
+  int os = block_excl_scan1024(ns, s_w, &ts);
+  int of = block_excl_scan1024(nf, s_w, &tf);
+  float *es = A.edge_sign + (size_t)b * A.edge_cap * 2, *ef = A.edge_free + (size_t)b * A.edge_cap * 2;
+  {
+    int row = p0 / A.cols, col = p0 - row * A.cols;
+    for (int p = p0; p < p1; p++) {
+      const uint8_t v = icp[(size_t)row * A.pitch + col];
+      if (v >= 150) { if (of < A.edge_cap) { ef[of * 2] = (float)col; ef[of * 2 + 1] = (float)row; } of++; }
+      else if (v >= 10) { if (os < A.edge_cap) { es[os * 2] = (float)col; es[os * 2 + 1] = (float)row; } os++; }
+      if (++col == A.cols) { col = 0; row++; }
+    }
+  }
+  if (tid == 0) { A.n_edge_sign[b] = ts; A.n_edge_free[b] = tf; }
+}
+
 }  // namespace
 
 extern "C" {
+
+int fb_bird_guidance_dev(const fb_bird_guidance_args *A, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(A && A->batch >= 0 && A->kp_stride >= 0 && A->cols > 0 && A->rows > 0 && A->pitch >= A->cols && A->edge_cap >= 0);
+  if (A->batch == 0) return FB_OK;
+  FB_ARG(A->contour && A->n_in && A->n_out && (A->kp_stride == 0 || (A->kps_in && A->kps_out)));
+  FB_ARG(!A->desc_in || (A->desc_out && ((uintptr_t)A->desc_in % 16 == 0) && ((uintptr_t)A->desc_out % 16 == 0)));
+  FB_ARG(A->kps_out != A->kps_in && (!A->desc_in || A->desc_out != A->desc_in));
+  FB_ARG(A->edge_cap == 0 || (A->n_edge_sign && A->n_edge_free && A->edge_sign && A->edge_free));
+  FB_ARG((size_t)A->rows * A->cols < (size_t)INT_MAX);
+  const size_t lds = (size_t)A->kp_stride + 16;
+  if (lds > 150 * 1024) { fb::set_error("fb_bird_guidance: kp_stride %d beyond the LDS flag array", A->kp_stride); return FB_ERR_CAPACITY; }
+  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bird_guidance), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  fb::ProfScope prof_(fb::P_BIRDCAM, fb::as_stream(stream));
+  k_bird_guidance<<<A->batch, GUIDE_THREADS, lds, fb::as_stream(stream)>>>(*A);
+  FB_HIP(hipGetLastError());
+  if (A->edge_cap > 0) {
+    k_bird_edges<<<A->batch, GUIDE_THREADS, 0, fb::as_stream(stream)>>>(*A);
+    FB_HIP(hipGetLastError());
+  }
+  return FB_OK;
+}
+
+int fb_bird_guidance(const fb_bird_guidance_args *H) {
+  FB_TRY(fb::check_device());
+  FB_ARG(H && H->batch >= 0 && H->kp_stride >= 0 && H->cols > 0 && H->rows > 0 && H->pitch >= H->cols && H->edge_cap >= 0);
+  if (H->batch == 0) return FB_OK;
+  FB_ARG(H->contour && H->n_in && H->n_out && (H->kp_stride == 0 || (H->kps_in && H->kps_out)));
+  FB_ARG(!H->desc_in || H->desc_out);
+  for (int b = 0; b < H->batch; b++) FB_ARG(H->n_in[b] >= 0 && H->n_in[b] <= H->kp_stride);
+  fb_bird_guidance_args D = *H;
+  const size_t B = H->batch, ks = H->kp_stride, img = (size_t)H->rows * H->pitch, ec = H->edge_cap;
+  fb::DevBuf c, m, ni, ki, di, no, ko, dout, kp, ns, nf, es, ef;
+  FB_TRY(c.upload(H->contour, B * img)); D.contour = c.as<uint8_t>();
+  if (H->mask) { FB_TRY(m.upload(H->mask, B * img)); D.mask = m.as<uint8_t>(); }
+  FB_TRY(ni.upload(H->n_in, B * 4)); D.n_in = ni.as<int32_t>();
+  FB_TRY(ki.upload(H->kps_in, B * ks * sizeof(fb_keypoint))); D.kps_in = ki.as<fb_keypoint>();
+  if (H->desc_in) { FB_TRY(di.upload(H->desc_in, B * ks * 32)); D.desc_in = di.as<uint8_t>(); }
+  FB_TRY(no.alloc(B * 4)); D.n_out = no.as<int32_t>();
+  // outputs are in/out: entries past n_out keep their previous content
+  FB_TRY(ko.upload(H->kps_out, B * ks * sizeof(fb_keypoint))); D.kps_out = ko.as<fb_keypoint>();
+  if (H->desc_in) { FB_TRY(dout.upload(H->desc_out, B * ks * 32)); D.desc_out = dout.as<uint8_t>(); }
+  if (H->keep) { FB_TRY(kp.upload(H->keep, B * ks)); D.keep = kp.as<uint8_t>(); }
+  if (ec) {
+    FB_ARG(H->n_edge_sign && H->n_edge_free && H->edge_sign && H->edge_free);
+    FB_TRY(ns.alloc(B * 4)); D.n_edge_sign = ns.as<int32_t>();
+    FB_TRY(nf.alloc(B * 4)); D.n_edge_free = nf.as<int32_t>();
+    FB_TRY(es.upload(H->edge_sign, B * ec * 8)); D.edge_sign = es.as<float>();
+    FB_TRY(ef.upload(H->edge_free, B * ec * 8)); D.edge_free = ef.as<float>();
+  }
+  FB_TRY(fb_bird_guidance_dev(&D, nullptr));
+  FB_HIP(hipDeviceSynchronize());
+  FB_TRY(no.download(H->n_out, B * 4));
+  FB_TRY(ko.download(H->kps_out, B * ks * sizeof(fb_keypoint)));
+  if (H->desc_in) FB_TRY(dout.download(H->desc_out, B * ks * 32));
+  if (H->keep) FB_TRY(kp.download(H->keep, B * ks));
+  if (ec) {
+    FB_TRY(ns.download(H->n_edge_sign, B * 4));
+    FB_TRY(nf.download(H->n_edge_free, B * 4));
+    FB_TRY(es.download(H->edge_sign, B * ec * 8));
+    FB_TRY(ef.download(H->edge_free, B * ec * 8));
+  }
+  return FB_OK;
+}
 
 int fb_in_frustum_dev(const fb_frustum_args *A, void *stream) {
   FB_TRY(fb::check_device());

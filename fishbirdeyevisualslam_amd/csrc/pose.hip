@@ -177,24 +177,38 @@ __device__ __forceinline__ void unpack_system(const double *red, double *H, doub
   for (int i = 0; i < 6; i++) b[i] = red[22 + i];
 }
 
-// chi2 of one edge at pose T (computeError + chi2(), base_edge.h:58-61)
+// chi2 of one edge at pose T for the inlier / outlier decision (computeError + chi2(), base_edge.h:58-61; compared as
+// float with 5.991 / 1.5 at Optimizer.cc:410,645,672).  This file is compiled with fused multiply-adds for the LM
+// evaluations, which are held to a tolerance; the DECISION is an integer result, so its arithmetic is written out here
+// with contraction off and with g2o's own quotients (project2d: v / v(2)), operation for operation what the oracle
+// evaluates: given the same pose the masks are equal by construction, not by luck of the rounding.
 __device__ __forceinline__ double edge_chi2(const EdgeView &E, int e, bool bird, const fb::SE3 &T, double fx,
                                             double fy, double cx, double cy) {
-  double p[3];
+#pragma clang fp contract(off)
+  const float *X = bird ? E.bxw + e * 3 : E.fxw + e * 3;
+  const double v0 = X[0], v1 = X[1], v2 = X[2];
+  const double qx = T.r.x, qy = T.r.y, qz = T.r.z, qw = T.r.w;
+  // Eigen's quaternion * vector (fb::quat_rotate), then + t (se3quat.h:217-220)
+  double u0 = qy * v2 - qz * v1, u1 = qz * v0 - qx * v2, u2 = qx * v1 - qy * v0;
+  u0 += u0; u1 += u1; u2 += u2;
+  const double p0 = (v0 + qw * u0 + (qy * u2 - qz * u1)) + T.t[0];
+  const double p1 = (v1 + qw * u1 + (qz * u0 - qx * u2)) + T.t[1];
+  const double p2 = (v2 + qw * u2 + (qx * u1 - qy * u0)) + T.t[2];
   if (!bird) {
-    const double Xw[3] = {E.fxw[e * 3], E.fxw[e * 3 + 1], E.fxw[e * 3 + 2]};
-    fb::se3_map(T, Xw, p);
-    const double invz = 1.0 / p[2];
-    const double e0 = (double)E.fobs[e * 2] - ((p[0] * invz) * fx + cx);
-    const double e1 = (double)E.fobs[e * 2 + 1] - ((p[1] * invz) * fy + cy);
+    const double e0 = (double)E.fobs[e * 2] - ((p0 / p2) * fx + cx);
+    const double e1 = (double)E.fobs[e * 2 + 1] - ((p1 / p2) * fy + cy);
     const double info = (double)E.finf[e] * E.wf;
-    return e0 * (info * e0) + e1 * (info * e1);
+    double s = 0;
+    s += e0 * (info * e0);
+    s += e1 * (info * e1);
+    return s;
   }
-  const double Xw[3] = {E.bxw[e * 3], E.bxw[e * 3 + 1], E.bxw[e * 3 + 2]};
-  fb::se3_map(T, Xw, p);
   const double info = (double)E.binf[e] * E.wb;
+  const double d0 = (double)E.bxc[e * 3] - p0, d1 = (double)E.bxc[e * 3 + 1] - p1, d2 = (double)E.bxc[e * 3 + 2] - p2;
   double s = 0;
-  for (int i = 0; i < 3; i++) { const double d = (double)E.bxc[e * 3 + i] - p[i]; s += d * (info * d); }
+  s += d0 * (info * d0);
+  s += d1 * (info * d1);
+  s += d2 * (info * d2);
   return s;
 }
 

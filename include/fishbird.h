@@ -152,6 +152,42 @@ int fb_bird_keys_to_cam_dev(const fb_keypoint *d_kps, const int32_t *d_n, int ba
                             double rear_axle_to_center, const float *Tcb12 /* host */,
                             float *d_cam_xyz, void *stream);
 
+/* Frame::GuidenceKeyBirdPts + nearEdges + genEdgesPC (src/Frame.cc:671-739, called at :342 between the bird
+ * detect and compute steps) and the mask of extractorBird->detect(img, kps, mask) (Frame.cc:337-339).
+ *
+ * A bird key point survives iff
+ *   (mask == NULL || mask[(int)(y + .5f)][(int)(x + .5f)] != 0)          -- cv::KeyPointsFilter::runByPixelsMask on the
+ *                                                                           level-0 position (the per-level masks of
+ *                                                                           cv::ORB are part of the E9 substitution)
+ *   && nearEdges(kp): any contour pixel >= 10 in the box  row in [trunc(max(x-10,0)), min(x+10, cols)),
+ *                     col in [trunc(max(y-10,0)), min(y+10, rows))  -- sic: the key point's X selects the image ROW and
+ *                     is clamped with cols, its Y selects the COLUMN and is clamped with rows (Frame.cc:719-729); loop
+ *                     bounds are float compares of a size_t counter, as in the reference.  On a non-square contour image
+ *                     the reference reads out of bounds; here pixels outside the image count as 0 (free).
+ * Survivors are appended in input order (push_back, Frame.cc:680); descriptors (computed before the filter in this
+ * build, after it in the reference) move with their key points.  Outputs must not alias the inputs.
+ * genEdgesPC (Frame.cc:686-715; lists nothing in the reference ever reads) is optional: edge_sign = pixels in [10,150),
+ * edge_free = pixels >= 150, as (x = col, y = row) float pairs in raster order, at most edge_cap each (counts are
+ * the true totals; entries beyond edge_cap are dropped). */
+typedef struct fb_bird_guidance_args {
+  int32_t batch, kp_stride;
+  int32_t cols, rows, pitch;            /* mBirdviewContourICP / mBirdviewMask geometry; images rows*pitch bytes apart */
+  const uint8_t *contour;               /* [batch][rows][pitch] u8                                               */
+  const uint8_t *mask;                  /* optional, same geometry                                               */
+  const int32_t *n_in;                  /* [batch]                                                               */
+  const fb_keypoint *kps_in;            /* [batch][kp_stride]  preKeysBird (level-0 pixel coordinates)           */
+  const uint8_t *desc_in;               /* optional [batch][kp_stride][32]                                       */
+  int32_t *n_out;                       /* [batch]             Nbird                                             */
+  fb_keypoint *kps_out;                 /* [batch][kp_stride]  mvKeysBird                                        */
+  uint8_t *desc_out;                    /* [batch][kp_stride][32] (required iff desc_in)                         */
+  uint8_t *keep;                        /* optional [batch][kp_stride]: 1 = survived                             */
+  int32_t edge_cap;                     /* 0 = skip genEdgesPC                                                   */
+  int32_t *n_edge_sign, *n_edge_free;   /* [batch]                                                               */
+  float *edge_sign, *edge_free;         /* [batch][edge_cap][2]                                                  */
+} fb_bird_guidance_args;
+int fb_bird_guidance(const fb_bird_guidance_args *a);                    /* host pointers  */
+int fb_bird_guidance_dev(const fb_bird_guidance_args *a, void *stream);  /* device pointers */
+
 /* ======================================================================== */
 /* ORBmatcher (include/ORBmatcher.h:41-88, src/ORBmatcher.cc)                */
 /* ======================================================================== */

@@ -149,6 +149,17 @@ struct PoseProblem : LMProblem {
   void applyUpdate() override { T = se3_mul(se3_exp(x), T); }  // VertexSE3Expmap::oplusImpl
 };
 
+// Test instrumentation: the smallest relative distance |chi2 - threshold| / threshold over every inlier / outlier
+// decision taken since the last reset (float values, as compared at Optimizer.cc:410,645,672).  It is the margin a
+// differently rounded implementation has before a mask can flip.
+double g_min_margin = 1e300;
+long g_decisions = 0;
+inline void note_margin(float chi2, double thr) {
+  const double m = std::fabs((double)chi2 - thr) / thr;
+  if (m < g_min_margin) g_min_margin = m;
+  g_decisions++;
+}
+
 int pose_opt_one(const fb_pose_opt_args *A, int bidx) {
   const int mode = A->mode;
   const size_t fo = (size_t)bidx * A->front_stride, bo = (size_t)bidx * A->bird_stride;
@@ -205,6 +216,7 @@ int pose_opt_one(const fb_pose_opt_args *A, int bidx) {
       bool bad;
       if (mode == FB_POSE_FRONT) bad = chi2 > chi2Mono;                         // :410-412
       else bad = chi2 > chi2Mono * ((double)A->wF + 1e-9);                       // :645
+      note_margin(chi2, mode == FB_POSE_FRONT ? (double)chi2Mono : chi2Mono * ((double)A->wF + 1e-9));
       if (bad) { A->front_outlier[fo + i] = 1; e.level = 1; nBad++; }
       else { A->front_outlier[fo + i] = 0; e.level = 0; }
       if (it == 2) e.robust = false;
@@ -216,6 +228,7 @@ int pose_opt_one(const fb_pose_opt_args *A, int bidx) {
       if (A->bird_outlier[bo + i]) P.computeError(e);
       const float chi2 = (float)PoseProblem::chi2(e);
       const float chi2Bad = (float)(chi2Bird * ((double)A->wB + 1e-9));          // :672, :806
+      note_margin(chi2, (double)chi2Bad);
       if (chi2 > chi2Bad) { A->bird_outlier[bo + i] = 1; e.level = 1; nBadBird++; }
       else { A->bird_outlier[bo + i] = 0; e.level = 0; }
       if (it == 2) e.robust = false;
@@ -238,6 +251,9 @@ int orc_pose_opt(const fb_pose_opt_args *A) {
   }
   return FB_OK;
 }
+
+void orc_pose_margin_reset() { g_min_margin = 1e300; g_decisions = 0; }
+int orc_pose_margin_get(double *min_margin, long *decisions) { *min_margin = g_min_margin; *decisions = g_decisions; return FB_OK; }
 
 // known-answer hooks -------------------------------------------------------------
 int orc_se3_exp(const double *u6, double *q4t3) {  // -> qx,qy,qz,qw,tx,ty,tz
