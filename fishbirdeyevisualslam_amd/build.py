@@ -55,7 +55,8 @@ def build(force=False, verbose=True):
             # fast-honor-pragmas, not fast: "fast" lets the backend fuse everything and ignores the
             # `#pragma clang fp contract(off)` that keeps the inlier / outlier decision of k_pose_opt unfused
             flags = [("-ffp-contract=fast-honor-pragmas" if f == "-ffp-contract=off" else f) for f in FLAGS]
-        cmd = [hipcc()] + flags + ["-c", s, "-o", o]
+        # FB_BUILD_DEFS="-DFB_POSE_STAMPS ...": diagnostic variants for the probes under profiles/probes/ (never the product build)
+        cmd = [hipcc()] + flags + os.environ.get("FB_BUILD_DEFS", "").split() + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))

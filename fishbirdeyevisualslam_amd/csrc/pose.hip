@@ -23,15 +23,27 @@
 
 namespace {
 
-constexpr int POSE_THREADS = 256;
-constexpr int NW = POSE_THREADS / 64;
+constexpr int POSE_THREADS = 256;  // the LDS-staged kernel
 constexpr int NACC = 28;  // chi2, 21 x H upper, 6 x b
+
+// -DFB_POSE_STAMPS (profiles/probes/pose_stamps.py builds that variant on the GPU box): thread 0 of workgroup 0 adds the
+// shader-clock time of each phase of an LM evaluation to g_pose_stamps[]; compiled out of the product build.
+#ifdef FB_POSE_STAMPS
+__device__ unsigned long long g_pose_stamps[16];
+#define POSE_T0() unsigned long long pt_ = 0; if (blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); pt_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define POSE_TICK(slot_) if (blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); g_pose_stamps[slot_] += t_ - pt_; pt_ = t_; }
+#define POSE_COUNT(slot_) if (blockIdx.x == 0 && threadIdx.x == 0) g_pose_stamps[slot_] += 1;
+#else
+#define POSE_T0()
+#define POSE_TICK(slot_)
+#define POSE_COUNT(slot_)
+#endif
 
 struct PoseLds {  // fixed-size shared state
   fb::SE3 T, Ttrial, Teval;
   double H[36], b[6], x[6];
   double red[NACC];
-  double part[NW][NACC];
+  double part[8][NACC];  // per-wave partial sums (up to 512 threads)
   int ok2;
 };
 
@@ -126,12 +138,16 @@ __device__ __forceinline__ void accumulate_bird_edge(const double (&p)[3], const
 }
 
 // one evaluation: robust chi2 + H + b at pose T over the active edges
+template <int NT>
 __device__ void eval_pass(const EdgeView &E, const fb::SE3 &T, bool robust, double delta, double fx, double fy,
                           double cx, double cy, PoseLds *S) {
+  constexpr int POSE_THREADS = NT, NW = NT / 64;
   double acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; i++) acc[i] = 0;
   const int tid = threadIdx.x;
+  POSE_T0()
+  POSE_COUNT(15)
   for (int e = tid; e < E.nfs; e += POSE_THREADS) {  // EdgeSE3ProjectXYZOnlyPose
     if (E.flevel[e] != 0) continue;
     const double Xw[3] = {E.fxw[e * 3], E.fxw[e * 3 + 1], E.fxw[e * 3 + 2]};
@@ -145,6 +161,7 @@ __device__ void eval_pass(const EdgeView &E, const fb::SE3 &T, bool robust, doub
                             {(1 + Y * Y * invz_2) * fy, -X * Y * invz_2 * fy, -X * invz * fy, 0, -invz * fy, Y * invz_2 * fy}};
     accumulate_edge<2, (1u << 4) | (1u << 9)>(J, err, (double)E.finf[e] * E.wf, robust, delta, acc);  // J[0][4] = J[1][3] = 0
   }
+  POSE_TICK(0)
   for (int k = tid; k < E.nbs; k += POSE_THREADS) {  // EdgeSE3ProjectBirdPoint2CamXYZ
     if (E.blevel[k] != 0) continue;
     const double Xw[3] = {E.bxw[k * 3], E.bxw[k * 3 + 1], E.bxw[k * 3 + 2]};
@@ -153,6 +170,7 @@ __device__ void eval_pass(const EdgeView &E, const fb::SE3 &T, bool robust, doub
     const double err[3] = {(double)E.bxc[k * 3] - p[0], (double)E.bxc[k * 3 + 1] - p[1], (double)E.bxc[k * 3 + 2] - p[2]};
     accumulate_bird_edge(p, err, (double)E.binf[k] * E.wb, robust, delta, acc);  // J = -[-skew(p), I]
   }
+  POSE_TICK(1)
   const int lane = tid & 63, wv = tid >> 6;
   {
     double v[32];
@@ -161,6 +179,7 @@ __device__ void eval_pass(const EdgeView &E, const fb::SE3 &T, bool robust, doub
     const double s = fb::wave_column_sums32(v, lane);
     if ((lane & 1) == 0 && (lane >> 1) < NACC) S->part[wv][lane >> 1] = s;
   }
+  POSE_TICK(2)
   __syncthreads();
   if (tid < NACC) {
     double s = 0;
@@ -168,6 +187,7 @@ __device__ void eval_pass(const EdgeView &E, const fb::SE3 &T, bool robust, doub
     S->red[tid] = s;
   }
   __syncthreads();
+  POSE_TICK(3)
 }
 
 __device__ __forceinline__ void unpack_system(const double *red, double *H, double *b) {
@@ -212,11 +232,16 @@ __device__ __forceinline__ double edge_chi2(const EdgeView &E, int e, bool bird,
   return s;
 }
 
-__global__ __launch_bounds__(POSE_THREADS) void k_pose_opt(fb_pose_opt_args A, int staged) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ PoseLds S;
-  __shared__ int s_cnt[2];
+// The generic schedule for any number of edges per frame: edges staged in LDS as float (staged = 1) or read from HBM / L2
+// in every evaluation (staged = 0), per-edge level bytes in LDS, butterfly sums.  It is the whole kernel for frames beyond
+// the register-resident kernel below, and that kernel's in-kernel way out for a frame with more edges than its slots.
+template <int NT>
+__device__ void pose_generic(const fb_pose_opt_args &A, int staged, uint8_t *smem, PoseLds &S, int *s_cnt) {
+  constexpr int POSE_THREADS = NT, NW = NT / 64;
   const int bidx = blockIdx.x, tid = threadIdx.x;
+#ifdef FB_POSE_STAMPS
+  const unsigned long long pose_t_start = __builtin_amdgcn_s_memtime();
+#endif
   const int mode = A.mode;
   const size_t fo = (size_t)bidx * A.front_stride, bo = (size_t)bidx * A.bird_stride;
   const int nfs = (mode != FB_POSE_BIRD) ? A.n_front[bidx] : 0;
@@ -294,7 +319,7 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose_opt(fb_pose_opt_args A, i
     nact = __syncthreads_count(nact > 0);
     if (nact > 0) {
       // ---- optimize(10): OptimizationAlgorithmLevenberg
-      eval_pass(E, S.T, robust, delta, fx, fy, cx, cy, &S);
+      eval_pass<NT>(E, S.T, robust, delta, fx, fy, cx, cy, &S);
       if (tid == 0) { unpack_system(S.red, S.H, S.b); S.Teval = S.T; }
       double currentChi = S.red[0];
       __syncthreads();
@@ -312,13 +337,19 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose_opt(fb_pose_opt_args A, i
         double rho = 0;
         int qmax = 0;
         do {
-          if (tid == 0) {
-            S.ok2 = fb::ldlt6(S.H, lambda, S.b, S.x) ? 1 : 0;
-            S.Ttrial = fb::se3_mul(fb::se3_exp(S.x), S.T);  // oplus
-            S.Teval = S.Ttrial;
+          {
+            POSE_T0()
+            if (tid == 0) {
+              S.ok2 = fb::ldlt6(S.H, lambda, S.b, S.x) ? 1 : 0;
+              POSE_TICK(4)
+              S.Ttrial = fb::se3_mul(fb::se3_exp(S.x), S.T);  // oplus
+              S.Teval = S.Ttrial;
+              POSE_TICK(5)
+            }
+            __syncthreads();
+            POSE_TICK(6)
           }
-          __syncthreads();
-          eval_pass(E, S.Ttrial, robust, delta, fx, fy, cx, cy, &S);
+          eval_pass<NT>(E, S.Ttrial, robust, delta, fx, fy, cx, cy, &S);
           double tempChi = S.red[0];
           if (!S.ok2) tempChi = 1.7976931348623157e308;
           rho = currentChi - tempChi;
@@ -350,6 +381,7 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose_opt(fb_pose_opt_args A, i
       }
     }
     // ---- classify (Optimizer.cc:396-431, 627-686, 791-822)
+    POSE_T0()
     const fb::SE3 T = S.T, Teval = S.Teval;
     int bad = 0, badb = 0;
     for (int i = tid; i < nfs; i += POSE_THREADS) {
@@ -382,12 +414,427 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose_opt(fb_pose_opt_args A, i
       nBad = (int)tb; nBadBird = (int)tbb;
       __syncthreads();
     }
+    POSE_TICK(7)
     if (nf + nb < 10) break;  // optimizer.edges().size()<10
   }
   if (tid == 0) {
     fb::se3_to_float12(S.T, Tcw);
     A.ninliers[bidx] = (mode == FB_POSE_BIRD) ? nb - nBadBird : nf - nBad;
   }
+#ifdef FB_POSE_STAMPS
+  if (blockIdx.x == 0 && tid == 0) g_pose_stamps[14] += __builtin_amdgcn_s_memtime() - pose_t_start;
+#endif
+}
+
+__global__ __launch_bounds__(256) void k_pose_opt(fb_pose_opt_args A, int staged) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ PoseLds S;
+  __shared__ int s_cnt[2];
+  pose_generic<256>(A, staged, smem, S, s_cnt);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_pose_opt_reg -- the same schedule, built for the latency of ONE frame (single-sequence tracking is bounded by this
+// kernel).  Phase stamps of the LDS-staged kernel above (profiles/r02_pose_stamps_before.txt): an LM evaluation took
+// ~29 k cycles = 12.6 k edge arithmetic of one wave per SIMD, 7 k for the 28 cross-lane sums (ds_bpermute butterflies
+// are latency chains), 4 k for the 6x6 solve + exponential map on one lane.  Here
+//  * the edges of a thread live in REGISTERS (edge e -> thread e % NT, slot e / NT, up to 8 front + 4 bird slots), so an
+//    evaluation reads nothing but the pose from LDS and NT = 512 threads (two waves per SIMD) cover each other's fp64
+//    latencies;
+//  * the 28 sums go through an LDS transpose: every thread stores its 28 accumulators (conflict-free rows of NT + CPA
+//    doubles), 28 x CPA threads add 32 values each with 4 independent chains, the CPA partial sums of an accumulator
+//    sit in adjacent lanes and are combined with DPP row shifts (VALU moves, no LDS crossbar);
+//  * the update T <- exp(x) T is formed directly on the quaternion (no rotation matrix, one reciprocal square root per
+//    normalisation).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {  // v of the lane selected by the DPP control, +0.0 where there is none
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void quat_normalize_fast(fb::Quat &q) {  // normalizeRotation (se3quat.h:280-285) with one reciprocal
+  if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+  const double inv = 1.0 / sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv;
+}
+
+// SE3Quat::exp (se3quat.h:223-257) without the detour over R: q = (sin(t/2) w/t, cos(t/2)), translation V u with
+// V = I + b [w]x + d [w]x^2 written as cross products.  The reference's small-angle branch (R = I + [w]x + [w]x^2, sic)
+// is kept verbatim through fb::se3_exp.
+__device__ __forceinline__ fb::SE3 se3_exp_direct(const double u[6]) {
+  const double wx = u[0], wy = u[1], wz = u[2];
+  const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+  if (theta < 0.00001) return fb::se3_exp(u);
+  double sh, ch;
+  sincos(0.5 * theta, &sh, &ch);
+  const double it = 1.0 / theta, it2 = it * it;
+  const double k = sh * it;
+  fb::SE3 T;
+  T.r.x = wx * k; T.r.y = wy * k; T.r.z = wz * k; T.r.w = ch;
+  const double sn = 2.0 * sh * ch;                        // sin(theta)
+  const double b = 2.0 * sh * sh * it2;                   // (1 - cos(theta)) / theta^2
+  const double d = (theta - sn) * (it2 * it);             // (theta - sin(theta)) / theta^3
+  const double c1x = wy * u[5] - wz * u[4], c1y = wz * u[3] - wx * u[5], c1z = wx * u[4] - wy * u[3];
+  const double c2x = wy * c1z - wz * c1y, c2y = wz * c1x - wx * c1z, c2z = wx * c1y - wy * c1x;
+  T.t[0] = u[3] + b * c1x + d * c2x;
+  T.t[1] = u[4] + b * c1y + d * c2y;
+  T.t[2] = u[5] + b * c1z + d * c2z;
+  quat_normalize_fast(T.r);
+  return T;
+}
+
+__device__ __forceinline__ fb::SE3 se3_mul_fast(const fb::SE3 &a, const fb::SE3 &b) {  // se3quat.h:104-110
+  fb::SE3 r = a;
+  double rt[3];
+  fb::quat_rotate(a.r, b.t, rt);
+  r.t[0] += rt[0]; r.t[1] += rt[1]; r.t[2] += rt[2];
+  r.r = fb::quat_mul(a.r, b.r);
+  quat_normalize_fast(r.r);
+  return r;
+}
+
+__device__ __forceinline__ void front_edge_acc(const fb::SE3 &T, float x0, float x1, float x2, float o0, float o1, double info,
+                                               bool robust, double delta, double fx, double fy, double cx, double cy,
+                                               double (&acc)[NACC]) {
+  const double Xw[3] = {x0, x1, x2};
+  double p[3];
+  fb::se3_map(T, Xw, p);
+  const double X = p[0], Y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
+  const double err[2] = {(double)o0 - ((X * invz) * fx + cx), (double)o1 - ((Y * invz) * fy + cy)};
+  const double J[2][6] = {{X * Y * invz_2 * fx, -(1 + (X * X * invz_2)) * fx, Y * invz * fx, -invz * fx, 0, X * invz_2 * fx},
+                          {(1 + Y * Y * invz_2) * fy, -X * Y * invz_2 * fy, -X * invz * fy, 0, -invz * fy, Y * invz_2 * fy}};
+  accumulate_edge<2, (1u << 4) | (1u << 9)>(J, err, info, robust, delta, acc);
+}
+
+__device__ __forceinline__ void bird_edge_acc(const fb::SE3 &T, float x0, float x1, float x2, float c0, float c1, float c2, double info,
+                                              bool robust, double delta, double (&acc)[NACC]) {
+  const double Xw[3] = {x0, x1, x2};
+  double p[3];
+  fb::se3_map(T, Xw, p);
+  const double err[3] = {(double)c0 - p[0], (double)c1 - p[1], (double)c2 - p[2]};
+  accumulate_bird_edge(p, err, info, robust, delta, acc);
+}
+
+// decision chi2 from register-resident edge data (same unfused arithmetic as edge_chi2 above)
+__device__ __forceinline__ double chi2_front_vals(float x0, float x1, float x2, float o0, float o1, double info, const fb::SE3 &T,
+                                                  double fx, double fy, double cx, double cy) {
+#pragma clang fp contract(off)
+  const double v0 = x0, v1 = x1, v2 = x2;
+  const double qx = T.r.x, qy = T.r.y, qz = T.r.z, qw = T.r.w;
+  double u0 = qy * v2 - qz * v1, u1 = qz * v0 - qx * v2, u2 = qx * v1 - qy * v0;
+  u0 += u0; u1 += u1; u2 += u2;
+  const double p0 = (v0 + qw * u0 + (qy * u2 - qz * u1)) + T.t[0];
+  const double p1 = (v1 + qw * u1 + (qz * u0 - qx * u2)) + T.t[1];
+  const double p2 = (v2 + qw * u2 + (qx * u1 - qy * u0)) + T.t[2];
+  const double e0 = (double)o0 - ((p0 / p2) * fx + cx);
+  const double e1 = (double)o1 - ((p1 / p2) * fy + cy);
+  double s = 0;
+  s += e0 * (info * e0);
+  s += e1 * (info * e1);
+  return s;
+}
+__device__ __forceinline__ double chi2_bird_vals(float x0, float x1, float x2, float c0, float c1, float c2, double info, const fb::SE3 &T) {
+#pragma clang fp contract(off)
+  const double v0 = x0, v1 = x1, v2 = x2;
+  const double qx = T.r.x, qy = T.r.y, qz = T.r.z, qw = T.r.w;
+  double u0 = qy * v2 - qz * v1, u1 = qz * v0 - qx * v2, u2 = qx * v1 - qy * v0;
+  u0 += u0; u1 += u1; u2 += u2;
+  const double p0 = (v0 + qw * u0 + (qy * u2 - qz * u1)) + T.t[0];
+  const double p1 = (v1 + qw * u1 + (qz * u0 - qx * u2)) + T.t[1];
+  const double p2 = (v2 + qw * u2 + (qx * u1 - qy * u0)) + T.t[2];
+  const double d0 = (double)c0 - p0, d1 = (double)c1 - p1, d2 = (double)c2 - p2;
+  double s = 0;
+  s += d0 * (info * d0);
+  s += d1 * (info * d1);
+  s += d2 * (info * d2);
+  return s;
+}
+
+// EF / EB = front / bird edge slots per thread.  <512, 5, 3> (up to 2560 + 1536 edges: the 2000-feature extractor, capacity
+// 2064) keeps acc[28] + the edges + the per-edge temporaries inside the 256 registers two waves per SIMD leave a thread;
+// <512, 8, 4> (up to 4096 + 2048 edges, the 4000-feature initialisation extractor) spills a little.
+template <int NT, int EF, int EB>
+__global__ __launch_bounds__(NT) void k_pose_opt_reg(fb_pose_opt_args A) {
+  constexpr int CPA = NT / 32;   // threads that share one accumulator in the column sums (each adds 32 values)
+  constexpr int RS = NT + CPA;   // row stride in doubles: 2 * RS mod 64 = 2 * CPA, so the CPA-wide windows of the accumulators
+                                 // handled by one ds_read_b64 lane group fall into disjoint banks; the row writes are contiguous
+  constexpr int NWR = NT / 64;
+  extern __shared__ __attribute__((aligned(16))) double s_part[];  // [NACC][RS]
+  __shared__ PoseLds S;
+  __shared__ int s_cnt[2];
+  __shared__ int s_wcnt[2][NWR];
+  const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef FB_POSE_STAMPS
+  const unsigned long long pose_t_start = __builtin_amdgcn_s_memtime();
+#endif
+  const int mode = A.mode;
+  const size_t fo = (size_t)bidx * A.front_stride, bo = (size_t)bidx * A.bird_stride;
+  const int nfs = (mode != FB_POSE_BIRD) ? A.n_front[bidx] : 0;
+  const int nbs = (mode != FB_POSE_FRONT) ? A.n_bird[bidx] : 0;
+  float *Tcw = A.Tcw + (size_t)bidx * 12;
+  // ---- edge construction (Optimizer.cc:525-602).  The slots with an edge are compacted (rank among the valid slots, in
+  //      slot order) so that a thread's registers hold real edges only: wave w scans the contiguous range of slots
+  //      [w * per, (w + 1) * per), pass 1 counts, pass 2 writes the slot index of the edge with rank r to s_idx[r].
+  unsigned short *s_idxF = reinterpret_cast<unsigned short *>(s_part);   // [EF * NT]
+  unsigned short *s_idxB = s_idxF + EF * NT;                             // [EB * NT]
+  const int perF = (((nfs + NWR - 1) / NWR) + 63) & ~63, perB = (((nbs + NWR - 1) / NWR) + 63) & ~63;
+  {
+    int cf = 0, cb = 0;
+    for (int i = wv * perF + lane; i < min((wv + 1) * perF, nfs); i += 64) cf += (!A.front_valid || A.front_valid[fo + i]) ? 1 : 0;
+    for (int i = wv * perB + lane; i < min((wv + 1) * perB, nbs); i += 64) cb += (!A.bird_valid || A.bird_valid[bo + i]) ? 1 : 0;
+    cf = (int)wave_sum((double)cf); cb = (int)wave_sum((double)cb);
+    if (lane == 0) { s_wcnt[0][wv] = cf; s_wcnt[1][wv] = cb; }
+  }
+  __syncthreads();
+  int nf = 0, nb = 0, baseF = 0, baseB = 0;
+#pragma unroll
+  for (int w = 0; w < NWR; w++) {
+    if (w < wv) { baseF += s_wcnt[0][w]; baseB += s_wcnt[1][w]; }
+    nf += s_wcnt[0][w]; nb += s_wcnt[1][w];
+  }
+  if (nf > EF * NT || nb > EB * NT || A.front_stride > 65535 || A.bird_stride > 65535) {
+    // more edges than register slots: the generic schedule, edges read from HBM / L2 (the level bytes take the LDS)
+    __syncthreads();
+    pose_generic<NT>(A, 0, reinterpret_cast<uint8_t *>(s_part), S, s_cnt);
+    return;
+  }
+  if (mode == FB_POSE_BIRD ? nb < 3 : nf < 3) {  // Optimizer.cc:379,607,776
+    // (the edge slots' mvbOutlier entries are still cleared, as the edge construction loop does before the count is known)
+    for (int i = tid; i < nfs; i += NT)
+      if (!A.front_valid || A.front_valid[fo + i]) A.front_outlier[fo + i] = 0;
+    if (tid == 0) A.ninliers[bidx] = 0;
+    return;
+  }
+  for (int i0 = wv * perF; i0 < min((wv + 1) * perF, nfs); i0 += 64) {
+    const int i = i0 + lane;
+    const bool v = i < min((wv + 1) * perF, nfs) && (!A.front_valid || A.front_valid[fo + i]);
+    const unsigned long long m = __ballot(v);
+    if (v) s_idxF[baseF + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (unsigned short)i;
+    baseF += __popcll(m);
+  }
+  for (int i0 = wv * perB; i0 < min((wv + 1) * perB, nbs); i0 += 64) {
+    const int i = i0 + lane;
+    const bool v = i < min((wv + 1) * perB, nbs) && (!A.bird_valid || A.bird_valid[bo + i]);
+    const unsigned long long m = __ballot(v);
+    if (v) s_idxB[baseB + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (unsigned short)i;
+    baseB += __popcll(m);
+  }
+  __syncthreads();
+  // this thread's edges -> registers: edge with rank r = s * NT + tid.  level 0 = active, 1 = outlier level, 2 = no edge
+  // (two bits per slot); fidx / bidx_ = the frame slot the edge came from (where its outlier flag lives)
+  float fx0[EF], fx1[EF], fx2[EF], fo0[EF], fo1[EF], fin[EF];
+  float bx0[EB], bx1[EB], bx2[EB], bc0[EB], bc1[EB], bc2[EB], bin[EB];
+  int fidx[EF], bidx_[EB];
+  unsigned flev = 0, blev = 0, fout = 0, bout = 0;
+#pragma unroll
+  for (int s = 0; s < EF; s++) {
+    const int r = s * NT + tid;
+    const bool v = r < nf;
+    fx0[s] = fx1[s] = fx2[s] = fo0[s] = fo1[s] = fin[s] = 0.f;
+    fidx[s] = 0;
+    if (v) {
+      const int e = s_idxF[r];
+      fidx[s] = e;
+      const float *X = A.front_xw + (fo + e) * 3, *O = A.front_obs + (fo + e) * 2;
+      fx0[s] = X[0]; fx1[s] = X[1]; fx2[s] = X[2]; fo0[s] = O[0]; fo1[s] = O[1];
+      fin[s] = A.front_inv_sigma2[fo + e];
+      A.front_outlier[fo + e] = 0;
+    }
+    flev |= (v ? 0u : 2u) << (2 * s);
+  }
+#pragma unroll
+  for (int s = 0; s < EB; s++) {
+    const int r = s * NT + tid;
+    const bool v = r < nb;
+    bx0[s] = bx1[s] = bx2[s] = bc0[s] = bc1[s] = bc2[s] = bin[s] = 0.f;
+    bidx_[s] = 0;
+    if (v) {
+      const int e = s_idxB[r];
+      bidx_[s] = e;
+      const float *X = A.bird_xw + (bo + e) * 3, *Cc = A.bird_xc + (bo + e) * 3;
+      bx0[s] = X[0]; bx1[s] = X[1]; bx2[s] = X[2]; bc0[s] = Cc[0]; bc1[s] = Cc[1]; bc2[s] = Cc[2];
+      bin[s] = A.bird_inv_sigma2[bo + e];
+      if (A.bird_outlier[bo + e]) bout |= 1u << s;  // the incoming mvBirdOutlier decides which chi2 the first round recomputes
+    }
+    blev |= (v ? 0u : 2u) << (2 * s);
+  }
+  __syncthreads();  // s_idx lives in the buffer the evaluations overwrite
+  const double wf = (mode == FB_POSE_FRONT) ? 1.0 : (double)A.wF, wb = (double)A.wB;
+  const double fx = A.fx, fy = A.fy, cx = A.cx, cy = A.cy;
+  const double delta = (double)(float)sqrt(5.991);
+  const float chi2Mono = (mode == FB_POSE_FRONT) ? 5.991f : 1.5f;
+  const float chi2Bird = 5.991f;
+  if (tid == 0) {
+    S.T = fb::se3_from_float12(Tcw);
+    S.Teval = S.T;
+  }
+  __syncthreads();
+  const fb::SE3 T0 = S.T;
+
+  // one evaluation at pose T: robust chi2 + H + b over this thread's active edges, then the 28 column sums -> S.red
+  auto eval = [&](const fb::SE3 &T, bool robust) {
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = 0;
+    POSE_T0()
+    POSE_COUNT(15)
+#pragma unroll
+    for (int s = 0; s < EF; s++)
+      if (((flev >> (2 * s)) & 3u) == 0u)
+        front_edge_acc(T, fx0[s], fx1[s], fx2[s], fo0[s], fo1[s], (double)fin[s] * wf, robust, delta, fx, fy, cx, cy, acc);
+    POSE_TICK(0)
+#pragma unroll
+    for (int s = 0; s < EB; s++)
+      if (((blev >> (2 * s)) & 3u) == 0u)
+        bird_edge_acc(T, bx0[s], bx1[s], bx2[s], bc0[s], bc1[s], bc2[s], (double)bin[s] * wb, robust, delta, acc);
+    POSE_TICK(1)
+#pragma unroll
+    for (int i = 0; i < NACC; i++) s_part[i * RS + tid] = acc[i];
+    __syncthreads();
+    POSE_TICK(2)
+    if (tid < NACC * CPA) {
+      const int a = tid / CPA, c = tid - a * CPA;
+      const double *row = s_part + a * RS + c;
+      double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+      for (int k = 0; k < 32; k += 4) {
+        s0 += row[(k + 0) * CPA]; s1 += row[(k + 1) * CPA]; s2 += row[(k + 2) * CPA]; s3 += row[(k + 3) * CPA];
+      }
+      double v = (s0 + s1) + (s2 + s3);
+      // the CPA partial sums of accumulator a sit in CPA adjacent lanes of one 16-lane DPP row: shift-add towards the last lane
+      if (CPA == 16) v += dpp_f64<0x118>(v);  // row_shr:8
+      v += dpp_f64<0x114>(v);                 // row_shr:4
+      v += dpp_f64<0x112>(v);                 // row_shr:2
+      v += dpp_f64<0x111>(v);                 // row_shr:1
+      if (c == CPA - 1) S.red[a] = v;
+    }
+    __syncthreads();
+    POSE_TICK(3)
+  };
+
+  int nBad = 0, nBadBird = 0;
+  for (int it = 0; it < 4; it++) {
+    const bool robust = it < 3;
+    if (tid == 0) S.T = T0;
+    bool mine = false;
+#pragma unroll
+    for (int s = 0; s < EF; s++) mine |= ((flev >> (2 * s)) & 3u) == 0u;
+#pragma unroll
+    for (int s = 0; s < EB; s++) mine |= ((blev >> (2 * s)) & 3u) == 0u;
+    const int nact = __syncthreads_count(mine);  // also publishes S.T
+    if (nact > 0) {
+      eval(S.T, robust);
+      if (tid == 0) { unpack_system(S.red, S.H, S.b); S.Teval = S.T; }
+      double currentChi = S.red[0];
+      __syncthreads();
+      double lambda = 0, ni = 2;
+      int nBadLM = 0;
+      for (int iter = 0; iter < 10; iter++) {
+        const double iniChi = currentChi;
+        if (iter == 0) {
+          double m = 0;
+          for (int j = 0; j < 6; j++) m = fmax(fabs(S.H[j * 6 + j]), m);
+          lambda = 1e-5 * m;
+          ni = 2;
+          nBadLM = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+          {
+            POSE_T0()
+            if (tid == 0) {
+              S.ok2 = fb::ldlt6(S.H, lambda, S.b, S.x) ? 1 : 0;
+              POSE_TICK(4)
+              S.Ttrial = se3_mul_fast(se3_exp_direct(S.x), S.T);  // oplus
+              S.Teval = S.Ttrial;
+              POSE_TICK(5)
+            }
+            __syncthreads();
+            POSE_TICK(6)
+          }
+          eval(S.Ttrial, robust);
+          double tempChi = S.red[0];
+          if (!S.ok2) tempChi = 1.7976931348623157e308;
+          rho = currentChi - tempChi;
+          double scale = 0;
+          for (int j = 0; j < 6; j++) scale += S.x[j] * (lambda * S.x[j] + S.b[j]);
+          scale += 1e-3;
+          rho /= scale;
+          const bool accept = rho > 0 && isfinite(tempChi);
+          __syncthreads();  // everyone has read red/x/b
+          if (accept) {
+            double alpha = 1. - pow((2 * rho - 1), 3);
+            alpha = fmin(alpha, 2. / 3.);
+            const double scaleFactor = fmax(1. / 3., alpha);
+            lambda *= scaleFactor;
+            ni = 2;
+            currentChi = tempChi;
+            if (tid == 0) { S.T = S.Ttrial; unpack_system(S.red, S.H, S.b); }
+          } else {
+            lambda *= ni;
+            ni *= 2;
+          }
+          __syncthreads();
+          qmax++;
+        } while (rho < 0 && qmax < 10);
+        if (qmax == 10 || rho == 0) break;
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++;
+        else nBadLM = 0;
+        if (nBadLM >= 3) break;
+      }
+    }
+    // ---- classify (Optimizer.cc:396-431, 627-686, 791-822)
+    POSE_T0()
+    const fb::SE3 T = S.T, Teval = S.Teval;
+    int bad = 0, badb = 0;
+#pragma unroll
+    for (int s = 0; s < EF; s++) {
+      if (((flev >> (2 * s)) & 3u) == 2u) continue;
+      const bool wasOut = (fout >> s) & 1u;
+      const float chi2 = (float)chi2_front_vals(fx0[s], fx1[s], fx2[s], fo0[s], fo1[s], (double)fin[s] * wf, wasOut ? T : Teval, fx, fy, cx, cy);
+      bool isBad;
+      if (mode == FB_POSE_FRONT) isBad = chi2 > chi2Mono;
+      else isBad = chi2 > chi2Mono * ((double)A.wF + 1e-9);
+      A.front_outlier[fo + fidx[s]] = isBad ? 1 : 0;
+      flev = (flev & ~(3u << (2 * s))) | ((isBad ? 1u : 0u) << (2 * s));
+      fout = (fout & ~(1u << s)) | ((isBad ? 1u : 0u) << s);
+      bad += isBad;
+    }
+#pragma unroll
+    for (int s = 0; s < EB; s++) {
+      if (((blev >> (2 * s)) & 3u) == 2u) continue;
+      const bool wasOut = (bout >> s) & 1u;
+      const float chi2 = (float)chi2_bird_vals(bx0[s], bx1[s], bx2[s], bc0[s], bc1[s], bc2[s], (double)bin[s] * wb, wasOut ? T : Teval);
+      const float chi2Bad = (float)(chi2Bird * ((double)A.wB + 1e-9));
+      const bool isBad = chi2 > chi2Bad;
+      A.bird_outlier[bo + bidx_[s]] = isBad ? 1 : 0;
+      blev = (blev & ~(3u << (2 * s))) | ((isBad ? 1u : 0u) << (2 * s));
+      bout = (bout & ~(1u << s)) | ((isBad ? 1u : 0u) << s);
+      badb += isBad;
+    }
+    {
+      // per-wave counts through the ballots of each slot would cost 12 ballots; two wave sums + one LDS hop instead
+      const double sb = wave_sum((double)bad), sbb = wave_sum((double)badb);
+      if ((tid & 63) == 0) { S.part[0][tid >> 6] = sb; S.part[1][tid >> 6] = sbb; }
+      __syncthreads();
+      double tb = 0, tbb = 0;
+      for (int w2 = 0; w2 < NWR; w2++) { tb += S.part[0][w2]; tbb += S.part[1][w2]; }
+      nBad = (int)tb; nBadBird = (int)tbb;
+      __syncthreads();
+    }
+    POSE_TICK(7)
+    if (nf + nb < 10) break;  // optimizer.edges().size()<10
+  }
+  if (tid == 0) {
+    fb::se3_to_float12(S.T, Tcw);
+    A.ninliers[bidx] = (mode == FB_POSE_BIRD) ? nb - nBadBird : nf - nBad;
+  }
+#ifdef FB_POSE_STAMPS
+  if (blockIdx.x == 0 && tid == 0) g_pose_stamps[14] += __builtin_amdgcn_s_memtime() - pose_t_start;
+#endif
 }
 
 // --- device-side edge construction (Optimizer.cc:525-602) --------------------------------
@@ -441,6 +888,25 @@ int fb_pose_opt_batch_dev(const fb_pose_opt_args *A, void *stream) {
   if (A->mode != FB_POSE_FRONT)
     FB_ARG(A->n_bird && A->bird_outlier && (A->bird_stride == 0 || (A->bird_xw && A->bird_xc && A->bird_inv_sigma2)));
   if (A->batch == 0) return FB_OK;
+  // register-resident kernel (k_pose_opt_reg) whenever its in-kernel way out (level bytes of every slot in LDS) fits;
+  // FB_POSE_NT=256 / 0 selects the one-wave-per-SIMD variant / the LDS-staged kernel (measurements only)
+  static const int regNT = [] { const char *e = getenv("FB_POSE_NT"); const int v = e ? atoi(e) : 512; return v == 256 || v == 512 ? v : 0; }();
+  if (regNT) {
+    const size_t lds = (size_t)NACC * (regNT + regNT / 32) * sizeof(double);
+    const size_t flagBytes = ((size_t)((A->front_stride + 15) & ~15)) + ((A->bird_stride + 15) & ~15);
+    if (flagBytes <= lds && A->front_stride <= 65535 && A->bird_stride <= 65535) {
+      fb::ProfScope prof_(fb::P_POSE, fb::as_stream(stream));
+      if (regNT == 512) {
+        FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pose_opt_reg<512, 5, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_pose_opt_reg<512, 5, 3><<<A->batch, 512, lds, fb::as_stream(stream)>>>(*A);
+      } else {
+        FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pose_opt_reg<256, 10, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_pose_opt_reg<256, 10, 6><<<A->batch, 256, lds, fb::as_stream(stream)>>>(*A);
+      }
+      FB_HIP(hipGetLastError());
+      return FB_OK;
+    }
+  }
   const size_t flags = ((size_t)((A->front_stride + 15) & ~15)) + ((A->bird_stride + 15) & ~15);
   const size_t stagedBytes = ((size_t)A->front_stride * 6 + (size_t)A->bird_stride * 7) * 4;
   int staged = 1;
@@ -453,6 +919,17 @@ int fb_pose_opt_batch_dev(const fb_pose_opt_args *A, void *stream) {
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
+
+#ifdef FB_POSE_STAMPS
+// probe build only: copies and clears the 16 phase accumulators
+int fb_pose_debug_stamps(uint64_t *dst16) {
+  unsigned long long h[16], z[16] = {0};
+  FB_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pose_stamps), sizeof(h)));
+  FB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pose_stamps), z, sizeof(z)));
+  for (int i = 0; i < 16; i++) dst16[i] = h[i];
+  return FB_OK;
+}
+#endif
 
 int fb_pose_opt(const fb_pose_opt_args *H) {
   FB_TRY(fb::check_device());
