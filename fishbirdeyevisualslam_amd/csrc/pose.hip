@@ -454,10 +454,96 @@ __device__ __forceinline__ double dpp_f64(double v) {  // v of the lane selected
   return __hiloint2double(hi, lo);
 }
 
+// fp64 reciprocal / reciprocal square root from the hardware seed (v_rcp_f64 / v_rsq_f64) and two Newton steps: 6 instead
+// of the ~35 dependent instructions of the IEEE division sequence, relative error < 2^-50.  Only for the tolerance-held
+// LM evaluations (pose within 1e-4); the inlier / outlier decision keeps true quotients (chi2_*_vals).
+__device__ __forceinline__ double rcp_fast(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double rsqrt_fast(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x, r * r, 1.5);
+  r = r * fma(-0.5 * x, r * r, 1.5);
+  return r;
+}
+// sin and cos of a small angle (|x| <= 0.5: the half angle of an LM step) by their Taylor series to x^17 / x^18
+// (truncation < 1e-19); larger arguments go to the library
+__device__ __forceinline__ void sincos_small(double x, double *s, double *c) {
+  if (fabs(x) > 0.5) { sincos(x, s, c); return; }
+  const double x2 = x * x;
+  double ps = -1.0 / 355687428096000.0;
+  ps = fma(ps, x2, 1.0 / 1307674368000.0);
+  ps = fma(ps, x2, -1.0 / 6227020800.0);
+  ps = fma(ps, x2, 1.0 / 39916800.0);
+  ps = fma(ps, x2, -1.0 / 362880.0);
+  ps = fma(ps, x2, 1.0 / 5040.0);
+  ps = fma(ps, x2, -1.0 / 120.0);
+  ps = fma(ps, x2, 1.0 / 6.0);
+  *s = fma(-(x * x2), ps, x);
+  double pc = 1.0 / 6402373705728000.0;
+  pc = fma(pc, x2, -1.0 / 20922789888000.0);
+  pc = fma(pc, x2, 1.0 / 87178291200.0);
+  pc = fma(pc, x2, -1.0 / 479001600.0);
+  pc = fma(pc, x2, 1.0 / 3628800.0);
+  pc = fma(pc, x2, -1.0 / 40320.0);
+  pc = fma(pc, x2, 1.0 / 720.0);
+  pc = fma(pc, x2, -1.0 / 24.0);
+  pc = fma(pc, x2, 0.5);
+  *c = fma(-x2, pc, 1.0);
+}
+
 __device__ __forceinline__ void quat_normalize_fast(fb::Quat &q) {  // normalizeRotation (se3quat.h:280-285) with one reciprocal
   if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
-  const double inv = 1.0 / sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  const double inv = rsqrt_fast(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
   q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv;
+}
+
+// fb::ldlt6 with the pivots' reciprocals from rcp_fast (this routine is one lane's serial work inside every LM trial)
+__device__ __forceinline__ bool ldlt6_fast(const double H[36], double lambda, const double b[6], double x[6]) {
+  double A[36], d[6], dinv[6], y[6];
+#pragma unroll
+  for (int i = 0; i < 36; i++) A[i] = H[i];
+#pragma unroll
+  for (int j = 0; j < 6; j++) A[j * 6 + j] += lambda;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double dj = A[j * 6 + j];
+#pragma unroll
+    for (int k = 0; k < j; k++) dj -= A[j * 6 + k] * A[j * 6 + k] * d[k];
+    if (dj < 0) ok = false;
+    d[j] = dj;
+    const double inv = dj != 0 ? rcp_fast(dj) : 0.0;
+    dinv[j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      double s = A[i * 6 + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= A[i * 6 + k] * A[j * 6 + k] * d[k];
+      A[i * 6 + j] = s * inv;
+    }
+  }
+  if (!ok) return false;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= A[i * 6 + k] * y[k];
+    y[i] = s;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] = y[i] * dinv[i];
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double s = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) s -= A[k * 6 + i] * x[k];
+    x[i] = s;
+  }
+  return true;
 }
 
 // SE3Quat::exp (se3quat.h:223-257) without the detour over R: q = (sin(t/2) w/t, cos(t/2)), translation V u with
@@ -468,8 +554,8 @@ __device__ __forceinline__ fb::SE3 se3_exp_direct(const double u[6]) {
   const double theta = sqrt(wx * wx + wy * wy + wz * wz);
   if (theta < 0.00001) return fb::se3_exp(u);
   double sh, ch;
-  sincos(0.5 * theta, &sh, &ch);
-  const double it = 1.0 / theta, it2 = it * it;
+  sincos_small(0.5 * theta, &sh, &ch);
+  const double it = rcp_fast(theta), it2 = it * it;
   const double k = sh * it;
   fb::SE3 T;
   T.r.x = wx * k; T.r.y = wy * k; T.r.z = wz * k; T.r.w = ch;
@@ -501,7 +587,7 @@ __device__ __forceinline__ void front_edge_acc(const fb::SE3 &T, float x0, float
   const double Xw[3] = {x0, x1, x2};
   double p[3];
   fb::se3_map(T, Xw, p);
-  const double X = p[0], Y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
+  const double X = p[0], Y = p[1], invz = rcp_fast(p[2]), invz_2 = invz * invz;
   const double err[2] = {(double)o0 - ((X * invz) * fx + cx), (double)o1 - ((Y * invz) * fy + cy)};
   const double J[2][6] = {{X * Y * invz_2 * fx, -(1 + (X * X * invz_2)) * fx, Y * invz * fx, -invz * fx, 0, X * invz_2 * fx},
                           {(1 + Y * Y * invz_2) * fy, -X * Y * invz_2 * fy, -X * invz * fy, 0, -invz * fy, Y * invz_2 * fy}};
@@ -746,7 +832,7 @@ __global__ __launch_bounds__(NT) void k_pose_opt_reg(fb_pose_opt_args A) {
           {
             POSE_T0()
             if (tid == 0) {
-              S.ok2 = fb::ldlt6(S.H, lambda, S.b, S.x) ? 1 : 0;
+              S.ok2 = ldlt6_fast(S.H, lambda, S.b, S.x) ? 1 : 0;
               POSE_TICK(4)
               S.Ttrial = se3_mul_fast(se3_exp_direct(S.x), S.T);  // oplus
               S.Teval = S.Ttrial;
