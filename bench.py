@@ -8,11 +8,24 @@ with ~2k front + ~1k bird edges).  All inputs are resident in HBM before the tim
 For N>1 the driver launches one rank per GPU with torch.distributed.run; every rank processes its
 own batch (independent sequences -> weak scaling, no data-path collective).
 Prints ONE JSON line on rank 0.
+
+What the line carries besides the contract fields:
+  roofline      the dominant kernel of the SINGLE-STREAM pass (every kernel bracketed by HIP events on its launch stream,
+                no overlap: the same ranking `rocprofv3 --kernel-trace --stats` gives), its SURVEY 8(d) algorithmic bytes
+                per launch over its average launch duration inside the timed region; + the whole step against the roof
+  parity_check  the oracle results of the cpu_baseline sample compared with the same entries of the timed GPU batch
+                (key points, descriptors, match indices, outlier masks, inlier counts bit-exact, pose within 1e-4);
+                a mismatch makes the process exit non-zero
+  cpu_baseline  the oracle on 1 core (per-stage medians over >= 50 frames after 5 warm-ups) and as
+                N independent sequences on N cores
+  single_sequence  ms per frame pair at B = 1 and B = 8 (config 5's sequence count) with the same pipeline
 """
 import argparse
 import ctypes as C
 import json
+import multiprocessing as mp
 import os
+import statistics
 import sys
 import time
 
@@ -26,22 +39,23 @@ FRONT_WH, BIRD_WH = (1280, 720), (512, 512)
 P_FRONT, P_BIRD = 2853088, 811960          # sum of pyramid pixels
 PX0 = {"front": 1280 * 720, "bird": 512 * 512}
 PX7 = {"front": 357 * 201, "bird": 143 * 143}
+PAIR_BYTES = 13384242                       # extract, per frame pair: (P - px7) + (P - px0) + 2 P, front + bird
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
 FP64_MFMA_PEAK_TFLOPS = 78.6                # MI355X public spec, FP64 matrix (= FP64 vector); the local guide lists no f64 row
+REL_TOL = 1e-4                              # BASELINE.json north_star: pose within 1e-4 relative
 
 
 def algorithmic_bytes_per_pair():
-    """Per frame pair and kernel: bytes the algorithm must move.  Used for roofline.achieved."""
+    """Per frame pair and kernel (profiler name): bytes the algorithm must move, SURVEY 8(d): every level >= 1 is produced by
+    reading level l-1 and writing level l; every level is read once for FAST and once for blur + descriptor TOGETHER (the
+    blurred image is not re-materialised in the model, although k_blur does write it: that traffic counts against us)."""
     p = {"front": P_FRONT, "bird": P_BIRD}
-    resize = sum((p[k] - PX7[k]) + (p[k] - PX0[k]) for k in p)       # read level l-1, write level l
-    fast = sum(p.values())                                            # every level read once
-    blur = 2 * sum(p.values())                                        # every level read once, blurred level written once
-    describe = 2 * sum(p.values())                                    # raw level (orientation) + blurred level (BRIEF), once each
-    match_front = 32 * 2000 + 32 * 2000 + 16 * 2000 + 8 * 2000        # 184,000 B per 2000x2000 problem
-    match_bird = 32 * 2000 + 32 * 1000 + 16 * 2000 + 8 * 1000
-    pose = 2000 * 24 + 1000 * 28                                      # edge inputs read once (LDS staged)
-    return {"k_resize": resize, "k_fast": fast, "k_blur": blur, "k_describe": describe, "k_proj_frame": match_front,
-            "k_bird_mappoints": match_bird, "k_pose_opt": pose}
+    return {"k_resize": sum((p[k] - PX7[k]) + (p[k] - PX0[k]) for k in p),
+            "k_fast<44>": P_FRONT, "k_fast<56>": P_BIRD,
+            "k_blur+k_describe": P_FRONT + P_BIRD,
+            "k_proj_frame": 32 * 2000 + 32 * 2000 + 16 * 2000 + 8 * 2000,       # 184,000 B per 2000x2000 problem
+            "k_bird_mappoints": 32 * 2000 + 32 * 1000 + 16 * 2000 + 8 * 1000,
+            "k_pose_opt": 2000 * 24 + 1000 * 28}                                # edge inputs, read once
 
 
 def make_images(batch, rank):
@@ -51,64 +65,145 @@ def make_images(batch, rank):
     return f, b
 
 
-def cpu_baseline(front, bird, world, nsample):
-    """Oracle (CPU restatement of the reference path, single thread like the reference) on a bounded sample."""
+STAGES = ("extract_front", "extract_bird", "match_front", "match_bird", "pose_opt")
+
+
+def _cpu_worker(args):
+    """One sequence on one core: `nframes` frame pairs through the oracle (5 warm-ups first).  Runs in its own process for
+    the N-core leg; the images are synthesised in the worker from their seeds (identical bytes as the GPU's)."""
+    seeds, worlds, warm = args[:3]
+    keep = len(args) > 3 and args[3]
+    from fishbirdeyevisualslam_amd import synth
     from oracle import pyoracle as O
     params = O.orb_params()
-    O.frame_pipeline(params, front[0], bird[0], world[0])  # warm-up (page in, build .so)
+    imgs = [(synth.synth_image(1000 + s, *FRONT_WH), synth.synth_image(1500 + s, *BIRD_WH)) for s in seeds]
+    for i in range(warm):
+        O.frame_pipeline(params, imgs[i % len(imgs)][0], imgs[i % len(imgs)][1], worlds[i % len(imgs)])
+    per_frame, stages, results = [], {k: [] for k in STAGES}, []
+    t_all = time.perf_counter()
+    for (f, b), w in zip(imgs, worlds):
+        tm = {}
+        t0 = time.perf_counter()
+        r = O.frame_pipeline(params, f, b, w, timings=tm)
+        per_frame.append(time.perf_counter() - t0)
+        for k in STAGES:
+            stages[k].append(tm[k])
+        if keep:
+            results.append(r)
+    return time.perf_counter() - t_all, per_frame, stages, results
+
+
+def parity_check(refs, fk, fd, bk, bd, res):
+    """The oracle results the cpu_baseline leg computed for the first frame pairs against the same entries of the GPU batch."""
+    bad, worst = [], 0.0
+    nsample = len(refs)
+    for b, ref in enumerate(refs):
+        n, nb = len(ref["fk"]), len(ref["bk"])
+        checks = {
+            "front keypoints": len(fk[b]) == n and np.array_equal(fk[b], ref["fk"]),
+            "front descriptors": len(fd[b]) == n and np.array_equal(fd[b], ref["fd"]),
+            "bird keypoints": len(bk[b]) == nb and np.array_equal(bk[b], ref["bk"]),
+            "bird descriptors": len(bd[b]) == nb and np.array_equal(bd[b], ref["bd"]),
+            "front match indices": np.array_equal(res["m_front"][b, :n], ref["m_front"][:n]),
+            "bird match indices": np.array_equal(res["m_bird"][b, :nb], ref["m_bird"][:nb]),
+            "front outlier mask": np.array_equal(res["front_outlier"][b, :n][ref["fv"] == 1], ref["front_outlier"][:n][ref["fv"] == 1]),
+            "bird outlier mask": np.array_equal(res["bird_outlier"][b, :nb][ref["bv"] == 1], ref["bird_outlier"][:nb][ref["bv"] == 1]),
+            "inlier count": int(res["ninliers"][b]) == ref["ninliers"],
+        }
+        rel = float(np.abs(res["Tcw"][b] - ref["Tcw"]).max() / max(1.0, np.abs(ref["Tcw"]).max()))
+        worst = max(worst, rel)
+        checks["pose within 1e-4"] = rel <= REL_TOL
+        for k, ok in checks.items():
+            if not ok:
+                bad.append("pair %d: %s" % (b, k))
+    return {"pairs": nsample, "mismatches": len(bad), "details": bad[:8], "worst_relative_pose_difference": worst,
+            "checked": "key points + descriptors (front, bird), M3 / M9 match indices, front / bird outlier masks, inlier count: "
+                       "bit-exact; pose <= 1e-4 relative; GPU values are those of the timed batch"}
+
+
+def cpu_baseline(world, nsample, rank, refs_out):
+    """The oracle (CPU restatement of the reference path, compiled -O3 -march=native, single-threaded per frame like the
+    reference) on the host cores of this box: (a) one sequence on one core, per-stage medians; (b) N sequences on N cores."""
+    seeds = [rank * 10000 + i for i in range(nsample)]
+    t1, per_frame, stages, results = _cpu_worker((seeds, world[:nsample], 5, True))
+    refs_out.extend(results)
+    one = {"frames": nsample, "warmup_frames": 5, "seconds": t1, "frames_per_s_mean": nsample / t1,
+           "ms_per_frame_median": statistics.median(per_frame) * 1e3, "ms_per_frame_mean": statistics.mean(per_frame) * 1e3,
+           "stage_ms_median": {k: statistics.median(v) * 1e3 for k, v in stages.items()},
+           "stage_ms_mean": {k: statistics.mean(v) * 1e3 for k, v in stages.items()}}
+    # N sequences on N cores: N = the cores this process may use, at most 16 (the box's CPU share for one GPU)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncore = max(1, min(avail, 16))
+    per = max(10, min(nsample, 24))
+    jobs = [([rank * 10000 + (w * 7 + i) % nsample for i in range(per)], [world[(w * 7 + i) % nsample] for i in range(per)], 2)
+            for w in range(ncore)]
     t0 = time.perf_counter()
-    for i in range(nsample):
-        O.frame_pipeline(params, front[i], bird[i], world[i])
-    dt = time.perf_counter() - t0
-    return {"value": nsample / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frame pairs of the same workload (extract front+bird, grids, M3, M9, PoseOptimizationWithBird), "
-                      "oracle/ C++ -O3 -march=native, 1 thread, %.1f s" % (nsample, dt)}
+    with mp.get_context("spawn").Pool(ncore) as pool:
+        outs = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0
+    busy = max(o[0] for o in outs)  # slowest worker, without process start-up and image synthesis
+    many = {"cores": ncore, "cores_available": avail, "os_cpu_count": os.cpu_count(), "frames_per_sequence": per,
+            "frames_per_s": ncore * per / busy, "wall_s_incl_startup": wall,
+            "note": "N independent sequences, one process per core, timed from each worker's first to last timed frame (slowest worker)"}
+    return {"value": one["frames_per_s_mean"], "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frame pairs of the same workload (extract front+bird, grids, M3, M9, PoseOptimizationWithBird) after 5 warm-ups, "
+                      "oracle/ C++ -O3 -march=native, 1 thread, %.1f s; stage times = inside the oracle's C++ only" % (nsample, t1),
+            "one_core": one, "n_cores": many}
 
 
 def local_ba_leg(L, rank, world_size, local_rank, reps=3):
     """Secondary measurement (not part of `value`): one LocalBundleAdjustmentWithOdom of BASELINE config 4
     (20 keyframes x 8k map points + 2k bird points).  N=1: fb_local_ba; N>1: the same problem landmark-sharded
-    over all ranks (fb_local_ba_sharded, RCCL all-reduce of the reduced normal equations)."""
-    import ctypes as C
+    over all ranks (fb_local_ba_sharded, all-reduce of the reduced normal equations)."""
     import torch
-    from fishbirdeyevisualslam_amd import ba_problem, synth, dist as fbd
+    from fishbirdeyevisualslam_amd import ba_problem, synth, dist as fbd, cabi
     p = synth.make_ba_problem(4000, n_kf=20, n_mp=8000, n_mpb=2000)
     cb = fbd.make_allreduce(stage_device=torch.device("cuda", local_rank)) if world_size > 1 else None
+
+    def run(a):
+        return L.fb_local_ba_sharded(C.byref(a), rank, world_size, cb, None) if world_size > 1 else L.fb_local_ba(C.byref(a))
     times = []
     for _ in range(reps):
         a, out, keep = ba_problem.local_ba_args(p, with_odom=1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        rc = L.fb_local_ba_sharded(C.byref(a), rank, world_size, cb, None) if world_size > 1 else L.fb_local_ba(C.byref(a))
+        rc = run(a)
         dt = time.perf_counter() - t0
         if rc != 0:
             raise RuntimeError(L.fb_last_error().decode())
         times.append(dt)
     res = {"ms_per_ba": sorted(times)[len(times) // 2] * 1e3, "workload": "configs[3]: 20 keyframes x 8000 map points + 2000 bird "
            "points, %d front + %d bird + %d odometry edges" % (len(p["obs_kf"]), len(p["bobs_kf"]), len(p["odom_kf_i"])),
-           "mode": "sharded over %d ranks (landmark partition, all-reduce of S,b,chi2)" % world_size if world_size > 1 else "1 GPU",
-           "includes": "host<->device copies and the host-driven LM loop"}
-    # MFMA utilisation of the Schur kernel (north_star: "MFMA utilisation for J^T J"): one more BA under the event
-    # profiler.  k_ba_schur multiplies dense LDS panels with v_mfma_f64_16x16x4_f64, upper-triangular 16x16 tiles only.
-    from fishbirdeyevisualslam_amd import cabi
+           "mode": ("sharded over %d ranks (landmark partition, all-reduce of S,b,chi2; " % world_size + fbd.TRANSPORT_NOTE + ")") if world_size > 1 else "1 GPU",
+           "includes": "host<->device copies of the graph and the results"}
+    # MFMA utilisation of the Schur kernel (north_star: "MFMA utilisation for J^T J"): one more BA under the event profiler
     a, out, keep = ba_problem.local_ba_args(p, with_odom=1)
     L.fb_prof_reset()
     L.fb_prof_enable(1)
-    rc = L.fb_local_ba_sharded(C.byref(a), rank, world_size, cb, None) if world_size > 1 else L.fb_local_ba(C.byref(a))
+    rc = run(a)
     L.fb_prof_enable(0)
-    ents = (cabi.ProfEntry * 40)()
-    n = L.fb_prof_report(ents, 40)
+    ents = (cabi.ProfEntry * 48)()
+    n = L.fb_prof_report(ents, 48)
     kern = {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n)}
     if rc == 0 and "k_ba_schur" in kern and kern["k_ba_schur"][1] > 0:
-        n_free = int((np.asarray(keep["kf_fixed"] if "kf_fixed" in keep else p["kf_fixed"]) == 0).sum())
+        n_free = int((np.asarray(p["kf_fixed"]) == 0).sum())
         nt = (6 * n_free + 1 + 15) // 16                       # 16x16 tiles per side of the reduced system (+ rhs column)
         n_lm = (len(p["mp_xw"]) + len(p["mpb_xw"]) + world_size - 1) // world_size  # landmarks of this rank
         launches, ms = kern["k_ba_schur"]
-        flop = 2.0 * (nt * (nt + 1) // 2) * 256 * 3 * n_lm      # MFMA flops issued per launch (upper tiles, K = 3 per landmark)
-        tf = flop * launches / (ms * 1e-3) / 1e12
-        res["mfma"] = {"kernel": "k_ba_schur", "dtype": "f64", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "frac": tf / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": ms / launches, "launches_per_ba": launches,
-                       "flop_per_launch": flop, "free_keyframes": n_free, "tiles": nt,
+        issued = 2.0 * (nt * (nt + 1) // 2) * 256 * 3 * n_lm    # MFMA flops issued per launch (upper tiles, K = 3 per landmark)
+        # USEFUL flops: landmark with k observers contributes (6k+1 choose 2 upper) x 3 multiply-adds (SURVEY 8d's Schur term)
+        deg = np.bincount(np.asarray(p["obs_mp"]), minlength=len(p["mp_xw"]))
+        degb = np.bincount(np.asarray(p["bobs_mpb"]), minlength=len(p["mpb_xw"]))
+        rows = np.concatenate([6 * deg + 1, 6 * degb + 1]).astype(np.float64)
+        useful = float((2.0 * 3.0 * rows * (rows + 1) / 2).sum()) / world_size
+        tf_issued = issued * launches / (ms * 1e-3) / 1e12
+        tf_useful = useful * launches / (ms * 1e-3) / 1e12
+        res["mfma"] = {"kernel": "k_ba_schur", "dtype": "f64", "achieved": tf_useful, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": tf_useful / FP64_MFMA_PEAK_TFLOPS, "achieved_issued": tf_issued, "frac_issued": tf_issued / FP64_MFMA_PEAK_TFLOPS,
+                       "avg_launch_ms": ms / launches, "launches_per_ba": launches, "useful_flop_per_launch": useful,
+                       "issued_flop_per_launch": issued, "free_keyframes": n_free, "tiles": nt,
+                       "note": "achieved counts only the block products a landmark's observer set requires (useful flops); "
+                               "achieved_issued counts the zero padding of the dense panels as well",
                        "kernels_ms_per_ba": {k: v[1] for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}}
     if rank == 0 and world_size == 1:
         from oracle import pyoracle as O
@@ -119,7 +214,7 @@ def local_ba_leg(L, rank, world_size, local_rank, reps=3):
     return res
 
 
-def match_pair_rate(pipe, world, kern_serial, B, nprob=4, th=15.0):
+def match_pair_rate(pipe, world, kern_serial, nsteps, B, nprob=4, th=15.0):
     fk, _ = pipe.keypoints_host("front")
     sf = np.array(list(pipe.tables.scale_factor)[: pipe.params.nlevels], np.float32)
     pairs = []
@@ -142,9 +237,30 @@ def match_pair_rate(pipe, world, kern_serial, B, nprob=4, th=15.0):
     per_problem = float(np.mean(pairs))
     ms = kern_serial["k_proj_frame"][1] / kern_serial["k_proj_frame"][0] if "k_proj_frame" in kern_serial else None
     return {"kernel": "k_proj_frame", "descriptor_pairs_per_problem": per_problem, "problems_sampled": len(pairs),
-            "gpairs_per_s_no_overlap": per_problem * B / (ms * 1e-3) / 1e9 if ms else None,
-            "note": "256-bit Hamming distances per second of the front matcher alone (single-stream launch time, per "
-                    "fixed-point round once); window th=15"}
+            "gpairs_per_s_single_stream": per_problem * B / (ms * 1e-3) / 1e9 if ms else None,
+            "note": "256-bit Hamming distances per second of the front matcher alone (single-stream launch time); window th=15"}
+
+
+def single_sequence_leg(Pipeline, rank, local_rank, batches=(1, 8), steps=200, warmup=20):
+    """ms per frame pair when one GPU tracks 1 / 8 sequences (BASELINE config 5 has 8): same pipeline, small batch."""
+    import torch
+    out = {}
+    for b in batches:
+        f, bd = make_images(b, rank)
+        pipe = Pipeline(b, FRONT_WH, BIRD_WH, device="cuda:%d" % local_rank)
+        pipe.set_images(f, bd)
+        pipe.build_world(seed=5000 + rank * 10000)
+        for _ in range(warmup):
+            pipe.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["b%d" % b] = {"ms_per_step": dt / steps * 1e3, "ms_per_pair": dt / steps / b * 1e3, "frames_per_s": b * steps / dt, "steps": steps}
+        pipe.close()
+    return out
 
 
 def main():
@@ -153,8 +269,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frame pairs per step and per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=96, help="frame pairs timed on the host for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=55, help="frame pairs timed on the host for cpu_baseline and checked against the GPU batch (0 = skip)")
     ap.add_argument("--no-ba", action="store_true", help="skip the secondary local-BA measurement")
+    ap.add_argument("--no-single", action="store_true", help="skip the B=1 / B=8 single-sequence sub-results")
     ap.add_argument("--serial", action="store_true", help="single-stream steps (kernels do not overlap; for profiling)")
     a = ap.parse_args()
 
@@ -191,10 +308,10 @@ def main():
     step = pipe.step_serial if a.serial else pipe.step
     for _ in range(a.warmup):
         step()
-    ents = (cabi.ProfEntry * 40)()
+    ents = (cabi.ProfEntry * 48)()
 
     def prof_pass(fn, nsteps):
-        """nsteps untimed steps with every kernel bracketed by HIP events -> {kernel: (launches, total ms)}"""
+        """nsteps untimed steps with every kernel bracketed by HIP events on its launch stream -> {kernel: (launches, total ms)}"""
         torch.cuda.synchronize()
         L.fb_prof_only(None)
         L.fb_prof_reset()
@@ -203,15 +320,18 @@ def main():
             fn()
         torch.cuda.synchronize()
         L.fb_prof_enable(0)
-        n_ = L.fb_prof_report(ents, 40)
+        n_ = L.fb_prof_report(ents, 48)
         return {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n_)}
 
-    # probe (untimed): the same steps with every kernel bracketed, to find the dominant kernel.  Two events per launch
-    # cost ~8 us of stream bubble each, so in the timed region only the dominant kernel stays bracketed.
+    # untimed: single-stream steps with every kernel bracketed -> each kernel's own speed; the dominant kernel is the one
+    # with the largest total there (with three overlapped streams the event times of a kernel include its neighbours)
     PROBE = 3
-    kern_all = prof_pass(step, PROBE)
-    dom = max(kern_all, key=lambda k: kern_all[k][1])
+    kern_serial = prof_pass(pipe.step_serial, PROBE)
+    dom = max(kern_serial, key=lambda k: kern_serial[k][1])
+    for _ in range(2):
+        step()
     barrier()
+    # timed region: only the dominant kernel stays bracketed (two events per launch cost ~8 us of stream bubble each)
     L.fb_prof_only(dom.encode())
     L.fb_prof_reset()
     L.fb_prof_enable(1)
@@ -228,12 +348,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # device time of the dominant kernel over the timed region (HIP events on its launch stream)
-    n = L.fb_prof_report(ents, 40)
+    n = L.fb_prof_report(ents, 48)
     kern = {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n)}
     res = pipe.results_host()
-    # the same kernels without stream overlap (3 single-stream steps, outside the timed region): each kernel's own speed
-    kern_serial = prof_pass(pipe.step_serial, 3)
     ba = None
     if not a.no_ba:
         try:
@@ -241,25 +358,37 @@ def main():
         except Exception as e:  # the secondary leg must never take the headline line down
             ba = {"error": str(e)}
 
+    rc = 0
     if rank == 0:
-        total_ms = sum(v[1] for v in kern_all.values()) / PROBE * a.steps
-        # HBM traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside this process; the
-        # committed profiles/r01_pmc_traffic.json holds the per-launch means of separate PMC passes over this same
-        # workload (profiles/probes/make_summary.py), used only when the batch size matches
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pt = json.load(f)
-            kk = "k_resize_rows" if dom == "k_resize" else dom
-            if pt.get("batch") == B and kk in pt["kernels"]:
-                traffic = pt["kernels"][kk]["fetch_bytes_per_launch"] + pt["kernels"][kk]["write_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            traffic = None
         alg = algorithmic_bytes_per_pair()
+
+        def alg_key(k):  # the byte model lists blur and describe together
+            return "k_blur+k_describe" if k in ("k_blur", "k_describe") else k
+
+        def ser(k):      # (launches, total ms) of a byte-model entry in the single-stream pass
+            if k == "k_blur+k_describe":
+                return (kern_serial["k_blur"][0], kern_serial["k_blur"][1] + kern_serial["k_describe"][1])
+            return kern_serial.get(k)
         launches, ms = kern[dom]
         per_launch_ms = ms / launches
-        alg_per_launch = alg.get(dom, 0) * B * a.steps / launches   # bytes one launch must move, averaged over its launches
-        achieved = alg_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        # bytes ONE launch of the dominant kernel must move = per-pair bytes x B pairs x steps / launches in the timed region
+        alg_per_launch = alg.get(alg_key(dom), 0) * B * a.steps / launches
+        if alg_key(dom) == "k_blur+k_describe":  # the pair shares P: charge the launch with the pair's time
+            other = "k_describe" if dom == "k_blur" else "k_blur"
+            per_launch_model_ms = per_launch_ms + kern_serial[other][1] / kern_serial[other][0]
+        else:
+            per_launch_model_ms = per_launch_ms
+        achieved = alg_per_launch / (per_launch_model_ms * 1e-3) / 1e9 if per_launch_model_ms > 0 else 0.0
+        traffic, traffic_src = None, None
+        try:  # PMC counters cannot be read inside this process: per-launch means of separate rocprofv3 --pmc passes
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+                pt = json.load(f)
+            if pt.get("batch") == B and dom in pt["kernels"]:
+                traffic = pt["kernels"][dom]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/r02_pmc_traffic.json: " + pt.get("method", "")
+        except (OSError, ValueError, KeyError):
+            pass
+        ms_step = elapsed / a.steps * 1e3
         out = {
             "metric": "frames/s (extract+match+pose-opt), 1280x720+512x512 pair",
             "value": world_size * B * a.steps / elapsed,
@@ -267,7 +396,7 @@ def main():
             "n_gpus": world_size,
             "steps": a.steps,
             "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -277,40 +406,55 @@ def main():
                                    "PoseOptimizationWithBird (~2k front + ~1k bird edges)",
                        "frame_pairs_per_step_per_gpu": B, "nfeatures": 2000, "parallelism": "replicas x%d" % world_size},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, raw, mean per launch)" if traffic else None,
-                         "avg_launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": alg_per_launch,
-                         "note": "dominant kernel chosen in an untimed probe pass with every kernel bracketed; in the timed region (3 "
-                                 "concurrent streams) only this kernel carries events; *_no_overlap = same kernel in single-stream steps",
-                         "avg_launch_ms_no_overlap": kern_serial[dom][1] / kern_serial[dom][0],
-                         "achieved_no_overlap": alg.get(dom, 0) * B * 3 / kern_serial[dom][0] / (kern_serial[dom][1] / kern_serial[dom][0] * 1e-3) / 1e9},
-            "kernels_ms_per_step_no_overlap": {k: v[1] / 3 for k, v in sorted(kern_serial.items(), key=lambda kv: -kv[1][1])},
-            "kernels_ms_per_step": {k: v[1] / PROBE for k, v in sorted(kern_all.items(), key=lambda kv: -kv[1][1])},  # probe pass
-            # north_star: "HBM GB/s for matching" -- algorithmic bytes / single-stream kernel time, every kernel with a
-            # SURVEY 8(d) byte count (fraction of the 8 TB/s roof)
-            "hbm_gbs_no_overlap": {k: {"gbs": alg[k] * B * 3 / (kern_serial[k][1] * 1e-3) / 1e9,
-                                       "frac": alg[k] * B * 3 / (kern_serial[k][1] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                                   for k in alg if k in kern_serial and kern_serial[k][1] > 0},
-            "kernel_ms_sum_over_wall": total_ms / (elapsed * 1e3),  # >1: the three streams overlap
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "avg_launch_ms": per_launch_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": alg_per_launch,
+                         "avg_launch_ms_single_stream": kern_serial[dom][1] / kern_serial[dom][0],
+                         "byte_model": "SURVEY 8(d): FAST reads every level once (P); blur + describe share P; resize (P-px7)+(P-px0)",
+                         "note": "dominant kernel = largest total in the untimed single-stream pass (every kernel bracketed by HIP "
+                                 "events on its launch stream); achieved = its algorithmic bytes per launch / its average launch "
+                                 "duration in the timed region, where only this kernel carries events",
+                         "step": {"algorithmic_bytes_per_pair": PAIR_BYTES, "achieved": PAIR_BYTES * B / (ms_step * 1e-3) / 1e9,
+                                  "frac": PAIR_BYTES * B / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
+                                  "note": "whole step: extract bytes of B pairs / ms_per_step"}},
+            "kernels_ms_per_step_single_stream": {k: v[1] / PROBE for k, v in sorted(kern_serial.items(), key=lambda kv: -kv[1][1])},
+            "kernel_ms_sum_single_stream": sum(v[1] for v in kern_serial.values()) / PROBE,
+            # north_star: "HBM GB/s for matching" -- algorithmic bytes / single-stream kernel time for every byte-model entry
+            "hbm_gbs_single_stream": {k: {"gbs": alg[k] * B * PROBE / (ser(k)[1] * 1e-3) / 1e9,
+                                          "frac": alg[k] * B * PROBE / (ser(k)[1] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                      for k in alg if ser(k) and ser(k)[1] > 0},
             "workload_check": {"kps_front": float(res["n_front"].mean()), "kps_bird": float(res["n_bird"].mean()),
                                "front_matches": float(res["nm_front"].mean()), "bird_matches": float(res["nm_bird"].mean()),
                                "pose_inliers": float(res["ninliers"].mean())},
         }
-        # the matchers' integer work = descriptor pairs actually compared.  Counted on the host for the first
-        # problems of the batch with the window rule of SearchByProjection(CurrentFrame, LastFrame) (ORBmatcher.cc:1361-
-        # 1411: radius th * scale[octave], levels octave-1 .. octave+1, |dx|,|dy| < r as GetFeaturesInArea, Frame.cc:498-546)
         try:
-            out["match"] = match_pair_rate(pipe, world, kern_serial, B)
+            out["match"] = match_pair_rate(pipe, world, kern_serial, PROBE, B)
         except Exception as e:  # a reporting extra must never cost the bench line
             out["match"] = {"error": str(e)[:200]}
         out["local_ba"] = ba
-        # the CPU leg is timed on rank 0 of the single-GPU run only (N > 1 would stall the other ranks)
-        out["cpu_baseline"] = cpu_baseline(front, bird, world, min(a.cpu_sample, B)) if (a.cpu_sample > 0 and world_size == 1) else None
+        # the CPU legs run on rank 0 of the single-GPU run only (N > 1 would stall the other ranks)
+        out["cpu_baseline"], out["parity_check"] = None, None
+        if a.cpu_sample > 0 and world_size == 1:
+            ns = min(a.cpu_sample, B)
+            fk, fd = pipe.keypoints_host("front")
+            bk, bd = pipe.keypoints_host("bird")
+            refs = []
+            out["cpu_baseline"] = cpu_baseline(world, ns, rank, refs)
+            out["parity_check"] = parity_check(refs, fk, fd, bk, bd, res)
+            if out["parity_check"]["mismatches"]:
+                rc = 3
+        if not a.no_single and world_size == 1:
+            try:
+                out["single_sequence"] = single_sequence_leg(FramePipeline, rank, local_rank)
+            except Exception as e:
+                out["single_sequence"] = {"error": str(e)[:200]}
         print(json.dumps(out), flush=True)
+        if rc:
+            print("bench.py: GPU results differ from the oracle: %s" % out["parity_check"]["details"], file=sys.stderr, flush=True)
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()
     pipe.close()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -26,6 +26,7 @@
 #include "fb_se3.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 
 namespace {
@@ -73,6 +74,16 @@ struct State {
   SE3 *pose;     // [n_kf]
   double *pt;    // [npt][3]
 };
+
+// reciprocal from the hardware seed + two Newton steps (relative error < 2^-50) for the pivots of the reduced pose system:
+// the BA is held to 1e-4 on poses and landmarks, and an IEEE division is ~35 dependent instructions on the critical path
+// of every block step of k_ba_solve
+__device__ __forceinline__ double ba_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
 
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -152,9 +163,9 @@ __device__ __forceinline__ void edge_jacobians(const BADev &D, int type, const S
 // ------------------------------------------------------------------------------------------
 // k_ba_linearize: one lane per landmark
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BADev D, State S, LinBuf B, int robust) {
-  __shared__ double s_part[LIN_THREADS / 64];
-  const int l = blockIdx.x * LIN_THREADS + threadIdx.x;
+template <int TH>
+__device__ __forceinline__ void linearize_body(const BADev &D, const State &S, const LinBuf &B, int robust, double *s_part) {
+  const int l = blockIdx.x * TH + threadIdx.x;
   double chi = 0;
   if (l < D.npt) {
     const double X[3] = {S.pt[3 * l], S.pt[3 * l + 1], S.pt[3 * l + 2]};
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BADev D, State S, 
   __syncthreads();
   if (threadIdx.x == 0) {
     double s = 0;
-    for (int i = 0; i < LIN_THREADS / 64; i++) s += s_part[i];
+    for (int i = 0; i < TH / 64; i++) s += s_part[i];
     B.chiPart[blockIdx.x] = s;
   }
 }
@@ -255,13 +266,15 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BADev D, State S, 
 // ------------------------------------------------------------------------------------------
 // k_ba_pose: one workgroup per free keyframe -> Hpp(k,k) and bp(k)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(POSE_THREADS) void k_ba_pose(BADev D, State S, LinBuf B, int robust, int P6) {
-  __shared__ double s_part[POSE_THREADS / 64][27];
-  const int k = blockIdx.x, tid = threadIdx.x;
+// part / nparts: this workgroup sums every nparts-th edge of key frame k starting at `part`; partOut != nullptr: the 27 sums
+// (21 upper Hpp entries, 6 bp) go to partOut instead of Hpp / bp (k_ba_control adds the parts in order)
+__device__ __forceinline__ void pose_body(const BADev &D, const State &S, const LinBuf &B, int robust, int P6, double (*s_part)[27], int k,
+                                          int part = 0, int nparts = 1, double *partOut = nullptr) {
+  const int tid = threadIdx.x;
   double acc[27];
 #pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0;
-  for (int c = D.ps_start[k] + tid; c < D.ps_start[k + 1]; c += POSE_THREADS) {
+  for (int c = D.ps_start[k] + part * POSE_THREADS + tid; c < D.ps_start[k + 1]; c += nparts * POSE_THREADS) {
     const int e = D.ps_edges[c];
     if (D.e_level[e] != 0) continue;
     const int type = D.e_type[e], l = D.e_pt[e];
@@ -311,6 +324,10 @@ __global__ __launch_bounds__(POSE_THREADS) void k_ba_pose(BADev D, State S, LinB
     s_part[0][tid] = s;
   }
   __syncthreads();
+  if (partOut) {
+    if (tid < 27) partOut[tid] = s_part[0][tid];
+    return;
+  }
   if (tid < 36) {
     const int i = tid / 6, j = tid % 6;
     const int a = i < j ? i : j, b2 = i < j ? j : i;
@@ -328,10 +345,8 @@ __global__ __launch_bounds__(POSE_THREADS) void k_ba_pose(BADev D, State S, LinB
 struct OdomLin { double A[36], Bm[36], err[6]; };
 
 template <bool GLOBAL>  // GLOBAL: the per-edge linearisations live in HBM scratch (they do not fit LDS)
-__global__ __launch_bounds__(256) void k_ba_odom(BADev D, State S, LinBuf B, int P6, int chiSlot, OdomLin *olGlobal) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  OdomLin *ol = GLOBAL ? olGlobal : reinterpret_cast<OdomLin *>(smem);
-  __shared__ double s_chi[256];
+__device__ __forceinline__ void odom_body(const BADev &D, const State &S, const LinBuf &B, int P6, int chiSlot, OdomLin *ol, double *s_chi,
+                                          double *Hout, double *bout, bool zeroFirst) {
   const int tid = threadIdx.x;
   double chi = 0;
   for (int e = tid; e < D.nO; e += 256) {
@@ -381,6 +396,10 @@ __global__ __launch_bounds__(256) void k_ba_odom(BADev D, State S, LinBuf B, int
   // phase b: lane (k, i) = row i of free pose k
   for (int row = tid; row < P6; row += 256) {
     const int k = row / 6, i = row % 6;
+    if (zeroFirst) {  // Hout / bout are this kernel's own scratch (merged into Hpp / bp by k_ba_control)
+      for (int j = 0; j < P6; j++) Hout[(size_t)row * P6 + j] = 0;
+      bout[row] = 0;
+    }
     for (int cc = D.od_start[k]; cc < D.od_start[k + 1]; cc++) {  // incident edges only, in edge order
       const int e = D.od_edges[cc];
       const int pi = D.poseIdx[D.o_i[e]], pj = D.poseIdx[D.o_j[e]];
@@ -390,7 +409,7 @@ __global__ __launch_bounds__(256) void k_ba_odom(BADev D, State S, LinBuf B, int
       const double *Mine = (pi == k) ? o.A : o.Bm;
       double bsum = 0;
       for (int r = 0; r < 6; r++) bsum += Mine[r * 6 + i] * (-(info * o.err[r]));
-      B.bp[row] += bsum;
+      bout[row] += bsum;
       for (int side = 0; side < 2; side++) {
         const int pc = side == 0 ? pi : pj;
         if (pc < 0) continue;
@@ -398,13 +417,13 @@ __global__ __launch_bounds__(256) void k_ba_odom(BADev D, State S, LinBuf B, int
         for (int j = 0; j < 6; j++) {
           double s = 0;
           for (int r = 0; r < 6; r++) s += Mine[r * 6 + i] * info * Oth[r * 6 + j];
-          B.Hpp[(size_t)row * P6 + 6 * pc + j] += s;
+          Hout[(size_t)row * P6 + 6 * pc + j] += s;
         }
       }
       if (pi == k && pj == k) {  // degenerate self edge: also the Bm rows
         double b2 = 0;
         for (int r = 0; r < 6; r++) b2 += o.Bm[r * 6 + i] * (-(info * o.err[r]));
-        B.bp[row] += b2;
+        bout[row] += b2;
       }
     }
   }
@@ -421,9 +440,8 @@ __global__ __launch_bounds__(256) void k_ba_odom(BADev D, State S, LinBuf B, int
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 template <int MAXT>  // accumulator tiles per wave (compile-time so the C tiles stay in registers)
-__global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BADev D, LinBuf B, double lambda, double *Dinv, double *Spart,
-                                                            int P6, int NT, int lmPerWg) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+__device__ __forceinline__ void schur_body(const BADev &D, const LinBuf &B, double lambda, double *Dinv, double *Spart,
+                                           int P6, int NT, int lmPerWg, uint8_t *smem) {
   const int rows = NT * 16;
   double *Yp = reinterpret_cast<double *>(smem);  // [rows][KPAD]
   double *Wp = Yp + (size_t)rows * KPAD;           // [rows][KPAD]
@@ -540,13 +558,13 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BADev D, LinBuf B, d
 // ------------------------------------------------------------------------------------------
 // k_ba_solve: reduce partials, S = Hpp + lambda I - sum, LDL^T (no pivoting) and solves.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lambda, const double *Spart, int nWg, int P6,
-                                                            int NT, double *xp, double *okFlag) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// HppO != nullptr: the dense Hpp is not materialised: B.Hpp holds the key frames' diagonal blocks only and HppO the
+// odometry (pose-pose) blocks (device-resident schedule)
+__device__ __forceinline__ void solve_body(const LinBuf &B, double lambda, const double *Spart, int nWg, int P6,
+                                           int NT, double *xp, double *okFlag, uint8_t *smem, int &s_ok, const double *HppO = nullptr) {
   double *A = reinterpret_cast<double *>(smem);  // [P6][P6+1] lower triangle used
   const int ld = P6 + 1;
   double *rhs = A + (size_t)P6 * ld;             // [P6]
-  __shared__ int s_ok;
   const int tid = threadIdx.x, rows = NT * 16;
   if (tid == 0) s_ok = 1;
   for (int idx = tid; idx < P6 * P6; idx += SOLVE_THREADS) {
@@ -554,7 +572,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lam
     if (j > i) continue;  // lower triangle: A[i][j] = S[j][i] (upper, as g2o's solver reads it)
     double s = 0;
     for (int w = 0; w < nWg; w++) s += Spart[(size_t)w * rows * rows + (size_t)j * rows + i];
-    double h = B.Hpp[(size_t)j * P6 + i];
+    double h;
+    if (HppO) h = (i / 6 == j / 6 ? B.Hpp[(size_t)j * P6 + i] : 0.0) + HppO[(size_t)j * P6 + i];
+    else h = B.Hpp[(size_t)j * P6 + i];
     if (i == j) h += lambda;
     A[(size_t)i * ld + j] = h - s;
   }
@@ -585,7 +605,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lam
       for (int m = 0; m < c; m++) dc -= Lb[c][m] * Lb[c][m] * d[m];
       if (dc < 0) neg = true;
       d[c] = dc;
-      const double inv = dc != 0 ? 1.0 / dc : 0.0;
+      const double inv = dc != 0 ? ba_rcp(dc) : 0.0;
       dinv[c] = inv;
 #pragma unroll
       for (int r = c + 1; r < 6; r++) {
@@ -660,7 +680,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lam
   }
   for (int i = tid; i < P6; i += SOLVE_THREADS) {  // D^-1
     const double dd = A[(size_t)i * ld + i];
-    rhs[i] = dd != 0 ? rhs[i] / dd : 0.0;
+    rhs[i] = dd != 0 ? rhs[i] * ba_rcp(dd) : 0.0;
   }
   __syncthreads();
   for (int J = nb6 - 1; J >= 0; J--) {  // backward: L^T x = y
@@ -689,11 +709,160 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lam
 }
 
 // ------------------------------------------------------------------------------------------
+// solve_lookahead: the same LDL^T (6x6 blocks, no pivoting, fails on a negative pivot) arranged for latency -- this one
+// workgroup sits on the critical path of every LM trial.
+//  * the right-hand side rides along as row P6 of the matrix: its panel steps ARE the forward substitution, so after the
+//    factorisation row P6 holds z = D^-1 L^-1 b and only the backward substitution remains;
+//  * look-ahead: in the trailing update of step J wave 0 updates only the NEXT diagonal block, factors it (a chain of ~100
+//    dependent fp64 operations) and publishes L, d, 1/d through LDS, while the other three waves update the rest of the
+//    trailing matrix; every thread used to factor the block redundantly BETWEEN the barriers;
+//  * two barriers per key frame instead of three.
+// HppO as in solve_body.
+__device__ __forceinline__ void solve_lookahead(const LinBuf &B, double lambda, const double *Spart, int P6, int NT, double *xp, double *okFlag,
+                                                uint8_t *smem, int &s_ok, const double *HppO) {
+  const int ld = P6 + 1, rows = NT * 16, tid = threadIdx.x;
+  double *A = reinterpret_cast<double *>(smem);   // [P6 + 1][ld], lower triangle; row P6 = right-hand side
+  double *Up = A + (size_t)(P6 + 1) * ld;         // [P6 + 1][6] panel u = l * d of the current step
+  double *fact = Up + (size_t)(P6 + 1) * 6;       // 36 L (row-major, lower) | 6 d | 6 1/d of the current diagonal block
+  double *rhs = fact + 48;                        // [P6] backward substitution
+  if (tid == 0) s_ok = 1;
+  for (int idx = tid; idx < P6 * P6; idx += SOLVE_THREADS) {
+    const int i = idx / P6, j = idx - i * P6;
+    if (j > i) continue;  // lower triangle: A[i][j] = S[j][i] (upper, as g2o's solver reads it)
+    double h = (i / 6 == j / 6 ? B.Hpp[(size_t)j * P6 + i] : 0.0) + HppO[(size_t)j * P6 + i];
+    if (i == j) h += lambda;
+    A[(size_t)i * ld + j] = h - Spart[(size_t)j * rows + i];
+  }
+  for (int i = tid; i < P6; i += SOLVE_THREADS) A[(size_t)P6 * ld + i] = B.bp[i] - Spart[(size_t)i * rows + P6];
+  __syncthreads();
+  const int nb6 = P6 / 6;
+  // factor the 6x6 diagonal block at c0 (wave-redundant in registers), lane `wlane` 0 publishes it
+  auto factor_block = [&](int c0) {
+    double Lb[6][6], d[6], dinv[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c <= r; c++) Lb[r][c] = A[(size_t)(c0 + r) * ld + c0 + c];
+    bool neg = false;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      double dc = Lb[c][c];
+#pragma unroll
+      for (int m = 0; m < c; m++) dc -= Lb[c][m] * Lb[c][m] * d[m];
+      if (dc < 0) neg = true;
+      d[c] = dc;
+      const double inv = dc != 0 ? ba_rcp(dc) : 0.0;
+      dinv[c] = inv;
+#pragma unroll
+      for (int r = c + 1; r < 6; r++) {
+        double v = Lb[r][c];
+#pragma unroll
+        for (int m = 0; m < c; m++) v -= Lb[r][m] * Lb[c][m] * d[m];
+        Lb[r][c] = v * inv;
+      }
+    }
+    if ((tid & 63) == 0) {
+      if (neg) s_ok = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        A[(size_t)(c0 + r) * ld + c0 + r] = d[r];
+        fact[36 + r] = d[r];
+        fact[42 + r] = dinv[r];
+#pragma unroll
+        for (int c = 0; c < r; c++) { A[(size_t)(c0 + r) * ld + c0 + c] = Lb[r][c]; fact[r * 6 + c] = Lb[r][c]; }
+      }
+    }
+  };
+  if (tid < 64 && nb6 > 0) factor_block(0);
+  __syncthreads();
+  for (int J = 0; J < nb6; J++) {
+    const int c0 = 6 * J, c1 = c0 + 6;
+    double Lb[6][6], dinv[6];
+#pragma unroll
+    for (int r = 1; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < r; c++) Lb[r][c] = fact[r * 6 + c];
+#pragma unroll
+    for (int c = 0; c < 6; c++) dinv[c] = fact[42 + c];
+    for (int i = c1 + tid; i <= P6; i += SOLVE_THREADS) {  // panel: row i of L below the block (row P6: forward substitution)
+      double u[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double v = A[(size_t)i * ld + c0 + c];
+#pragma unroll
+        for (int m = 0; m < c; m++) v -= u[m] * Lb[c][m];
+        u[c] = v;
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        Up[(size_t)i * 6 + c] = u[c];
+        A[(size_t)i * ld + c0 + c] = u[c] * dinv[c];  // dinv = 0 for a zero pivot
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {  // wave 0: the next diagonal block first, then its factorisation
+      if (c1 < P6) {
+        if (tid < 21) {
+          int r = 0, rem = tid;
+          while (rem > r) { rem -= r + 1; r++; }  // tid -> (r, cc), cc <= r
+          const int i = c1 + r, k = c1 + rem;
+          double acc2 = 0;
+#pragma unroll
+          for (int c = 0; c < 6; c++) acc2 += Up[(size_t)i * 6 + c] * A[(size_t)k * ld + c0 + c];
+          A[(size_t)i * ld + k] -= acc2;
+        }
+        factor_block(c1);
+      }
+    } else {  // waves 1..3: the rest of the trailing matrix, rows c1 + 6 .. P6 (row P6: columns < P6)
+      const int q = tid - 64, tr = q >> 4, tc = q & 15;
+      for (int i = c1 + 6 + tr; i <= P6; i += (SOLVE_THREADS - 64) / 16) {
+        double u[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) u[c] = Up[(size_t)i * 6 + c];
+        const int kEnd = i < P6 ? i : P6 - 1;
+        for (int k = c1 + tc; k <= kEnd; k += 16) {
+          double acc2 = 0;
+#pragma unroll
+          for (int c = 0; c < 6; c++) acc2 += u[c] * A[(size_t)k * ld + c0 + c];
+          A[(size_t)i * ld + k] -= acc2;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // row P6 now holds z = D^-1 L^-1 b
+  for (int i = tid; i < P6; i += SOLVE_THREADS) rhs[i] = A[(size_t)P6 * ld + i];
+  __syncthreads();
+  for (int J = nb6 - 1; J >= 0; J--) {  // backward: L^T x = z
+    const int c0 = 6 * J;
+    double xJ[6];
+#pragma unroll
+    for (int r = 5; r >= 0; r--) {
+      double v = rhs[c0 + r];
+#pragma unroll
+      for (int m = 5; m > r; m--) v -= A[(size_t)(c0 + m) * ld + c0 + r] * xJ[m];
+      xJ[r] = v;
+    }
+    __syncthreads();
+    if (tid < 6) rhs[c0 + tid] = xJ[tid];
+    for (int i = tid; i < c0; i += SOLVE_THREADS) {
+      double v = rhs[i];
+#pragma unroll
+      for (int c = 0; c < 6; c++) v -= A[(size_t)(c0 + c) * ld + i] * xJ[c];
+      rhs[i] = v;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < P6; i += SOLVE_THREADS) xp[i] = rhs[i];
+  __syncthreads();
+  if (tid == 0) *okFlag = s_ok ? 1.0 : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
 // k_ba_update: back-substitution, trial state, scale term sum x (lambda x + b)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LIN_THREADS) void k_ba_update(BADev D, LinBuf B, State cur, State trial, const double *Dinv,
-                                                           const double *xp, double lambda, double *scalePart, int countPoses) {
-  __shared__ double s_part[LIN_THREADS / 64];
+__device__ __forceinline__ void update_body(const BADev &D, const LinBuf &B, const State &cur, const State &trial, const double *Dinv,
+                                            const double *xp, double lambda, double *scalePart, int countPoses, double *s_part) {
   const int g = blockIdx.x * LIN_THREADS + threadIdx.x;
   double sc = 0;
   if (g < D.npt) {
@@ -738,13 +907,20 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_update(BADev D, LinBuf B, St
 }
 
 // Spart[0] = sum over the workgroup partials (sharded BA: the local sum that goes through the all-reduce)
-__global__ void k_ba_sumparts(double *Spart, int nWg, int n) {
+__device__ __forceinline__ void sumparts_body(double *Spart, int nWg, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  double s = 0;
-  for (int w = 0; w < nWg; w++) s += Spart[(size_t)w * n + i];
-  Spart[i] = s;
+  // 8 independent chains: a single running sum serialises nWg memory latencies per thread
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int w = 0;
+  for (; w + 8 <= nWg; w += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) a[u] += Spart[(size_t)(w + u) * n + i];
+  }
+  for (; w < nWg; w++) a[0] += Spart[(size_t)w * n + i];
+  Spart[i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
+__global__ void k_ba_sumparts(double *Spart, int nWg, int n) { sumparts_body(Spart, nWg, n); }
 
 // sum of partials in index order + max |diag| (computeLambdaInit)
 __global__ void k_ba_scalars(const double *part, int n, const double *Hpp, int P6, const double *Hll, int npt, double *out,
@@ -772,9 +948,7 @@ __global__ void k_ba_scalars(const double *part, int n, const double *Hpp, int P
 
 // gating between the two optimisation rounds and the final outlier flags
 // (Optimizer.cc:1059-1073,1102-1115 / 2534-2565,2573-2607)
-__global__ void k_ba_gate(BADev D, State S, int setLevel, uint8_t *outFlag) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= D.nE) return;
+__device__ __forceinline__ void gate_edge(const BADev &D, const State &S, int setLevel, uint8_t *outFlag, int e) {
   if (D.e_level[e] == 2) {  // edge owned by another rank of a sharded BA
     if (!setLevel) outFlag[e] = 0;
     return;
@@ -801,7 +975,230 @@ __global__ void k_ba_gate(BADev D, State S, int setLevel, uint8_t *outFlag) {
   else outFlag[e] = bad ? 1 : 0;
 }
 
+// ---- __global__ entry points of the bodies above: explicit arguments (host-driven Levenberg-Marquardt: sharded BA, the
+//      HBM-resident reduced system of ba_big.inc, FB_BA_TRACE) ---------------------------------------------------------
+__global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BADev D, State S, LinBuf B, int robust) {
+  __shared__ double s_part[LIN_THREADS / 64];
+  linearize_body<LIN_THREADS>(D, S, B, robust, s_part);
+}
+__global__ __launch_bounds__(POSE_THREADS) void k_ba_pose(BADev D, State S, LinBuf B, int robust, int P6) {
+  __shared__ double s_part[POSE_THREADS / 64][27];
+  pose_body(D, S, B, robust, P6, s_part, blockIdx.x);
+}
+template <bool GLOBAL>
+__global__ __launch_bounds__(256) void k_ba_odom(BADev D, State S, LinBuf B, int P6, int chiSlot, OdomLin *olGlobal) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ double s_chi[256];
+  odom_body<GLOBAL>(D, S, B, P6, chiSlot, GLOBAL ? olGlobal : reinterpret_cast<OdomLin *>(smem), s_chi, B.Hpp, B.bp, false);
+}
+template <int MAXT>
+__global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BADev D, LinBuf B, double lambda, double *Dinv, double *Spart, int P6, int NT, int lmPerWg) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  schur_body<MAXT>(D, B, lambda, Dinv, Spart, P6, NT, lmPerWg, smem);
+}
+__global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(LinBuf B, double lambda, const double *Spart, int nWg, int P6, int NT, double *xp, double *okFlag) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ int s_ok;
+  solve_body(B, lambda, Spart, nWg, P6, NT, xp, okFlag, smem, s_ok);
+}
+__global__ __launch_bounds__(LIN_THREADS) void k_ba_update(BADev D, LinBuf B, State cur, State trial, const double *Dinv, const double *xp, double lambda,
+                                                           double *scalePart, int countPoses) {
+  __shared__ double s_part[LIN_THREADS / 64];
+  update_body(D, B, cur, trial, Dinv, xp, lambda, scalePart, countPoses, s_part);
+}
+__global__ void k_ba_gate(BADev D, State S, int setLevel, uint8_t *outFlag) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < D.nE) gate_edge(D, S, setLevel, outFlag, e);
+}
+
+// ---- device-resident Levenberg-Marquardt ------------------------------------------------------------------------------
+// The accept / reject logic of OptimizationAlgorithmLevenberg::solve (optimization_algorithm_levenberg.cpp:61-164), the
+// iteration loop of SparseOptimizer::optimize and the two-stage schedule of LocalBundleAdjustment[WithOdom]
+// (Optimizer.cc:2504-2570: optimize(5) with kernels, chi2 gate, optimize(10) without) live in BACtl in device memory.  The
+// host enqueues identical "slots" of kernels without reading anything back; every kernel of a slot looks at BACtl and
+// does nothing once the schedule has finished.  A slot is either the linearisation that opens an optimize() (needInit:
+// chi2_0, lambda_0 = 1e-5 max diag) or one LM trial: Schur + solve at (cur, lambda) -> trial state -> its linearisation ->
+// k_ba_control decides.  pbStopFlag: the host writes `abort` from a side stream while it waits.
+struct BACtl {
+  double lambda, ni, currentChi, iniChi;
+  int phase;     // 0 = first optimize(), 1 = second optimize() (after the chi2 gate), 2 = finished
+  int it, qmax, nBad;
+  int cur;       // index of the accepted state and of its linearisation
+  int needInit;  // this slot linearises the accepted state instead of running a trial
+  int needGate;  // this slot starts with the chi2 gate
+  int abort;     // terminate(): set by the host when it sees *pbStopFlag
+  int trials, slots;
+};
+struct BASched { int its1, robust1, gate, its2; };
+struct St2 { State s[2]; };
+struct Lb2 { LinBuf b[2]; };
+
+template <int MAXT>
+__global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur_c(BADev D, Lb2 lb, const BACtl *c, double *Dinv, double *Spart, int P6, int NT, int lmPerWg) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (c->phase == 2 || c->needInit) return;
+  schur_body<MAXT>(D, lb.b[c->cur], c->lambda, Dinv, Spart, P6, NT, lmPerWg, smem);
+}
+__global__ void k_ba_sumparts_c(const BACtl *c, double *Spart, int nWg, int n) {
+  if (c->phase == 2 || c->needInit) return;
+  sumparts_body(Spart, nWg, n);
+}
+__global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve_c(Lb2 lb, const BACtl *c, const double *Spart, int P6, int NT, double *xp, double *okFlag,
+                                                              const double *HppO2) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ int s_ok;
+  if (c->phase == 2 || c->needInit) return;
+  solve_lookahead(lb.b[c->cur], c->lambda, Spart, P6, NT, xp, okFlag, smem, s_ok, HppO2 + (size_t)c->cur * ((size_t)P6 * P6 + P6));
+}
+__global__ __launch_bounds__(LIN_THREADS) void k_ba_update_c(BADev D, Lb2 lb, St2 st, const BACtl *c, const double *Dinv, const double *xp, double *scalePart) {
+  __shared__ double s_part[LIN_THREADS / 64];
+  if (c->phase == 2) return;
+  if (c->needInit) {
+    if (c->needGate)  // edges beyond chi2 5.991 (or behind the camera) go to level 1 (Optimizer.cc:1059-1073 / 2534-2565)
+      for (int e = blockIdx.x * LIN_THREADS + threadIdx.x; e < D.nE; e += gridDim.x * LIN_THREADS) gate_edge(D, st.s[c->cur], 1, nullptr, e);
+    return;
+  }
+  update_body(D, lb.b[c->cur], st.s[c->cur], st.s[1 - c->cur], Dinv, xp, c->lambda, scalePart, 1, s_part);
+}
+// The linearisation of a slot as ONE launch of 256-thread workgroups with three roles (they are independent of each
+// other): blocks [0, nLin) = landmarks (Hll, bl, W, chi2); the next POSE_PARTS * np blocks = a quarter of the edges of one
+// free key frame each (27 partial sums of its Hpp diagonal block and bp); the last block = the odometry edges (their
+// pose-pose blocks HppO, bpO).  The dense Hpp is never materialised: k_ba_control adds the key-frame parts into the diagonal
+// blocks and bp, k_ba_solve reads diagonal blocks + HppO.  Scratch per linearisation buffer t: [HppO | bpO], poseP.
+constexpr int POSE_PARTS = 4;
+template <bool GLOBAL>
+__global__ __launch_bounds__(256) void k_ba_lin_c(BADev D, St2 st, Lb2 lb, const BACtl *c, BASched sc, int P6, int nLin, int chiSlot, OdomLin *olGlobal,
+                                                  double *HppO2, double *poseP2) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ double s_buf[256];
+  if (c->phase == 2) return;
+  const int t = c->needInit ? c->cur : 1 - c->cur;
+  const int robust = c->phase == 0 ? sc.robust1 : 0;
+  const int bx = blockIdx.x;
+  if (bx < nLin) {
+    linearize_body<256>(D, st.s[t], lb.b[t], robust, s_buf);
+  } else if (bx < nLin + POSE_PARTS * D.np) {
+    const int q = bx - nLin, k = q / POSE_PARTS, part = q - k * POSE_PARTS;
+    pose_body(D, st.s[t], lb.b[t], robust, P6, reinterpret_cast<double(*)[27]>(s_buf), k, part, POSE_PARTS,
+              poseP2 + ((size_t)t * D.np * POSE_PARTS + q) * 27);
+  } else {
+    double *HppO = HppO2 + (size_t)t * ((size_t)P6 * P6 + P6);
+    odom_body<GLOBAL>(D, st.s[t], lb.b[t], P6, chiSlot, GLOBAL ? olGlobal : reinterpret_cast<OdomLin *>(smem), s_buf, HppO, HppO + (size_t)P6 * P6, true);
+  }
+}
+
+// The decision at the end of a slot (one workgroup): assemble the key frames' diagonal blocks and bp from the parts, sum the
+// chi2 / scale partials in index order (thread 0, from LDS), maximum of the diagonal (computeLambdaInit,
+// optimization_algorithm_levenberg.cpp:166-180), then the LM state machine.
+__global__ __launch_bounds__(256) void k_ba_control(BADev D, Lb2 lb, BACtl *c, BASched sc, int nLin, int chiSlot, const double *scalePart, int nScale,
+                                                    const double *okFlag, int P6, const double *HppO2, const double *poseP2) {
+  __shared__ double s_m[256];
+  __shared__ double s_chiP[512], s_scaleP[512];
+  const int tid = threadIdx.x;
+  if (c->phase == 2) { if (tid == 0) c->slots++; return; }
+  const int init = c->needInit;
+  const int t = init ? c->cur : 1 - c->cur;
+  const LinBuf &B = lb.b[t];
+  const double *HppO = HppO2 + (size_t)t * ((size_t)P6 * P6 + P6), *bpO = HppO + (size_t)P6 * P6;
+  const double *poseP = poseP2 + (size_t)t * D.np * POSE_PARTS * 27;
+  double m = 0;
+  for (int idx = tid; idx < D.np * 42; idx += 256) {  // 36 block entries + 6 bp entries per key frame
+    const int k = idx / 42, r = idx - k * 42;
+    const double *pp = poseP + (size_t)k * POSE_PARTS * 27;
+    if (r < 36) {
+      const int i = r / 6, j = r % 6;
+      const int a = i < j ? i : j, b2 = i < j ? j : i;
+      const int u = a * 6 - a * (a - 1) / 2 + (b2 - a);  // upper-triangular packing
+      double v = 0;
+      for (int q = 0; q < POSE_PARTS; q++) v += pp[q * 27 + u];
+      B.Hpp[(size_t)(6 * k + i) * P6 + 6 * k + j] = v;
+      if (i == j && init) m = fmax(m, fabs(v + HppO[(size_t)(6 * k + i) * P6 + 6 * k + i]));
+    } else {
+      const int i = r - 36;
+      double v = 0;
+      for (int q = 0; q < POSE_PARTS; q++) v += pp[q * 27 + 21 + i];
+      B.bp[6 * k + i] = v + bpO[6 * k + i];
+    }
+  }
+  for (int i = tid; i < min(nLin, 512); i += 256) s_chiP[i] = B.chiPart[i];
+  if (!init) for (int i = tid; i < min(nScale, 512); i += 256) s_scaleP[i] = scalePart[i];
+  if (init) for (int i = tid; i < D.npt * 3; i += 256) m = fmax(m, fabs(B.Hll[(size_t)9 * (i / 3) + 4 * (i % 3)]));
+  s_m[tid] = m;
+  __syncthreads();
+  if (tid != 0) return;
+  double chi = 0;
+  for (int i = 0; i < nLin; i++) chi += i < 512 ? s_chiP[i] : B.chiPart[i];
+  chi += B.chiPart[chiSlot];
+  double scale = 0;
+  if (!init) for (int i = 0; i < nScale; i++) scale += i < 512 ? s_scaleP[i] : scalePart[i];
+  double maxDiag = 0;
+  if (init) for (int i = 0; i < 256; i++) maxDiag = fmax(maxDiag, s_m[i]);
+  BACtl k = *c;
+  const int its = k.phase == 0 ? sc.its1 : sc.its2;
+  bool endOpt = false;
+  k.slots++;
+  k.needGate = 0;
+  if (init) {
+    k.needInit = 0;
+    k.currentChi = chi; k.iniChi = chi;
+    k.lambda = 1e-5 * maxDiag; k.ni = 2; k.nBad = 0; k.it = 0; k.qmax = 0;
+    if (its <= 0 || k.abort) endOpt = true;
+  } else {
+    k.trials++;
+    double tempChi = chi;
+    if (*okFlag == 0.0) tempChi = 1.7976931348623157e308;  // solver failure (levenberg.cpp:126-127)
+    double rho = k.currentChi - tempChi;
+    rho /= scale + 1e-3;
+    if (rho > 0 && isfinite(tempChi)) {
+      double alpha = 1. - pow((2 * rho - 1), 3);
+      alpha = fmin(alpha, 2. / 3.);
+      k.lambda *= fmax(1. / 3., alpha);
+      k.ni = 2;
+      k.currentChi = tempChi;
+      k.cur = 1 - k.cur;  // discardTop: the trial state and its linearisation become current
+    } else {
+      k.lambda *= k.ni;
+      k.ni *= 2;  // pop
+    }
+    k.qmax++;
+    if (!(rho < 0 && k.qmax < 10 && !k.abort)) {  // the iteration is over
+      if (k.qmax == 10 || rho == 0) endOpt = true;
+      else {
+        if ((k.iniChi - k.currentChi) * 1e3 < k.iniChi) k.nBad++;
+        else k.nBad = 0;
+        if (k.nBad >= 3) endOpt = true;
+      }
+      if (!endOpt) {
+        k.it++;
+        if (k.it >= its || k.abort) endOpt = true;
+        else { k.iniChi = k.currentChi; k.qmax = 0; }
+      }
+    }
+  }
+  if (endOpt) {
+    // the chi2 gate runs in the next slot's k_ba_update_c launch (that slot only linearises)
+    if (k.phase == 0 && sc.gate && !k.abort && D.nE > 0) { k.phase = 1; k.needInit = 1; k.needGate = 1; }
+    else k.phase = 2;
+  }
+  k.abort = c->abort;  // the host may have written it meanwhile: keep its value
+  *c = k;
+}
+
+__global__ void k_ba_gate_final_c(BADev D, St2 st, const BACtl *c, uint8_t *outFlag) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < D.nE) gate_edge(D, st.s[c->cur], 0, outFlag, e);
+}
+
 __global__ void k_ba_export(int n_kf, int npt, const SE3 *pose, const double *pt, const uint8_t *fixed, float *kfT, float *ptOut) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n_kf) {
+    if (!fixed[g]) fb::se3_to_float12(pose[g], kfT + 12 * g);
+  } else if (g < n_kf + npt * 3) ptOut[g - n_kf] = (float)pt[g - n_kf];
+}
+
+__global__ void k_ba_export_c(int n_kf, int npt, St2 st, const BACtl *c, const uint8_t *fixed, float *kfT, float *ptOut) {
+  const SE3 *pose = st.s[c->cur].pose;
+  const double *pt = st.s[c->cur].pt;
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < n_kf) {
     if (!fixed[g]) fb::se3_to_float12(pose[g], kfT + 12 * g);
@@ -843,6 +1240,11 @@ extern "C" int fb_local_ba_sharded(const fb_local_ba_args *A, int rank, int worl
 // Schur-reduced system (after k_ba_schur) and [Hpp, bp, chi2, scale] (after the linearisation at the trial state).
 static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allreduce_fn allreduce, void *ctx, const BASchedule &sc) {
   FB_TRY(fb::check_device());
+  const bool timing = getenv("FB_BA_TIMING") != nullptr;  // host-side phase times on stderr (probe)
+  const auto tStart = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (timing) fprintf(stderr, "[fb_local_ba] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tStart).count());
+  };
   const bool sharded = world > 1;
   auto reduce = [&](double *buf, int n, int op) -> int {
     if (!sharded || n <= 0) return FB_OK;
@@ -856,19 +1258,42 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
   const int npt = A->n_mp + A->n_mpb;  // bird points keep their slots even when unused
   const int nF = A->n_obs, nB = odom ? A->n_bobs : 0, nE = nF + nB, nO = (odom && rank == 0) ? A->n_odom : 0;
   (void)n_mpb;
-  // ---- host preprocessing: indices, CSR by landmark / pose
+  // ---- host preprocessing: indices, CSR by landmark / pose.  Everything the kernels read is laid out in ONE host staging
+  //      buffer and goes to the device with one copy (two dozen small synchronous copies were a quarter of a millisecond)
   std::vector<int> poseIdx(n_kf, -1);
   int np = 0;
   for (int k = 0; k < n_kf; k++) if (!A->kf_fixed[k]) poseIdx[k] = np++;
   const int P6 = 6 * np;
   if (P6 > 4096) { fb::set_error("fb_local_ba: more than 682 free keyframes"); return FB_ERR_CAPACITY; }
-  std::vector<int> e_pt(nE), e_kf(nE);
-  std::vector<uint8_t> e_type(nE), e_level(nE, 0);
-  std::vector<double> e_meas((size_t)nE * 3, 0.0), e_info(nE);
+  static thread_local std::vector<uint8_t> stage;
+  size_t stageBytes = 0;
+  auto reserve = [&](size_t bytes) { const size_t off = stageBytes; stageBytes += (bytes + 255) & ~(size_t)255; return off; };
+  const int nE1 = std::max(nE, 1), nO1 = std::max(nO, 1);
+  const size_t o_poseIdx = reserve((size_t)n_kf * 4), o_ept = reserve((size_t)nE1 * 4), o_ekf = reserve((size_t)nE1 * 4),
+               o_epj = reserve((size_t)nE1 * 4), o_etype = reserve(nE1), o_elevel = reserve(nE1), o_emeas = reserve((size_t)nE1 * 24),
+               o_einfo = reserve((size_t)nE1 * 8), o_lms = reserve((size_t)(npt + 1) * 4), o_lme = reserve((size_t)nE1 * 4),
+               o_pss = reserve((size_t)(np + 1) * 4), o_pse = reserve((size_t)nE1 * 4), o_oi = reserve((size_t)nO1 * 4),
+               o_oj = reserve((size_t)nO1 * 4), o_oz = reserve((size_t)nO1 * sizeof(SE3)), o_oinfo = reserve((size_t)nO1 * 8),
+               o_ods = reserve((size_t)(np + 1) * 4), o_ode = reserve((size_t)(2 * nO1) * 4), o_fixed = reserve(n_kf),
+               o_poses = reserve((size_t)n_kf * sizeof(SE3)), o_pts = reserve((size_t)std::max(npt, 1) * 24),
+               o_kfT = reserve((size_t)n_kf * 48);
+  if (stage.size() < stageBytes) stage.resize(stageBytes);
+  uint8_t *hs = stage.data();
+  int *h_poseIdx = reinterpret_cast<int *>(hs + o_poseIdx), *e_pt = reinterpret_cast<int *>(hs + o_ept), *e_kf = reinterpret_cast<int *>(hs + o_ekf),
+      *e_pj = reinterpret_cast<int *>(hs + o_epj), *lm_start = reinterpret_cast<int *>(hs + o_lms), *lm_edges = reinterpret_cast<int *>(hs + o_lme),
+      *ps_start = reinterpret_cast<int *>(hs + o_pss), *ps_edges = reinterpret_cast<int *>(hs + o_pse), *o_i = reinterpret_cast<int *>(hs + o_oi),
+      *o_j = reinterpret_cast<int *>(hs + o_oj), *od_start = reinterpret_cast<int *>(hs + o_ods), *od_edges = reinterpret_cast<int *>(hs + o_ode);
+  uint8_t *e_type = hs + o_etype, *e_level = hs + o_elevel;
+  double *e_meas = reinterpret_cast<double *>(hs + o_emeas), *e_info = reinterpret_cast<double *>(hs + o_einfo), *o_info = reinterpret_cast<double *>(hs + o_oinfo);
+  SE3 *oZinv = reinterpret_cast<SE3 *>(hs + o_oz), *poses = reinterpret_cast<SE3 *>(hs + o_poses);
+  double *pts = reinterpret_cast<double *>(hs + o_pts);
+  memcpy(h_poseIdx, poseIdx.data(), (size_t)n_kf * 4);
+  memcpy(hs + o_fixed, A->kf_fixed, n_kf);
+  memcpy(hs + o_kfT, A->kf_Tcw, (size_t)n_kf * 48);
   for (int i = 0; i < nF; i++) {
     FB_ARG(A->obs_mp[i] >= 0 && A->obs_mp[i] < n_mp && A->obs_kf[i] >= 0 && A->obs_kf[i] < n_kf);
     e_pt[i] = A->obs_mp[i]; e_kf[i] = A->obs_kf[i]; e_type[i] = T_PROJ;
-    e_meas[3 * i] = A->obs_uv[2 * i]; e_meas[3 * i + 1] = A->obs_uv[2 * i + 1];
+    e_meas[3 * i] = A->obs_uv[2 * i]; e_meas[3 * i + 1] = A->obs_uv[2 * i + 1]; e_meas[3 * i + 2] = 0.0;
     e_info[i] = odom ? (1.0 * (double)A->obs_inv_sigma2[i]) * (double)A->wF : (double)A->obs_inv_sigma2[i];
   }
   for (int i = 0; i < nB; i++) {
@@ -878,58 +1303,41 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
     for (int k = 0; k < 3; k++) e_meas[3 * e + k] = A->bobs_xc[3 * i + k];
     e_info[e] = (1.0 * (double)A->bobs_inv_sigma2[i]) * (double)A->wB;
   }
-  if (sharded)
-    for (int e = 0; e < nE; e++) if (e_pt[e] % world != rank) e_level[e] = 2;  // not this rank's landmark
-  std::vector<int> lm_start(npt + 1, 0), lm_edges(nE), ps_start(np + 1, 0), ps_edges;
+  for (int e = 0; e < nE; e++) {
+    e_level[e] = (sharded && e_pt[e] % world != rank) ? 2 : 0;  // 2 = not this rank's landmark
+    e_pj[e] = poseIdx[e_kf[e]];
+  }
+  for (int l = 0; l <= npt; l++) lm_start[l] = 0;
   for (int e = 0; e < nE; e++) lm_start[e_pt[e] + 1]++;
   for (int l = 0; l < npt; l++) lm_start[l + 1] += lm_start[l];
   {
-    std::vector<int> fill(lm_start.begin(), lm_start.end() - 1);
+    std::vector<int> fill(lm_start, lm_start + npt);
     for (int e = 0; e < nE; e++) lm_edges[fill[e_pt[e]]++] = e;
   }
-  for (int l = 0; l < npt; l++) {  // a keyframe observes a point at most once (map<KeyFrame*,size_t>)
-    std::vector<int> kfs;
-    for (int c = lm_start[l]; c < lm_start[l + 1]; c++) kfs.push_back(e_kf[lm_edges[c]]);
-    std::sort(kfs.begin(), kfs.end());
-    if (std::adjacent_find(kfs.begin(), kfs.end()) != kfs.end()) { fb::set_error("fb_local_ba: duplicate (keyframe, point) observation"); return FB_ERR_ARG; }
+  {  // a keyframe observes a point at most once (map<KeyFrame*,size_t>): stamp per key frame = last landmark seen
+    std::vector<int> seen(n_kf, -1);
+    for (int l = 0; l < npt; l++)
+      for (int c = lm_start[l]; c < lm_start[l + 1]; c++) {
+        int &sk = seen[e_kf[lm_edges[c]]];
+        if (sk == l) { fb::set_error("fb_local_ba: duplicate (keyframe, point) observation"); return FB_ERR_ARG; }
+        sk = l;
+      }
   }
-  for (int e = 0; e < nE; e++) if (poseIdx[e_kf[e]] >= 0) ps_start[poseIdx[e_kf[e]] + 1]++;
+  for (int k = 0; k <= np; k++) ps_start[k] = 0;
+  for (int e = 0; e < nE; e++) if (e_pj[e] >= 0) ps_start[e_pj[e] + 1]++;
   for (int k = 0; k < np; k++) ps_start[k + 1] += ps_start[k];
-  ps_edges.resize(ps_start[np]);
   {
-    std::vector<int> fill(ps_start.begin(), ps_start.end() - 1);
-    for (int e = 0; e < nE; e++) if (poseIdx[e_kf[e]] >= 0) ps_edges[fill[poseIdx[e_kf[e]]]++] = e;
+    std::vector<int> fill(ps_start, ps_start + np);
+    for (int e = 0; e < nE; e++) if (e_pj[e] >= 0) ps_edges[fill[e_pj[e]]++] = e;
   }
-  std::vector<SE3> poses(n_kf), oZinv(nO);
   for (int k = 0; k < n_kf; k++) poses[k] = fb::se3_from_float12(A->kf_Tcw + 12 * k);
-  std::vector<double> pts((size_t)npt * 3);
   for (int i = 0; i < 3 * n_mp; i++) pts[i] = A->mp_xw[i];
   for (int i = 0; i < 3 * A->n_mpb; i++) pts[3 * n_mp + i] = A->mpb_xw[i];
-  std::vector<int> o_i(nO), o_j(nO);
-  std::vector<double> o_info(nO);
   for (int i = 0; i < nO; i++) {
     FB_ARG(A->odom_kf_i[i] >= 0 && A->odom_kf_i[i] < n_kf && A->odom_kf_j[i] >= 0 && A->odom_kf_j[i] < n_kf);
     o_i[i] = A->odom_kf_i[i]; o_j[i] = A->odom_kf_j[i]; o_info[i] = A->odom_info[i];
     oZinv[i] = fb::se3_inverse(fb::se3_from_float12(A->odom_Tij + 12 * i));
   }
-  // ---- device buffers
-  const int NT = (P6 + 1 + 15) / 16;
-  const int rows = NT * 16;
-  const int nLinBlocks = (npt + LIN_THREADS - 1) / LIN_THREADS;
-  const int nUpdBlocks = (npt + n_kf + LIN_THREADS - 1) / LIN_THREADS;
-  int nWg = std::min(128, std::max(1, (npt + CHUNK - 1) / CHUNK));
-  const int lmPerWg = ((npt + nWg - 1) / nWg + CHUNK - 1) / CHUNK * CHUNK;
-  nWg = std::max(1, (npt + lmPerWg - 1) / std::max(lmPerWg, 1));
-  fb::DevBuf d_poseIdx, d_ept, d_ekf, d_etype, d_emeas, d_einfo, d_elevel, d_echi2, d_lms, d_lme, d_pss, d_pse, d_oi, d_oj,
-      d_oz, d_oinfo, d_fixed;
-  std::vector<int> e_pj(nE);
-  for (int e = 0; e < nE; e++) e_pj[e] = poseIdx[e_kf[e]];
-  fb::DevBuf d_epj;
-  if (nE > 0) BA_UP(d_epj, e_pj); else FB_TRY(d_epj.alloc(4));
-  BA_UP(d_poseIdx, poseIdx); BA_UP(d_ept, e_pt); BA_UP(d_ekf, e_kf); BA_UP(d_etype, e_type); BA_UP(d_emeas, e_meas);
-  BA_UP(d_einfo, e_info); BA_UP(d_elevel, e_level); BA_UP(d_lms, lm_start); BA_UP(d_lme, lm_edges); BA_UP(d_pss, ps_start);
-  BA_UP(d_pse, ps_edges); BA_UP(d_oi, o_i); BA_UP(d_oj, o_j); BA_UP(d_oz, oZinv); BA_UP(d_oinfo, o_info);
-  std::vector<int> od_start(np + 1, 0), od_edges;
   {
     std::vector<std::vector<int>> inc(np);
     for (int e = 0; e < nO; e++) {
@@ -937,39 +1345,62 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
       if (pi >= 0) inc[pi].push_back(e);
       if (pj >= 0 && pj != pi) inc[pj].push_back(e);
     }
-    for (int k = 0; k < np; k++) { od_start[k + 1] = od_start[k] + (int)inc[k].size(); od_edges.insert(od_edges.end(), inc[k].begin(), inc[k].end()); }
-    if (od_edges.empty()) od_edges.push_back(0);
+    od_start[0] = 0;
+    int q = 0;
+    for (int k = 0; k < np; k++) { for (int e : inc[k]) od_edges[q++] = e; od_start[k + 1] = q; }
   }
-  fb::DevBuf d_ods, d_ode;
-  BA_UP(d_ods, od_start); BA_UP(d_ode, od_edges);
-  FB_TRY(d_fixed.upload(A->kf_fixed, n_kf));
-  FB_TRY(d_echi2.alloc((size_t)std::max(nE, 1) * 8));
-  FB_HIP(hipMemset(d_echi2.p, 0, (size_t)std::max(nE, 1) * 8));
+  // ---- device buffers: the staged graph (one copy) + one scratch allocation carved below
+  const int NT = (P6 + 1 + 15) / 16;
+  const int rows = NT * 16;
+  const int nLinBlocks = (npt + LIN_THREADS - 1) / LIN_THREADS;
+  const int nUpdBlocks = (npt + n_kf + LIN_THREADS - 1) / LIN_THREADS;
+  int nWg = std::min(getenv("FB_BA_NWG") ? atoi(getenv("FB_BA_NWG")) : 256, std::max(1, (npt + CHUNK - 1) / CHUNK));
+  const int lmPerWg = ((npt + nWg - 1) / nWg + CHUNK - 1) / CHUNK * CHUNK;
+  nWg = std::max(1, (npt + lmPerWg - 1) / std::max(lmPerWg, 1));
+  lap("host preprocessing done");
+  fb::DevBuf d_stage, d_scratch;
+  FB_TRY(d_stage.upload(hs, stageBytes));
+  lap("graph uploaded");
+  uint8_t *ds = d_stage.as<uint8_t>();
+  size_t scratchBytes = 0;
+  auto carve = [&](size_t bytes) { const size_t off = scratchBytes; scratchBytes += (bytes + 255) & ~(size_t)255; return off; };
+  const size_t c_echi2 = carve((size_t)nE1 * 8);
+  size_t c_pose1 = carve((size_t)n_kf * sizeof(SE3)), c_pt1 = carve((size_t)std::max(npt, 1) * 24);
+  size_t c_Hll[2], c_bl[2], c_W[2], c_Hpp[2], c_bp[2], c_chi[2];
+  for (int q = 0; q < 2; q++) {
+    c_Hll[q] = carve((size_t)std::max(npt, 1) * 72); c_bl[q] = carve((size_t)std::max(npt, 1) * 24); c_W[q] = carve((size_t)nE1 * 144);
+    c_Hpp[q] = carve((size_t)std::max(P6 * P6, 1) * 8); c_bp[q] = carve((size_t)std::max(P6, 1) * 8); c_chi[q] = carve((size_t)(nLinBlocks + 1) * 8);
+  }
+  FB_TRY(d_scratch.alloc(scratchBytes));
+  uint8_t *dc = d_scratch.as<uint8_t>();
+  FB_HIP(hipMemsetAsync(dc + c_echi2, 0, (size_t)nE1 * 8, nullptr));
+  // state 0 = the staged copy, state 1 starts as the same poses / points
+  FB_HIP(hipMemcpyAsync(dc + c_pose1, ds + o_poses, (size_t)n_kf * sizeof(SE3), hipMemcpyDeviceToDevice, nullptr));
+  FB_HIP(hipMemcpyAsync(dc + c_pt1, ds + o_pts, (size_t)std::max(npt, 1) * 24, hipMemcpyDeviceToDevice, nullptr));
+  const uint8_t *d_fixed = ds + o_fixed;   // kf_fixed
+  const uint8_t *d_kfT0 = ds + o_kfT;      // the caller's float poses (fixed key frames are returned untouched)
   BADev D;
   D.n_kf = n_kf; D.np = np; D.npt = npt; D.nE = nE; D.nO = nO; D.quat = odom ? 1 : 0;
   D.fx = A->fx; D.fy = A->fy; D.cx = A->cx; D.cy = A->cy; D.delta = sc.delta;
-  D.e_pj = d_epj.as<int>();
-  D.poseIdx = d_poseIdx.as<int>(); D.e_pt = d_ept.as<int>(); D.e_kf = d_ekf.as<int>(); D.e_type = d_etype.as<uint8_t>();
-  D.e_meas = d_emeas.as<double>(); D.e_info = d_einfo.as<double>(); D.e_level = d_elevel.as<uint8_t>();
-  D.e_chi2 = d_echi2.as<double>(); D.lm_start = d_lms.as<int>(); D.lm_edges = d_lme.as<int>(); D.ps_start = d_pss.as<int>();
-  D.ps_edges = d_pse.as<int>(); D.o_i = d_oi.as<int>(); D.o_j = d_oj.as<int>(); D.o_Zinv = d_oz.as<SE3>();
-  D.o_info = d_oinfo.as<double>();
-  D.od_start = d_ods.as<int>(); D.od_edges = d_ode.as<int>();
-  fb::DevBuf d_pose[2], d_pt[2], d_Hll[2], d_bl[2], d_W[2], d_Hpp[2], d_bp[2], d_chi[2];
+  D.e_pj = reinterpret_cast<int *>(ds + o_epj);
+  D.poseIdx = reinterpret_cast<int *>(ds + o_poseIdx); D.e_pt = reinterpret_cast<int *>(ds + o_ept); D.e_kf = reinterpret_cast<int *>(ds + o_ekf);
+  D.e_type = ds + o_etype; D.e_meas = reinterpret_cast<double *>(ds + o_emeas); D.e_info = reinterpret_cast<double *>(ds + o_einfo);
+  D.e_level = ds + o_elevel; D.e_chi2 = reinterpret_cast<double *>(dc + c_echi2);
+  D.lm_start = reinterpret_cast<int *>(ds + o_lms); D.lm_edges = reinterpret_cast<int *>(ds + o_lme);
+  D.ps_start = reinterpret_cast<int *>(ds + o_pss); D.ps_edges = reinterpret_cast<int *>(ds + o_pse);
+  D.o_i = reinterpret_cast<int *>(ds + o_oi); D.o_j = reinterpret_cast<int *>(ds + o_oj); D.o_Zinv = reinterpret_cast<SE3 *>(ds + o_oz);
+  D.o_info = reinterpret_cast<double *>(ds + o_oinfo);
+  D.od_start = reinterpret_cast<int *>(ds + o_ods); D.od_edges = reinterpret_cast<int *>(ds + o_ode);
   State st[2];
   LinBuf lb[2];
-  for (int s = 0; s < 2; s++) {
-    FB_TRY(d_pose[s].upload(poses.data(), poses.size() * sizeof(SE3)));
-    FB_TRY(d_pt[s].upload(pts.data(), pts.size() * 8));
-    FB_TRY(d_Hll[s].alloc((size_t)npt * 9 * 8)); FB_TRY(d_bl[s].alloc((size_t)npt * 3 * 8));
-    FB_TRY(d_W[s].alloc((size_t)std::max(nE, 1) * 18 * 8)); FB_TRY(d_Hpp[s].alloc((size_t)std::max(P6 * P6, 1) * 8));
-    FB_TRY(d_bp[s].alloc((size_t)std::max(P6, 1) * 8)); FB_TRY(d_chi[s].alloc((size_t)(nLinBlocks + 1) * 8));
-    st[s].pose = d_pose[s].as<SE3>(); st[s].pt = d_pt[s].as<double>();
-    lb[s].Hll = d_Hll[s].as<double>(); lb[s].bl = d_bl[s].as<double>(); lb[s].W = d_W[s].as<double>();
-    lb[s].Hpp = d_Hpp[s].as<double>(); lb[s].bp = d_bp[s].as<double>(); lb[s].chiPart = d_chi[s].as<double>();
+  st[0].pose = reinterpret_cast<SE3 *>(ds + o_poses); st[0].pt = reinterpret_cast<double *>(ds + o_pts);
+  st[1].pose = reinterpret_cast<SE3 *>(dc + c_pose1); st[1].pt = reinterpret_cast<double *>(dc + c_pt1);
+  for (int q = 0; q < 2; q++) {
+    lb[q].Hll = reinterpret_cast<double *>(dc + c_Hll[q]); lb[q].bl = reinterpret_cast<double *>(dc + c_bl[q]); lb[q].W = reinterpret_cast<double *>(dc + c_W[q]);
+    lb[q].Hpp = reinterpret_cast<double *>(dc + c_Hpp[q]); lb[q].bp = reinterpret_cast<double *>(dc + c_bp[q]); lb[q].chiPart = reinterpret_cast<double *>(dc + c_chi[q]);
   }
   const size_t schurLds = (size_t)2 * rows * KPAD * 8;
-  const size_t solveLds = ((size_t)P6 * (P6 + 1) + P6 + (size_t)P6 * 6 + 2) * 8;
+  const size_t solveLds = ((size_t)(P6 + 1) * (P6 + 1) + (size_t)(P6 + 1) * 6 + 48 + P6 + 2) * 8;  // the larger of k_ba_solve / solve_lookahead
   // beyond ~23 free key frames the reduced system no longer fits LDS: HBM-resident path of ba_big.inc
   const bool big = schurLds > 160 * 1024 || solveLds > 160 * 1024 || P6 + 1 > 256;
   fb::DevBuf d_Dinv, d_Spart, d_xp, d_ok, d_scale, d_scal, d_bigS, d_bigM, d_bigU, d_bigR;
@@ -1037,6 +1468,103 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
     FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_odom<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)odomLds));
   }
   hipStream_t s0 = nullptr;
+
+  // ---- device-resident Levenberg-Marquardt (LDS-resident reduced system, one GPU): no read-back inside the schedule
+  if (!sharded && !big && !getenv("FB_BA_TRACE") && !getenv("FB_BA_HOST_LM")) {
+    static hipStream_t sAux = nullptr;      // side stream for the abort flag (does not synchronise with the null stream)
+    static BACtl *hCtl = nullptr;           // pinned mirror of the control block
+    if (!sAux) FB_HIP(hipStreamCreateWithFlags(&sAux, hipStreamNonBlocking));
+    if (!hCtl) FB_HIP(hipHostMalloc(reinterpret_cast<void **>(&hCtl), sizeof(BACtl), hipHostMallocDefault));
+    fb::DevBuf d_ctl, d_flags, d_kfT, d_ptOut;
+    BACtl init;
+    memset(&init, 0, sizeof(init));
+    const bool anything = nE + nO > 0 && (np > 0 || npt > 0);
+    init.phase = anything ? 0 : 2;
+    init.needInit = 1;
+    FB_TRY(d_ctl.upload(&init, sizeof(init)));
+    BACtl *ctl = d_ctl.as<BACtl>();
+    const BASched sched = {sc.its1, sc.robust1, sc.gate ? 1 : 0, sc.its2};
+    St2 st2; st2.s[0] = st[0]; st2.s[1] = st[1];
+    Lb2 lb2; lb2.b[0] = lb[0]; lb2.b[1] = lb[1];
+    auto schurC = NT <= 8 ? k_ba_schur_c<9> : (NT <= 12 ? k_ba_schur_c<20> : k_ba_schur_c<34>);
+    FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(schurC), hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
+    FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve_c), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
+    const int nS = rows * rows;
+    const int nLin256 = (npt + 255) / 256;
+    // scratch of the two linearisation buffers: odometry blocks [HppO | bpO] and the key-frame parts
+    const size_t odomO = (size_t)P6 * P6 + P6;
+    fb::DevBuf d_odomO, d_poseP;
+    FB_TRY(d_odomO.alloc((2 * odomO + 1) * 8));
+    FB_TRY(d_poseP.alloc(((size_t)2 * np * POSE_PARTS * 27 + 1) * 8));
+    double *HppO2 = d_odomO.as<double>(), *poseP2 = d_poseP.as<double>();
+    if (!olGlobal) FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_lin_c<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)odomLds));
+    const int linGrid = nLin256 + POSE_PARTS * np + 1;
+    auto slot = [&]() {
+      { fb::ProfScope pr(fb::P_BA_SCHUR, s0);
+        schurC<<<nWg, SCHUR_THREADS, schurLds, s0>>>(D, lb2, ctl, d_Dinv.as<double>(), d_Spart.as<double>(), P6, NT, lmPerWg); }
+      { fb::ProfScope pr(fb::P_BA_SOLVE, s0);
+        k_ba_sumparts_c<<<(nS + 255) / 256, 256, 0, s0>>>(ctl, d_Spart.as<double>(), nWg, nS);
+        k_ba_solve_c<<<1, SOLVE_THREADS, solveLds, s0>>>(lb2, ctl, d_Spart.as<double>(), P6, NT, d_xp.as<double>(), d_scal.as<double>() + 3, HppO2); }
+      { fb::ProfScope pr(fb::P_BA_UPDATE, s0);
+        k_ba_update_c<<<nUpdBlocks, LIN_THREADS, 0, s0>>>(D, lb2, st2, ctl, d_Dinv.as<double>(), d_xp.as<double>(), d_scale.as<double>()); }
+      { fb::ProfScope pr(fb::P_BA_LINEARIZE, s0);
+        if (olGlobal) k_ba_lin_c<true><<<linGrid, 256, 0, s0>>>(D, st2, lb2, ctl, sched, P6, nLin256, nLinBlocks, olGlobal, HppO2, poseP2);
+        else k_ba_lin_c<false><<<linGrid, 256, odomLds, s0>>>(D, st2, lb2, ctl, sched, P6, nLin256, nLinBlocks, nullptr, HppO2, poseP2); }
+      { fb::ProfScope pr(fb::P_BA_MISC, s0);
+        k_ba_control<<<1, 256, 0, s0>>>(D, lb2, ctl, sched, nLin256, nLinBlocks, d_scale.as<double>(), nUpdBlocks, d_scal.as<double>() + 3, P6, HppO2, poseP2); }
+    };
+    FB_TRY(d_flags.alloc(std::max(nE, 1)));
+    FB_TRY(d_kfT.alloc((size_t)n_kf * 48));
+    FB_HIP(hipMemcpyAsync(d_kfT.p, d_kfT0, (size_t)n_kf * 48, hipMemcpyDeviceToDevice, s0));
+    FB_TRY(d_ptOut.alloc((size_t)std::max(npt, 1) * 12));
+    hipEvent_t evDone = nullptr;
+    FB_HIP(hipEventCreateWithFlags(&evDone, hipEventDisableTiming));
+    bool abortSent = false;
+    static const int one = 1;
+    // a typical schedule takes one trial per iteration: its1 + its2 trials + the two opening linearisations
+    int batch = anything ? sc.its1 + (sc.gate ? sc.its2 + 1 : 0) + 1 + 3 : 0;
+    int rcLoop = FB_OK;
+    lap("buffers ready");
+    for (int round = 0; round < 64; round++) {
+      for (int i = 0; i < batch; i++) slot();
+      lap("slots enqueued");
+      // the results of the state that is current now (final when the schedule has finished, which is the common case)
+      if (nE > 0) k_ba_gate_final_c<<<(nE + 255) / 256, 256, 0, s0>>>(D, st2, ctl, d_flags.as<uint8_t>());
+      k_ba_export_c<<<(n_kf + npt * 3 + 255) / 256, 256, 0, s0>>>(n_kf, npt, st2, ctl, d_fixed, d_kfT.as<float>(), d_ptOut.as<float>());
+      if (hipGetLastError() != hipSuccess) { fb::set_error("fb_local_ba: kernel launch failed"); rcLoop = FB_ERR_HIP; break; }
+      if (hipMemcpyAsync(hCtl, ctl, sizeof(BACtl), hipMemcpyDeviceToHost, s0) != hipSuccess || hipEventRecord(evDone, s0) != hipSuccess) {
+        fb::set_error("fb_local_ba: control block read-back failed"); rcLoop = FB_ERR_HIP; break;
+      }
+      for (;;) {  // wait; meanwhile forward pbStopFlag (polled by k_ba_control at the end of every slot)
+        const hipError_t q = hipEventQuery(evDone);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) { fb::set_error("fb_local_ba: %s", hipGetErrorString(q)); rcLoop = FB_ERR_HIP; break; }
+        if (!abortSent && A->stop_flag && *A->stop_flag) {
+          (void)hipMemcpyAsync(&ctl->abort, &one, sizeof(int), hipMemcpyHostToDevice, sAux);
+          abortSent = true;
+        }
+      }
+      if (rcLoop != FB_OK || hCtl->phase == 2) break;
+      batch = 6;
+    }
+    lap("schedule finished");
+    (void)hipEventDestroy(evDone);
+    if (rcLoop != FB_OK) return rcLoop;
+    if (hCtl->phase != 2) { fb::set_error("fb_local_ba: the LM schedule did not finish"); return FB_ERR_HIP; }
+    std::vector<uint8_t> flags(std::max(nE, 1));
+    FB_TRY(d_flags.download(flags.data(), std::max(nE, 1)));
+    std::vector<float> po((size_t)std::max(npt, 1) * 3);
+    FB_TRY(d_ptOut.download(po.data(), (size_t)npt * 12));
+    if (sc.gate) {  // the global BA classifies nothing
+      for (int i = 0; i < nF; i++) A->obs_outlier[i] = flags[i];
+      for (int i = 0; i < nB; i++) A->bobs_outlier[i] = flags[nF + i];
+    }
+    FB_TRY(d_kfT.download(A->kf_Tcw, (size_t)n_kf * 48));
+    for (int i = 0; i < 3 * n_mp; i++) A->mp_xw[i] = po[i];
+    for (int i = 0; i < 3 * A->n_mpb; i++) A->mpb_xw[i] = po[3 * n_mp + i];
+    lap("results copied out");
+    return FB_OK;
+  }
 
   double lastScale = 0;  // sum x (lambda x + b) of the most recent k_ba_update (all ranks)
   bool lastOk = true;    // LDL^T status of the most recent k_ba_solve
@@ -1182,7 +1710,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
   if (nE > 0) k_ba_gate<<<(nE + 255) / 256, 256, 0, s0>>>(D, st[cur], 0, d_flags.as<uint8_t>());
   FB_TRY(d_kfT.upload(A->kf_Tcw, (size_t)n_kf * 48));
   FB_TRY(d_ptOut.alloc((size_t)std::max(npt, 1) * 12));
-  k_ba_export<<<(n_kf + npt * 3 + 255) / 256, 256, 0, s0>>>(n_kf, npt, st[cur].pose, st[cur].pt, d_fixed.as<uint8_t>(),
+  k_ba_export<<<(n_kf + npt * 3 + 255) / 256, 256, 0, s0>>>(n_kf, npt, st[cur].pose, st[cur].pt, d_fixed,
                                                             d_kfT.as<float>(), d_ptOut.as<float>());
   FB_HIP(hipGetLastError());
   FB_HIP(hipDeviceSynchronize());

@@ -1467,7 +1467,7 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
     }
   }
   if (K.totalCells > 0) {
-    fb::ProfScope prof_(fb::P_FAST, s);
+    fb::ProfScope prof_(K.fastTP == 44 ? fb::P_FAST : K.fastTP == 56 ? fb::P_FAST56 : fb::P_FAST72, s);
     const dim3 grdF((K.totalGroups + 7) / 8 * 8, batch);
     const size_t ldsF = (size_t)2 * K.fastTileBytes + 2 * K.fastMaxPix;
 #define FAST_LAUNCH(TP_) { if (K.dbg == 20) k_fast<TP_, true><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cellCand.as<uint32_t>(), o->cellCount.as<int>()); \

@@ -74,11 +74,13 @@ void pool_give(void *p, size_t granted) {
 bool g_prof_on = false;
 int g_prof_only = -1;
 namespace {
-const char *kProfNames[P_COUNT] = {"k_resize", "k_fast", "k_octree", "k_describe", "k_grid_build", "k_bird_keys_to_cam",
+// the names rocprofv3 shows, without the namespace and the argument list (k_fast: one row per tile-pitch instantiation,
+// 44 = 1280x720 / 640x480 levels, 56 = 512x512 levels)
+const char *kProfNames[P_COUNT] = {"k_resize", "k_fast<44>", "k_octree", "k_describe", "k_grid_build", "k_bird_keys_to_cam",
                                    "k_descriptor_distance", "k_proj_frame", "k_proj_points", "k_bird_mappoints",
                                    "k_birdview", "k_match_bow", "k_match_triangulation", "k_pose_opt", "k_pose_gather", "k_ba_linearize", "k_ba_schur",
                                    "k_ba_solve", "k_ba_update", "k_ba_misc", "k_proj_kf", "k_match_bow_kf", "k_in_frustum",
-                                   "k_undistort", "k_blur", "k_kf_search", "k_distinctive", "k_bow_transform"};
+                                   "k_undistort", "k_blur", "k_kf_search", "k_distinctive", "k_bow_transform", "k_fast<56>", "k_fast<72>"};
 struct ProfRec { int id; hipEvent_t a, b; };
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;

@@ -14,6 +14,9 @@ import numpy as np
 
 from . import cabi
 
+# what bench.py prints next to the sharded-BA numbers
+TRANSPORT_NOTE = "host-staged all-reduce callback: D2H, torch.distributed all_reduce, H2D"
+
 
 def init_from_env(backend=None, device=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun sets them)."""

@@ -84,17 +84,25 @@ def call(name, args):
     assert rc == 0, (name, rc)
 
 
-def frame_pipeline(params, front, bird, world, fx=500.0, fy=500.0):
+def frame_pipeline(params, front, bird, world, fx=500.0, fy=500.0, timings=None):
     """CPU restatement of the per-frame hot path for ONE frame pair, stage by stage, in the order of
-    fishbirdeyevisualslam_amd.pipeline.FramePipeline.step().  `world` is one entry of build_world()."""
+    fishbirdeyevisualslam_amd.pipeline.FramePipeline.step().  `world` is one entry of build_world().
+    timings (dict): receives the seconds spent inside the oracle's C++ for each stage of BASELINE.md section 3
+    (extract_front, extract_bird, match_front, match_bird, pose_opt); the numpy glue between the calls is not counted."""
+    import time
     from fishbirdeyevisualslam_amd import synth, problems as P
     from fishbirdeyevisualslam_amd.cabi import fill
+    tm = timings if timings is not None else {}
     fh, fw = front.shape
     bh, bw = bird.shape
     cap = params.nfeatures + 8 * params.nlevels
     t = orb_tables(params)
+    t0 = time.perf_counter()
     fk, fd = orb_extract(params, front)
+    t1 = time.perf_counter()
     bk, bd = orb_extract(params, bird)
+    t2 = time.perf_counter()
+    tm["extract_front"], tm["extract_bird"] = t1 - t0, t2 - t1
     gf = P.grid_geom(synth.front_grid_geom(fw, fh))
     gb = P.grid_geom(synth.bird_grid_geom(bw, bh))
     fcs, fci = P.build_grid_host([fk], gf, grid_build, cap)
@@ -117,12 +125,16 @@ def frame_pipeline(params, front, bird, world, fx=500.0, fy=500.0):
                 last_angle=world["last_angle"])
     a, out3, keep = P.proj_frame_args([prob], fcs, fci, th=15.0, nnratio=0.9, cur_stride=cap,
                                       scale_factors=[t.scale_factor[i] for i in range(params.nlevels)])
+    t0 = time.perf_counter()
     call("orc_match_projection_frame", a)
+    tm["match_front"] = time.perf_counter() - t0
     m3 = out3["match_cur_to_last"]
     bprob = dict(cols=bw, rows=bh, Tbc=Tbc, Tcb=Tcb, Tcw=world["Tcw0"], cur_kps=bk, cur_desc=bd, cur_cam_xyz=bcam,
                  ref_valid=np.ones(nr, np.uint8), ref_xw=world["ref_xw"], ref_desc=world["ref_desc"])
     a9, out9, keep9 = P.bird_mp_args([bprob], bcs, bci, cur_stride=cap)
+    t0 = time.perf_counter()
     call("orc_match_bird_mappoints", a9)
+    tm["match_bird"] = time.perf_counter() - t0
     m9 = out9["match_cur_to_ref"]
     # edge construction (Optimizer.cc:525-602)
     inv = np.array([t.inv_level_sigma2[i] for i in range(params.nlevels)], np.float32)
@@ -136,7 +148,9 @@ def frame_pipeline(params, front, bird, world, fx=500.0, fy=500.0):
               front_inv_sigma2=inv[fk["octave"]], bird_xw=bx_w, bird_xc=bcam, bird_inv_sigma2=inv[bk["octave"]],
               Tcw0=world["Tcw0"])
     ap, outp, keepp = P.pose_args([pp], mode=cabi.FB_POSE_FRONT_BIRD, front_valid=[fv], bird_valid=[bv])
+    t0 = time.perf_counter()
     call("orc_pose_opt", ap)
+    tm["pose_opt"] = time.perf_counter() - t0
     return dict(fk=fk, fd=fd, bk=bk, bd=bd, bcam=bcam, m_front=m3[0], nm_front=int(out3["nmatches"][0]), m_bird=m9[0],
                 nm_bird=int(out9["ninliers"][0]), Tcw=outp["Tcw"][0], ninliers=int(outp["ninliers"][0]),
                 front_outlier=outp["front_outlier"][0], bird_outlier=outp["bird_outlier"][0], fv=fv, bv=bv)
