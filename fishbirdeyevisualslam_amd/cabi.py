@@ -270,5 +270,5 @@ EXPORTS = [
     "fb_bird_filter_matches_dev", "fb_bird_filter_matches", "fb_bow_transform_dev", "fb_bow_transform",
     "fb_in_frustum_dev", "fb_in_frustum", "fb_undistort_keypoints_dev", "fb_undistort_keypoints", "fb_image_bounds",
     "fb_pose_opt_batch_dev", "fb_pose_opt", "fb_pose_gather_front_dev", "fb_pose_gather_bird_dev",
-    "fb_local_ba", "fb_local_ba_sharded", "fb_global_ba",
+    "fb_local_ba", "fb_local_ba_sharded", "fb_local_ba_sharded_rccl", "fb_rccl_get_unique_id", "fb_rccl_comm_init", "fb_rccl_comm_destroy", "fb_global_ba",
 ]

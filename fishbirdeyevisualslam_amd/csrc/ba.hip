@@ -1032,6 +1032,16 @@ struct BACtl {
 struct BASched { int its1, robust1, gate, its2; };
 struct St2 { State s[2]; };
 struct Lb2 { LinBuf b[2]; };
+// The per-linearisation "exchange block" (one per buffer t, `stride` doubles apart): everything a rank contributes to the
+// pose system of a linearisation, contiguous so that the sharded BA sums it over the ranks with ONE all-reduce:
+//   [0, oH) key-frame parts (np x POSE_PARTS x 27) | [oH, oB) HppO (P6 x P6) | [oB, oS) bpO (P6) |
+//   [oS, oM) chi2, scale term, abort request, spare | [oM, stride) max |diag Hll| of each rank (own slot, others 0)
+struct XBLay {
+  double *base;
+  int stride, oH, oB, oS, oM;
+  __host__ __device__ double *at(int t) const { return base + (size_t)t * stride; }
+};
+
 
 template <int MAXT>
 __global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur_c(BADev D, Lb2 lb, const BACtl *c, double *Dinv, double *Spart, int P6, int NT, int lmPerWg) {
@@ -1044,13 +1054,14 @@ __global__ void k_ba_sumparts_c(const BACtl *c, double *Spart, int nWg, int n) {
   sumparts_body(Spart, nWg, n);
 }
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve_c(Lb2 lb, const BACtl *c, const double *Spart, int P6, int NT, double *xp, double *okFlag,
-                                                              const double *HppO2) {
+                                                              XBLay xb) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int s_ok;
   if (c->phase == 2 || c->needInit) return;
-  solve_lookahead(lb.b[c->cur], c->lambda, Spart, P6, NT, xp, okFlag, smem, s_ok, HppO2 + (size_t)c->cur * ((size_t)P6 * P6 + P6));
+  solve_lookahead(lb.b[c->cur], c->lambda, Spart, P6, NT, xp, okFlag, smem, s_ok, xb.at(c->cur) + xb.oH);
 }
-__global__ __launch_bounds__(LIN_THREADS) void k_ba_update_c(BADev D, Lb2 lb, St2 st, const BACtl *c, const double *Dinv, const double *xp, double *scalePart) {
+__global__ __launch_bounds__(LIN_THREADS) void k_ba_update_c(BADev D, Lb2 lb, St2 st, const BACtl *c, const double *Dinv, const double *xp, double *scalePart,
+                                                             int countPoses) {
   __shared__ double s_part[LIN_THREADS / 64];
   if (c->phase == 2) return;
   if (c->needInit) {
@@ -1058,7 +1069,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_update_c(BADev D, Lb2 lb, St
       for (int e = blockIdx.x * LIN_THREADS + threadIdx.x; e < D.nE; e += gridDim.x * LIN_THREADS) gate_edge(D, st.s[c->cur], 1, nullptr, e);
     return;
   }
-  update_body(D, lb.b[c->cur], st.s[c->cur], st.s[1 - c->cur], Dinv, xp, c->lambda, scalePart, 1, s_part);
+  update_body(D, lb.b[c->cur], st.s[c->cur], st.s[1 - c->cur], Dinv, xp, c->lambda, scalePart, countPoses, s_part);
 }
 // The linearisation of a slot as ONE launch of 256-thread workgroups with three roles (they are independent of each
 // other): blocks [0, nLin) = landmarks (Hll, bl, W, chi2); the next POSE_PARTS * np blocks = a quarter of the edges of one
@@ -1068,7 +1079,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_update_c(BADev D, Lb2 lb, St
 constexpr int POSE_PARTS = 4;
 template <bool GLOBAL>
 __global__ __launch_bounds__(256) void k_ba_lin_c(BADev D, St2 st, Lb2 lb, const BACtl *c, BASched sc, int P6, int nLin, int chiSlot, OdomLin *olGlobal,
-                                                  double *HppO2, double *poseP2) {
+                                                  XBLay xb) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ double s_buf[256];
   if (c->phase == 2) return;
@@ -1079,19 +1090,49 @@ __global__ __launch_bounds__(256) void k_ba_lin_c(BADev D, St2 st, Lb2 lb, const
     linearize_body<256>(D, st.s[t], lb.b[t], robust, s_buf);
   } else if (bx < nLin + POSE_PARTS * D.np) {
     const int q = bx - nLin, k = q / POSE_PARTS, part = q - k * POSE_PARTS;
-    pose_body(D, st.s[t], lb.b[t], robust, P6, reinterpret_cast<double(*)[27]>(s_buf), k, part, POSE_PARTS,
-              poseP2 + ((size_t)t * D.np * POSE_PARTS + q) * 27);
+    pose_body(D, st.s[t], lb.b[t], robust, P6, reinterpret_cast<double(*)[27]>(s_buf), k, part, POSE_PARTS, xb.at(t) + (size_t)q * 27);
   } else {
-    double *HppO = HppO2 + (size_t)t * ((size_t)P6 * P6 + P6);
-    odom_body<GLOBAL>(D, st.s[t], lb.b[t], P6, chiSlot, GLOBAL ? olGlobal : reinterpret_cast<OdomLin *>(smem), s_buf, HppO, HppO + (size_t)P6 * P6, true);
+    odom_body<GLOBAL>(D, st.s[t], lb.b[t], P6, chiSlot, GLOBAL ? olGlobal : reinterpret_cast<OdomLin *>(smem), s_buf, xb.at(t) + xb.oH, xb.at(t) + xb.oB,
+                      true);
   }
 }
 
 // The decision at the end of a slot (one workgroup): assemble the key frames' diagonal blocks and bp from the parts, sum the
 // chi2 / scale partials in index order (thread 0, from LDS), maximum of the diagonal (computeLambdaInit,
 // optimization_algorithm_levenberg.cpp:166-180), then the LM state machine.
+// Sharded BA: the block of this rank is summed over the ranks between this kernel and the control kernel; the chi2 / scale
+// partials are therefore added up here (index order), next to the abort request and this rank's max |diag Hll|.
+__global__ __launch_bounds__(256) void k_ba_prex(BADev D, Lb2 lb, const BACtl *c, int nLin, int chiSlot, const double *scalePart, int nScale, XBLay xb,
+                                                 const int *abortLocal, int rank, int world) {
+  __shared__ double s_m[256];
+  const int tid = threadIdx.x;
+  const int init = c->needInit, t = init ? c->cur : 1 - c->cur;
+  double *X = xb.at(t);
+  if (c->phase == 2) {  // keep taking part in the exchange with harmless numbers
+    if (tid < 4) X[xb.oS + tid] = (tid == 2 && *abortLocal) ? 1.0 : 0.0;
+    if (tid < world) X[xb.oM + tid] = 0.0;
+    return;
+  }
+  const LinBuf &B = lb.b[t];
+  double m = 0;
+  if (init) for (int i = tid; i < D.npt * 3; i += 256) m = fmax(m, fabs(B.Hll[(size_t)9 * (i / 3) + 4 * (i % 3)]));
+  s_m[tid] = m;
+  __syncthreads();
+  if (tid != 0) return;
+  double chi = 0;
+  for (int i = 0; i < nLin; i++) chi += B.chiPart[i];
+  chi += B.chiPart[chiSlot];
+  double scale = 0;
+  if (!init) for (int i = 0; i < nScale; i++) scale += scalePart[i];
+  double mm = 0;
+  for (int i = 0; i < 256; i++) mm = fmax(mm, s_m[i]);
+  X[xb.oS] = chi; X[xb.oS + 1] = scale; X[xb.oS + 2] = *abortLocal ? 1.0 : 0.0; X[xb.oS + 3] = 0.0;
+  for (int r = 0; r < world; r++) X[xb.oM + r] = r == rank ? mm : 0.0;
+}
+
+template <bool SHARDED>
 __global__ __launch_bounds__(256) void k_ba_control(BADev D, Lb2 lb, BACtl *c, BASched sc, int nLin, int chiSlot, const double *scalePart, int nScale,
-                                                    const double *okFlag, int P6, const double *HppO2, const double *poseP2) {
+                                                    const double *okFlag, int P6, XBLay xb, const int *abortLocal, int world) {
   __shared__ double s_m[256];
   __shared__ double s_chiP[512], s_scaleP[512];
   const int tid = threadIdx.x;
@@ -1099,8 +1140,8 @@ __global__ __launch_bounds__(256) void k_ba_control(BADev D, Lb2 lb, BACtl *c, B
   const int init = c->needInit;
   const int t = init ? c->cur : 1 - c->cur;
   const LinBuf &B = lb.b[t];
-  const double *HppO = HppO2 + (size_t)t * ((size_t)P6 * P6 + P6), *bpO = HppO + (size_t)P6 * P6;
-  const double *poseP = poseP2 + (size_t)t * D.np * POSE_PARTS * 27;
+  const double *XB = xb.at(t);
+  const double *HppO = XB + xb.oH, *bpO = XB + xb.oB, *poseP = XB;
   double m = 0;
   for (int idx = tid; idx < D.np * 42; idx += 256) {  // 36 block entries + 6 bp entries per key frame
     const int k = idx / 42, r = idx - k * 42;
@@ -1120,20 +1161,32 @@ __global__ __launch_bounds__(256) void k_ba_control(BADev D, Lb2 lb, BACtl *c, B
       B.bp[6 * k + i] = v + bpO[6 * k + i];
     }
   }
-  for (int i = tid; i < min(nLin, 512); i += 256) s_chiP[i] = B.chiPart[i];
-  if (!init) for (int i = tid; i < min(nScale, 512); i += 256) s_scaleP[i] = scalePart[i];
-  if (init) for (int i = tid; i < D.npt * 3; i += 256) m = fmax(m, fabs(B.Hll[(size_t)9 * (i / 3) + 4 * (i % 3)]));
+  if (!SHARDED) {
+    for (int i = tid; i < min(nLin, 512); i += 256) s_chiP[i] = B.chiPart[i];
+    if (!init) for (int i = tid; i < min(nScale, 512); i += 256) s_scaleP[i] = scalePart[i];
+    if (init) for (int i = tid; i < D.npt * 3; i += 256) m = fmax(m, fabs(B.Hll[(size_t)9 * (i / 3) + 4 * (i % 3)]));
+  }
   s_m[tid] = m;
   __syncthreads();
   if (tid != 0) return;
-  double chi = 0;
-  for (int i = 0; i < nLin; i++) chi += i < 512 ? s_chiP[i] : B.chiPart[i];
-  chi += B.chiPart[chiSlot];
-  double scale = 0;
-  if (!init) for (int i = 0; i < nScale; i++) scale += i < 512 ? s_scaleP[i] : scalePart[i];
+  double chi = 0, scale = 0;
+  int abortReq;
+  if (SHARDED) {  // reduced over the ranks: identical on all of them, and so is every decision below
+    chi = XB[xb.oS]; scale = XB[xb.oS + 1];
+    abortReq = XB[xb.oS + 2] > 0.0;
+  } else {
+    for (int i = 0; i < nLin; i++) chi += i < 512 ? s_chiP[i] : B.chiPart[i];
+    chi += B.chiPart[chiSlot];
+    if (!init) for (int i = 0; i < nScale; i++) scale += i < 512 ? s_scaleP[i] : scalePart[i];
+    abortReq = *abortLocal;
+  }
   double maxDiag = 0;
-  if (init) for (int i = 0; i < 256; i++) maxDiag = fmax(maxDiag, s_m[i]);
+  if (init) {
+    for (int i = 0; i < 256; i++) maxDiag = fmax(maxDiag, s_m[i]);
+    if (SHARDED) for (int r = 0; r < world; r++) maxDiag = fmax(maxDiag, XB[xb.oM + r]);
+  }
   BACtl k = *c;
+  k.abort = abortReq;
   const int its = k.phase == 0 ? sc.its1 : sc.its2;
   bool endOpt = false;
   k.slots++;
@@ -1180,7 +1233,6 @@ __global__ __launch_bounds__(256) void k_ba_control(BADev D, Lb2 lb, BACtl *c, B
     if (k.phase == 0 && sc.gate && !k.abort && D.nE > 0) { k.phase = 1; k.needInit = 1; k.needGate = 1; }
     else k.phase = 2;
   }
-  k.abort = c->abort;  // the host may have written it meanwhile: keep its value
   *c = k;
 }
 
@@ -1194,6 +1246,18 @@ __global__ void k_ba_export(int n_kf, int npt, const SE3 *pose, const double *pt
   if (g < n_kf) {
     if (!fixed[g]) fb::se3_to_float12(pose[g], kfT + 12 * g);
   } else if (g < n_kf + npt * 3) ptOut[g - n_kf] = (float)pt[g - n_kf];
+}
+
+// sharded result: every rank contributes its own landmarks (points as exported floats) and edge flags, the others zeros
+__global__ void k_ba_final_pack(int npt, int nE, int rank, int world, const float *ptOut, const uint8_t *flags, double *ex) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < npt * 3) ex[g] = ((g / 3) % world == rank) ? (double)ptOut[g] : 0.0;
+  else if (g < npt * 3 + nE) ex[g] = flags[g - npt * 3];
+}
+__global__ void k_ba_final_unpack(int npt, int nE, const double *ex, float *ptOut, uint8_t *flags) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < npt * 3) ptOut[g] = (float)ex[g];
+  else if (g < npt * 3 + nE) flags[g - npt * 3] = ex[g] != 0.0;
 }
 
 __global__ void k_ba_export_c(int n_kf, int npt, St2 st, const BACtl *c, const uint8_t *fixed, float *kfT, float *ptOut) {
@@ -1211,6 +1275,106 @@ __global__ void k_ba_export_c(int n_kf, int npt, St2 st, const BACtl *c, const u
 
 #include "ba_big.inc"
 
+// ---- exchange transport of the landmark-sharded BA ------------------------------------------------------------------
+// RCCL: the all-reduces are enqueued on the BA's stream and work on device buffers (nothing is staged through the host);
+// the entry points are resolved at run time from the RCCL the process already has (torch's librccl.so.1 when the host is
+// Python, /opt/rocm/lib otherwise), so the library carries no link-time dependency and single-GPU users never load it.
+// HOST: the fb_allreduce_fn callback of fb_local_ba_sharded (gloo in the CPU tests; host buffer).
+#include <dlfcn.h>
+namespace {
+struct RcclApi {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;                              // ncclGetUniqueId(ncclUniqueId *)
+  int (*CommInitRank)(void **, int, fb_rccl_unique_id, int) = nullptr; // ncclCommInitRank(comm *, nranks, id BY VALUE, rank)
+  int (*CommDestroy)(void *) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+RcclApi *rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (api.lib) break;
+    }
+    if (api.lib) {
+      api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
+      api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
+      api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
+      api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
+      api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+      if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) api.lib = nullptr;
+    }
+  }
+  return api.lib ? &api : nullptr;
+}
+constexpr int kNcclDouble = 8, kNcclSum = 0;  // ncclFloat64, ncclSum (rccl.h)
+
+struct Xchg {
+  int world = 1;
+  void *comm = nullptr;            // ncclComm_t, or
+  fb_allreduce_fn cb = nullptr;    // host callback
+  void *ctx = nullptr;
+  bool active() const { return world > 1 || comm != nullptr; }  // a 1-rank communicator still goes through RCCL (tests)
+  // in-place sum over the ranks of n doubles in DEVICE memory, ordered behind the work already on stream s
+  // (src may differ from dbuf: out-of-place, the source stays as it is)
+  int sum_dev(double *dbuf, size_t n, hipStream_t s, std::vector<double> &scratch, const double *src = nullptr) const {
+    if (!src) src = dbuf;
+    if (!active() || n == 0) return FB_OK;
+    if (comm) {
+      const int rc = rccl_api()->AllReduce(src, dbuf, n, kNcclDouble, kNcclSum, comm, s);
+      if (rc != 0) { fb::set_error("fb_local_ba_sharded: ncclAllReduce failed: %s", rccl_api()->GetErrorString ? rccl_api()->GetErrorString(rc) : "?"); return FB_ERR_HIP; }
+      return FB_OK;
+    }
+    scratch.resize(n);
+    FB_HIP(hipStreamSynchronize(s));
+    FB_HIP(hipMemcpy(scratch.data(), src, n * 8, hipMemcpyDeviceToHost));
+    if (cb(ctx, scratch.data(), (int32_t)n, 0) != 0) { fb::set_error("fb_local_ba_sharded: all-reduce callback failed"); return FB_ERR_ARG; }
+    FB_HIP(hipMemcpy(dbuf, scratch.data(), n * 8, hipMemcpyHostToDevice));
+    return FB_OK;
+  }
+  // in-place reduction of n doubles in HOST memory (op 0 = sum, 1 = max); the host-driven schedule uses it
+  int reduce_host(double *hbuf, int n, int op) const {
+    if (!active() || n <= 0) return FB_OK;
+    if (cb) {
+      if (cb(ctx, hbuf, n, op) != 0) { fb::set_error("fb_local_ba_sharded: all-reduce callback failed"); return FB_ERR_ARG; }
+      return FB_OK;
+    }
+    fb::DevBuf d;
+    FB_TRY(d.upload(hbuf, (size_t)n * 8));
+    const int rc = rccl_api()->AllReduce(d.p, d.p, (size_t)n, kNcclDouble, op == 0 ? kNcclSum : 2 /* ncclMax */, comm, nullptr);
+    if (rc != 0) { fb::set_error("fb_local_ba_sharded: ncclAllReduce failed (%d)", rc); return FB_ERR_HIP; }
+    FB_HIP(hipStreamSynchronize(nullptr));
+    return d.download(hbuf, (size_t)n * 8);
+  }
+};
+}  // namespace
+
+extern "C" int fb_rccl_get_unique_id(fb_rccl_unique_id *id) {
+  FB_ARG(id);
+  RcclApi *r = rccl_api();
+  if (!r) { fb::set_error("fb_rccl_get_unique_id: no RCCL in this process (librccl.so.1 not found)"); return FB_ERR_NODEVICE; }
+  const int rc = r->GetUniqueId(id);
+  if (rc != 0) { fb::set_error("ncclGetUniqueId failed (%d)", rc); return FB_ERR_HIP; }
+  return FB_OK;
+}
+extern "C" int fb_rccl_comm_init(const fb_rccl_unique_id *id, int rank, int world, void **comm) {
+  FB_TRY(fb::check_device());
+  FB_ARG(id && comm && world >= 1 && rank >= 0 && rank < world);
+  RcclApi *r = rccl_api();
+  if (!r) { fb::set_error("fb_rccl_comm_init: no RCCL in this process (librccl.so.1 not found)"); return FB_ERR_NODEVICE; }
+  const int rc = r->CommInitRank(comm, world, *id, rank);
+  if (rc != 0) { fb::set_error("ncclCommInitRank failed: %s", r->GetErrorString ? r->GetErrorString(rc) : "?"); return FB_ERR_HIP; }
+  return FB_OK;
+}
+extern "C" int fb_rccl_comm_destroy(void *comm) {
+  RcclApi *r = rccl_api();
+  if (comm && r) r->CommDestroy(comm);
+  return FB_OK;
+}
+
 // optimisation schedule: LocalBundleAdjustment[WithOdom] = optimize(5) robust, chi2 gate, optimize(10) plain
 // (Optimizer.cc:2504-2560); BundleAdjustmentWithOdom = ONE optimize(nIterations), robust iff bRobust, no gate (:2048-2050)
 struct BASchedule {
@@ -1219,40 +1383,88 @@ struct BASchedule {
   int its2;
   double delta;  // Huber delta: sqrt(5.991) local (:2290), sqrt(5.99) global (:1836)
 };
-static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allreduce_fn allreduce, void *ctx, const BASchedule &sc);
+static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, const BASchedule &sc);
 static const BASchedule kLocalSchedule = {5, 1, true, 10, (double)(float)sqrt(5.991)};
 
-extern "C" int fb_local_ba(const fb_local_ba_args *A) { return local_ba_impl(A, 0, 1, nullptr, nullptr, kLocalSchedule); }
+extern "C" int fb_local_ba(const fb_local_ba_args *A) { return local_ba_impl(A, 0, Xchg(), kLocalSchedule); }
 
 extern "C" int fb_global_ba(const fb_local_ba_args *A, int n_iterations, int robust) {
   FB_ARG(n_iterations >= 0);
   const BASchedule sc = {n_iterations, robust ? 1 : 0, false, 0, (double)(float)sqrt(5.99)};
-  return local_ba_impl(A, 0, 1, nullptr, nullptr, sc);
+  return local_ba_impl(A, 0, Xchg(), sc);
 }
 
 extern "C" int fb_local_ba_sharded(const fb_local_ba_args *A, int rank, int world, fb_allreduce_fn allreduce, void *ctx) {
   FB_ARG(world >= 1 && rank >= 0 && rank < world && (world == 1 || allreduce));
-  return local_ba_impl(A, rank, world, allreduce, ctx, kLocalSchedule);
+  Xchg X;
+  X.world = world; X.cb = allreduce; X.ctx = ctx;
+  return local_ba_impl(A, rank, X, kLocalSchedule);
+}
+
+extern "C" int fb_local_ba_sharded_rccl(const fb_local_ba_args *A, int rank, int world, void *comm) {
+  FB_ARG(world >= 1 && rank >= 0 && rank < world && comm);
+  if (!rccl_api()) { fb::set_error("fb_local_ba_sharded_rccl: no RCCL in this process"); return FB_ERR_NODEVICE; }
+  Xchg X;
+  X.world = world; X.comm = comm;
+  return local_ba_impl(A, rank, X, kLocalSchedule);
 }
 
 // Landmark-partitioned BA: rank r owns the landmarks l with l % world == r and all their edges, the
 // odometry edges live on rank 0, the keyframe state is replicated.  Per LM trial two small all-reduces: the
 // Schur-reduced system (after k_ba_schur) and [Hpp, bp, chi2, scale] (after the linearisation at the trial state).
-static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allreduce_fn allreduce, void *ctx, const BASchedule &sc) {
+static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, const BASchedule &sc) {
   FB_TRY(fb::check_device());
+  const int world = X.world;
   const bool timing = getenv("FB_BA_TIMING") != nullptr;  // host-side phase times on stderr (probe)
   const auto tStart = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
     if (timing) fprintf(stderr, "[fb_local_ba] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tStart).count());
   };
-  const bool sharded = world > 1;
-  auto reduce = [&](double *buf, int n, int op) -> int {
-    if (!sharded || n <= 0) return FB_OK;
-    if (allreduce(ctx, buf, n, op) != 0) { fb::set_error("fb_local_ba_sharded: all-reduce callback failed"); return FB_ERR_ARG; }
-    return FB_OK;
-  };
+  const bool sharded = X.active();
+  auto reduce = [&](double *buf, int n, int op) -> int { return sharded ? X.reduce_host(buf, n, op) : FB_OK; };
   FB_ARG(A && A->n_kf > 0 && A->n_mp >= 0 && A->n_mpb >= 0 && A->n_obs >= 0 && A->kf_Tcw && A->kf_fixed);
-  if (A->stop_flag && *A->stop_flag) return FB_OK;  // Optimizer.cc:902-906 / 2498-2500
+  // Optimizer.cc:902-906 / 2498-2500.  Sharded: a rank must not leave on its OWN view of the flag (the others would wait for
+  // it in the first exchange): every stop decision below goes through a reduction
+  if (!sharded && A->stop_flag && *A->stop_flag) return FB_OK;
+  if (sharded) {
+    // Agreement on the arguments before the first exchange: a rank that rejected its input alone would leave the others
+    // waiting in a collective.  (The same checks run again below, where they can no longer fail.)
+    int bad = 0;
+    if (!(A && A->n_kf > 0 && A->n_mp >= 0 && A->n_mpb >= 0 && A->n_obs >= 0 && A->kf_Tcw && A->kf_fixed)) bad = 1;
+    if (!bad) {
+      const bool od = A->with_odom != 0;
+      int free = 0;
+      for (int k = 0; k < A->n_kf; k++) free += A->kf_fixed[k] ? 0 : 1;
+      if (6 * free > 4096) bad = 1;
+      std::vector<long long> pairs;
+      pairs.reserve((size_t)A->n_obs + (od ? A->n_bobs : 0));
+      for (int i = 0; i < A->n_obs && !bad; i++) {
+        if (!(A->obs_mp[i] >= 0 && A->obs_mp[i] < A->n_mp && A->obs_kf[i] >= 0 && A->obs_kf[i] < A->n_kf)) bad = 1;
+        else pairs.push_back(((long long)A->obs_mp[i] << 32) | (unsigned)A->obs_kf[i]);
+      }
+      for (int i = 0; od && i < A->n_bobs && !bad; i++) {
+        if (!(A->bobs_mpb[i] >= 0 && A->bobs_mpb[i] < A->n_mpb && A->bobs_kf[i] >= 0 && A->bobs_kf[i] < A->n_kf)) bad = 1;
+        else pairs.push_back(((long long)(A->n_mp + A->bobs_mpb[i]) << 32) | (unsigned)A->bobs_kf[i]);
+      }
+      for (int i = 0; od && rank == 0 && i < A->n_odom && !bad; i++)
+        if (!(A->odom_kf_i[i] >= 0 && A->odom_kf_i[i] < A->n_kf && A->odom_kf_j[i] >= 0 && A->odom_kf_j[i] < A->n_kf)) bad = 1;
+      if (!bad) {
+        std::sort(pairs.begin(), pairs.end());
+        if (std::adjacent_find(pairs.begin(), pairs.end()) != pairs.end()) bad = 1;
+      }
+    }
+    double v = bad;
+    FB_TRY(X.reduce_host(&v, 1, 1));
+    if (v > 0.0) {
+      fb::set_error(bad ? "fb_local_ba_sharded: bad arguments on this rank" : "fb_local_ba_sharded: another rank rejected its arguments");
+      return FB_ERR_ARG;
+    }
+  }
+  auto stopped = [&]() -> bool {
+    double v = (A->stop_flag && *A->stop_flag) ? 1.0 : 0.0;
+    if (sharded && X.reduce_host(&v, 1, 1) != FB_OK) return true;
+    return v > 0.0;
+  };
   const bool odom = A->with_odom != 0;
   const int n_kf = A->n_kf, n_mp = A->n_mp, n_mpb = odom ? A->n_mpb : 0;
   const int npt = A->n_mp + A->n_mpb;  // bird points keep their slots even when unused
@@ -1469,19 +1681,24 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
   }
   hipStream_t s0 = nullptr;
 
-  // ---- device-resident Levenberg-Marquardt (LDS-resident reduced system, one GPU): no read-back inside the schedule
-  if (!sharded && !big && !getenv("FB_BA_TRACE") && !getenv("FB_BA_HOST_LM")) {
-    static hipStream_t sAux = nullptr;      // side stream for the abort flag (does not synchronise with the null stream)
+  // ---- device-resident Levenberg-Marquardt (LDS-resident reduced system): no read-back inside the schedule.  Sharded:
+  //      two all-reduces per slot on this stream (the Schur-reduced system; the exchange block of the linearisation), every
+  //      rank enqueues the same slots and takes the same decisions from the reduced values.
+  if (!big && !getenv("FB_BA_TRACE") && !getenv("FB_BA_HOST_LM")) {
+    static hipStream_t sAux = nullptr;      // side stream for the abort request (does not synchronise with the null stream)
     static BACtl *hCtl = nullptr;           // pinned mirror of the control block
     if (!sAux) FB_HIP(hipStreamCreateWithFlags(&sAux, hipStreamNonBlocking));
     if (!hCtl) FB_HIP(hipHostMalloc(reinterpret_cast<void **>(&hCtl), sizeof(BACtl), hipHostMallocDefault));
-    fb::DevBuf d_ctl, d_flags, d_kfT, d_ptOut;
+    fb::DevBuf d_ctl, d_flags, d_kfT, d_ptOut, d_xb, d_abort, d_ex;
     BACtl init;
     memset(&init, 0, sizeof(init));
-    const bool anything = nE + nO > 0 && (np > 0 || npt > 0);
+    // (sharded: nE / nO are this rank's view; every rank holds all edges, so `anything` agrees across the ranks)
+    const bool anything = nE + (odom ? A->n_odom : 0) > 0 && (np > 0 || npt > 0);
     init.phase = anything ? 0 : 2;
     init.needInit = 1;
     FB_TRY(d_ctl.upload(&init, sizeof(init)));
+    const int abort0 = (A->stop_flag && *A->stop_flag) ? 1 : 0;  // sharded: raised before the call on this rank only
+    FB_TRY(d_abort.upload(&abort0, sizeof(int)));
     BACtl *ctl = d_ctl.as<BACtl>();
     const BASched sched = {sc.its1, sc.robust1, sc.gate ? 1 : 0, sc.its2};
     St2 st2; st2.s[0] = st[0]; st2.s[1] = st[1];
@@ -1491,32 +1708,48 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
     FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve_c), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
     const int nS = rows * rows;
     const int nLin256 = (npt + 255) / 256;
-    // scratch of the two linearisation buffers: odometry blocks [HppO | bpO] and the key-frame parts
-    const size_t odomO = (size_t)P6 * P6 + P6;
-    fb::DevBuf d_odomO, d_poseP;
-    FB_TRY(d_odomO.alloc((2 * odomO + 1) * 8));
-    FB_TRY(d_poseP.alloc(((size_t)2 * np * POSE_PARTS * 27 + 1) * 8));
-    double *HppO2 = d_odomO.as<double>(), *poseP2 = d_poseP.as<double>();
+    XBLay xb;
+    xb.oH = np * POSE_PARTS * 27; xb.oB = xb.oH + P6 * P6; xb.oS = xb.oB + P6; xb.oM = xb.oS + 4; xb.stride = xb.oM + world;
+    // sharded: the kernels of a linearisation fill the RAW blocks; exchange 2 sums BOTH raw blocks into the REDUCED ones out of
+    // place (which of the two the slot wrote is device-side knowledge; the raw block of the accepted linearisation is not
+    // touched until it is overwritten, so re-reducing it is idempotent); k_ba_control and k_ba_solve read the reduced blocks
+    FB_TRY(d_xb.alloc((size_t)(sharded ? 4 : 2) * xb.stride * 8));
+    FB_HIP(hipMemsetAsync(d_xb.p, 0, (size_t)(sharded ? 4 : 2) * xb.stride * 8, s0));
+    xb.base = d_xb.as<double>();
+    XBLay xr = xb;  // reduced
+    if (sharded) xr.base = xb.base + (size_t)2 * xb.stride;
     if (!olGlobal) FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_lin_c<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)odomLds));
     const int linGrid = nLin256 + POSE_PARTS * np + 1;
+    std::vector<double> hostScratch;
+    int rcSlot = FB_OK;
     auto slot = [&]() {
+      if (rcSlot != FB_OK) return;
       { fb::ProfScope pr(fb::P_BA_SCHUR, s0);
         schurC<<<nWg, SCHUR_THREADS, schurLds, s0>>>(D, lb2, ctl, d_Dinv.as<double>(), d_Spart.as<double>(), P6, NT, lmPerWg); }
       { fb::ProfScope pr(fb::P_BA_SOLVE, s0);
         k_ba_sumparts_c<<<(nS + 255) / 256, 256, 0, s0>>>(ctl, d_Spart.as<double>(), nWg, nS);
-        k_ba_solve_c<<<1, SOLVE_THREADS, solveLds, s0>>>(lb2, ctl, d_Spart.as<double>(), P6, NT, d_xp.as<double>(), d_scal.as<double>() + 3, HppO2); }
+        if (sharded) rcSlot = X.sum_dev(d_Spart.as<double>(), (size_t)nS, s0, hostScratch);  // exchange 1: the Schur-reduced system
+        k_ba_solve_c<<<1, SOLVE_THREADS, solveLds, s0>>>(lb2, ctl, d_Spart.as<double>(), P6, NT, d_xp.as<double>(), d_scal.as<double>() + 3, xr); }
       { fb::ProfScope pr(fb::P_BA_UPDATE, s0);
-        k_ba_update_c<<<nUpdBlocks, LIN_THREADS, 0, s0>>>(D, lb2, st2, ctl, d_Dinv.as<double>(), d_xp.as<double>(), d_scale.as<double>()); }
+        k_ba_update_c<<<nUpdBlocks, LIN_THREADS, 0, s0>>>(D, lb2, st2, ctl, d_Dinv.as<double>(), d_xp.as<double>(), d_scale.as<double>(), rank == 0 ? 1 : 0); }
       { fb::ProfScope pr(fb::P_BA_LINEARIZE, s0);
-        if (olGlobal) k_ba_lin_c<true><<<linGrid, 256, 0, s0>>>(D, st2, lb2, ctl, sched, P6, nLin256, nLinBlocks, olGlobal, HppO2, poseP2);
-        else k_ba_lin_c<false><<<linGrid, 256, odomLds, s0>>>(D, st2, lb2, ctl, sched, P6, nLin256, nLinBlocks, nullptr, HppO2, poseP2); }
+        if (olGlobal) k_ba_lin_c<true><<<linGrid, 256, 0, s0>>>(D, st2, lb2, ctl, sched, P6, nLin256, nLinBlocks, olGlobal, xb);
+        else k_ba_lin_c<false><<<linGrid, 256, odomLds, s0>>>(D, st2, lb2, ctl, sched, P6, nLin256, nLinBlocks, nullptr, xb); }
       { fb::ProfScope pr(fb::P_BA_MISC, s0);
-        k_ba_control<<<1, 256, 0, s0>>>(D, lb2, ctl, sched, nLin256, nLinBlocks, d_scale.as<double>(), nUpdBlocks, d_scal.as<double>() + 3, P6, HppO2, poseP2); }
+        if (sharded) {
+          k_ba_prex<<<1, 256, 0, s0>>>(D, lb2, ctl, nLin256, nLinBlocks, d_scale.as<double>(), nUpdBlocks, xb, d_abort.as<int>(), rank, world);
+          // exchange 2: both raw blocks -> the reduced blocks, one all-reduce
+          if (rcSlot == FB_OK) rcSlot = X.sum_dev(xr.at(0), (size_t)2 * xb.stride, s0, hostScratch, xb.at(0));
+          k_ba_control<true><<<1, 256, 0, s0>>>(D, lb2, ctl, sched, nLin256, nLinBlocks, d_scale.as<double>(), nUpdBlocks, d_scal.as<double>() + 3, P6, xr, d_abort.as<int>(), world);
+        } else {
+          k_ba_control<false><<<1, 256, 0, s0>>>(D, lb2, ctl, sched, nLin256, nLinBlocks, d_scale.as<double>(), nUpdBlocks, d_scal.as<double>() + 3, P6, xb, d_abort.as<int>(), world);
+        } }
     };
     FB_TRY(d_flags.alloc(std::max(nE, 1)));
     FB_TRY(d_kfT.alloc((size_t)n_kf * 48));
     FB_HIP(hipMemcpyAsync(d_kfT.p, d_kfT0, (size_t)n_kf * 48, hipMemcpyDeviceToDevice, s0));
     FB_TRY(d_ptOut.alloc((size_t)std::max(npt, 1) * 12));
+    if (sharded) FB_TRY(d_ex.alloc(((size_t)npt * 3 + nE + 1) * 8));
     hipEvent_t evDone = nullptr;
     FB_HIP(hipEventCreateWithFlags(&evDone, hipEventDisableTiming));
     bool abortSent = false;
@@ -1527,20 +1760,28 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
     lap("buffers ready");
     for (int round = 0; round < 64; round++) {
       for (int i = 0; i < batch; i++) slot();
+      if (rcSlot != FB_OK) { rcLoop = rcSlot; break; }
       lap("slots enqueued");
       // the results of the state that is current now (final when the schedule has finished, which is the common case)
       if (nE > 0) k_ba_gate_final_c<<<(nE + 255) / 256, 256, 0, s0>>>(D, st2, ctl, d_flags.as<uint8_t>());
       k_ba_export_c<<<(n_kf + npt * 3 + 255) / 256, 256, 0, s0>>>(n_kf, npt, st2, ctl, d_fixed, d_kfT.as<float>(), d_ptOut.as<float>());
+      if (sharded) {  // every rank returns the complete result
+        const int nx = npt * 3 + nE;
+        k_ba_final_pack<<<(nx + 255) / 256, 256, 0, s0>>>(npt, nE, rank, world, d_ptOut.as<float>(), d_flags.as<uint8_t>(), d_ex.as<double>());
+        rcLoop = X.sum_dev(d_ex.as<double>(), (size_t)nx, s0, hostScratch);
+        if (rcLoop != FB_OK) break;
+        k_ba_final_unpack<<<(nx + 255) / 256, 256, 0, s0>>>(npt, nE, d_ex.as<double>(), d_ptOut.as<float>(), d_flags.as<uint8_t>());
+      }
       if (hipGetLastError() != hipSuccess) { fb::set_error("fb_local_ba: kernel launch failed"); rcLoop = FB_ERR_HIP; break; }
       if (hipMemcpyAsync(hCtl, ctl, sizeof(BACtl), hipMemcpyDeviceToHost, s0) != hipSuccess || hipEventRecord(evDone, s0) != hipSuccess) {
         fb::set_error("fb_local_ba: control block read-back failed"); rcLoop = FB_ERR_HIP; break;
       }
-      for (;;) {  // wait; meanwhile forward pbStopFlag (polled by k_ba_control at the end of every slot)
+      for (;;) {  // wait; meanwhile forward pbStopFlag (the control kernel sees it at the end of the slot that is running)
         const hipError_t q = hipEventQuery(evDone);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) { fb::set_error("fb_local_ba: %s", hipGetErrorString(q)); rcLoop = FB_ERR_HIP; break; }
         if (!abortSent && A->stop_flag && *A->stop_flag) {
-          (void)hipMemcpyAsync(&ctl->abort, &one, sizeof(int), hipMemcpyHostToDevice, sAux);
+          (void)hipMemcpyAsync(d_abort.p, &one, sizeof(int), hipMemcpyHostToDevice, sAux);
           abortSent = true;
         }
       }
@@ -1621,7 +1862,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
     double lambda = 0, ni = 2;
     int nBad = 0;
     for (int it = 0; it < iterations; it++) {
-      if (A->stop_flag && *A->stop_flag) break;  // terminate()
+      if (stopped()) break;  // terminate()
       const double iniChi = currentChi;
       if (it == 0) { lambda = 1e-5 * maxDiag; ni = 2; nBad = 0; }
       double rho = 0;
@@ -1691,7 +1932,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
           ni *= 2;  // pop: keep `cur`
         }
         qmax++;
-      } while (rho < 0 && qmax < 10 && !(A->stop_flag && *A->stop_flag));
+      } while (rho < 0 && qmax < 10 && !stopped());
       if (qmax == 10 || rho == 0) break;
       if ((iniChi - currentChi) * 1e3 < iniChi) nBad++;
       else nBad = 0;
@@ -1700,7 +1941,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, int world, fb_allr
     return FB_OK;
   };
   if (nE + nO > 0 && (np > 0 || npt > 0)) FB_TRY(optimize(sc.its1, sc.robust1));
-  const bool more = sc.gate && !(A->stop_flag && *A->stop_flag);
+  const bool more = sc.gate && !stopped();
   if (more && nE > 0) {
     k_ba_gate<<<(nE + 255) / 256, 256, 0, s0>>>(D, st[cur], 1, nullptr);
     if (nE + nO > 0) FB_TRY(optimize(sc.its2, 0));

@@ -15,7 +15,8 @@ import numpy as np
 from . import cabi
 
 # what bench.py prints next to the sharded-BA numbers
-TRANSPORT_NOTE = "host-staged all-reduce callback: D2H, torch.distributed all_reduce, H2D"
+TRANSPORT_RCCL = "RCCL inside the library: ncclAllReduce on device buffers, enqueued on the BA stream (2 per LM trial)"
+TRANSPORT_HOST = "host-staged all-reduce callback: D2H, torch.distributed all_reduce, H2D"
 
 
 def init_from_env(backend=None, device=None):
@@ -78,3 +79,34 @@ def make_allreduce(group=None, stage_device=None):
 def local_ba_sharded(lib, args, rank, world, allreduce):
     from . import check
     check(lib.fb_local_ba_sharded(C.byref(args), rank, world, allreduce, None), "fb_local_ba_sharded")
+
+
+class RcclComm:
+    """An ncclComm_t made by the library's own RCCL binding (fb_rccl_*): rank 0 draws the unique id, torch.distributed
+    (whatever backend the process group has) carries its 128 bytes to the other ranks."""
+
+    def __init__(self, lib, rank, world, device=None):
+        import torch
+        import torch.distributed as dist
+        from . import check
+        self.lib, self.comm = lib, C.c_void_p()
+        uid = (C.c_char * 128)()
+        if rank == 0:
+            check(lib.fb_rccl_get_unique_id(C.byref(uid)), "fb_rccl_get_unique_id")
+        if world > 1:
+            t = torch.tensor(list(bytes(uid)), dtype=torch.uint8)
+            if dist.get_backend() == "nccl":
+                t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+            dist.broadcast(t, src=0)
+            uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
+        check(lib.fb_rccl_comm_init(C.byref(uid), rank, world, C.byref(self.comm)), "fb_rccl_comm_init")
+
+    def close(self):
+        if self.comm:
+            self.lib.fb_rccl_comm_destroy(self.comm)
+            self.comm = C.c_void_p()
+
+
+def local_ba_sharded_rccl(lib, args, rank, world, comm):
+    from . import check
+    check(lib.fb_local_ba_sharded_rccl(C.byref(args), rank, world, comm.comm), "fb_local_ba_sharded_rccl")

@@ -758,6 +758,19 @@ int fb_global_ba(const fb_local_ba_args *args, int n_iterations, int robust);
 typedef int (*fb_allreduce_fn)(void *ctx, double *buf, int32_t n, int32_t op);
 int fb_local_ba_sharded(const fb_local_ba_args *args, int rank, int world, fb_allreduce_fn allreduce, void *ctx);
 
+/* The same with RCCL inside the library: the two exchanges of an LM trial are ncclAllReduce calls on device buffers,
+ * enqueued on the BA's stream between its kernels (no host staging, no read-back: the Levenberg-Marquardt state machine
+ * runs on the device and takes identical decisions on every rank from the reduced values; pbStopFlag and a rank's
+ * argument errors travel inside the reduced buffers so that every branch is collective).  `comm` is an ncclComm_t over
+ * the `world` ranks.  RCCL is resolved at run time (dlopen of librccl.so.1: torch's when the host is Python), so the
+ * library has no link-time dependency on it; fb_rccl_* wrap ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy of that
+ * same RCCL for hosts that do not own a communicator yet (rank 0 makes the id, the host broadcasts its 128 bytes).  */
+typedef struct fb_rccl_unique_id { char internal[128]; } fb_rccl_unique_id;
+int fb_rccl_get_unique_id(fb_rccl_unique_id *id);
+int fb_rccl_comm_init(const fb_rccl_unique_id *id, int rank, int world, void **comm);
+int fb_rccl_comm_destroy(void *comm);
+int fb_local_ba_sharded_rccl(const fb_local_ba_args *args, int rank, int world, void *comm);
+
 #ifdef __cplusplus
 }
 #endif

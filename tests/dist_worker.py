@@ -29,30 +29,49 @@ def main():
         assert cb(None, buf2, 2, 1) == 0
         assert list(buf2) == [1.0, 0.0]
         print("rank %d helpers ok" % rank, flush=True)
-    elif mode == "ba":
-        # landmark-sharded local BA on ONE GPU shared by the two ranks, gloo for the exchange
+    elif mode in ("ba", "ba_config5", "ba_stop"):
+        # landmark-sharded local BA on ONE GPU shared by the two ranks, gloo for the exchange (host-callback transport; the
+        # protocol -- slots, exchange blocks, device-side decisions -- is the one the RCCL transport runs)
         import fishbirdeyevisualslam_amd as fb
+        import oracle_lib as O
         from fishbirdeyevisualslam_amd import ba_problem, synth
         L = fb.lib()
-        p = synth.make_ba_problem(4000, n_kf=8, n_mp=1200, n_mpb=300)
-        a, out_s, keep = ba_problem.local_ba_args(p, with_odom=1)
+        if mode == "ba_config5":   # BASELINE config 5's shape: 20 key frames x 8000 + 2000 points
+            p = synth.make_ba_problem(4000, n_kf=20, n_mp=8000, n_mpb=2000)
+        else:
+            p = synth.make_ba_problem(4000, n_kf=8, n_mp=1200, n_mpb=300)
         cb = fbd.make_allreduce()
-        fbd.local_ba_sharded(L, a, rank, world, cb)
-        a1, out_1, keep1 = ba_problem.local_ba_args(p, with_odom=1)
-        fb.check(L.fb_local_ba(C.byref(a1)), "fb_local_ba")
-        rel = lambda x, y: float(np.abs(x - y).max() / max(1.0, np.abs(y).max()))
-        r = [rel(out_s["kf_Tcw"], out_1["kf_Tcw"]), rel(out_s["mp_xw"], out_1["mp_xw"]), rel(out_s["mpb_xw"], out_1["mpb_xw"])]
-        same = bool(np.array_equal(out_s["obs_outlier"], out_1["obs_outlier"]) and
-                    np.array_equal(out_s["bobs_outlier"][: len(p["bobs_kf"])], out_1["bobs_outlier"][: len(p["bobs_kf"])]))
-        # both ranks must hold the identical complete result
-        t = torch.from_numpy(out_s["kf_Tcw"].astype(np.float64).copy())
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tmin = t.clone()
-        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
-        identical = bool(torch.equal(tmax, tmin))
-        print("rank %d ba rel=%s flags_equal=%s identical_across_ranks=%s" % (rank, ["%.2e" % x for x in r], same, identical), flush=True)
-        assert max(r) <= 1e-4 and same and identical
+        if mode == "ba_stop":
+            # pbStopFlag raised on rank 1 ONLY, before the call: rank 0 must not hang in an exchange rank 1 never enters, and
+            # both ranks must come back with the same (barely optimised) result
+            stop = np.array([1 if rank == 1 else 0], np.uint8)
+            a, out_s, keep = ba_problem.local_ba_args(p, with_odom=1, stop_flag=stop)
+            fbd.local_ba_sharded(L, a, rank, world, cb)
+            t = torch.from_numpy(np.concatenate([out_s["kf_Tcw"].ravel(), out_s["mp_xw"].ravel()]).astype(np.float64))
+            tmax, tmin = t.clone(), t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+            identical = bool(torch.equal(tmax, tmin))
+            print("rank %d ba_stop returned identical_across_ranks=%s" % (rank, identical), flush=True)
+            assert identical
+        else:
+            a, out_s, keep = ba_problem.local_ba_args(p, with_odom=1)
+            fbd.local_ba_sharded(L, a, rank, world, cb)
+            a1, out_1, keep1 = ba_problem.local_ba_args(p, with_odom=1)
+            O.call("orc_local_ba", a1)   # the CPU oracle on the unsharded problem
+            rel = lambda x, y: float(np.abs(x - y).max() / max(1.0, np.abs(y).max()))
+            r = [rel(out_s["kf_Tcw"], out_1["kf_Tcw"]), rel(out_s["mp_xw"], out_1["mp_xw"]), rel(out_s["mpb_xw"], out_1["mpb_xw"])]
+            same = bool(np.array_equal(out_s["obs_outlier"], out_1["obs_outlier"]) and
+                        np.array_equal(out_s["bobs_outlier"][: len(p["bobs_kf"])], out_1["bobs_outlier"][: len(p["bobs_kf"])]))
+            # both ranks must hold the identical complete result
+            t = torch.from_numpy(out_s["kf_Tcw"].astype(np.float64).copy())
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tmin = t.clone()
+            dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+            identical = bool(torch.equal(tmax, tmin))
+            print("rank %d %s vs oracle rel=%s flags_equal=%s identical_across_ranks=%s" % (rank, mode, ["%.2e" % x for x in r], same, identical), flush=True)
+            assert max(r) <= 1e-4 and same and identical
     dist.barrier()
     dist.destroy_process_group()
 
