@@ -303,7 +303,11 @@ int fb_match_projection_points_dev(const fb_proj_points_args *args, void *stream
 int fb_match_projection_points(const fb_proj_points_args *args);
 
 /* --- M8: BirdviewMatch(CurF, refKeys, refDesc, refMPBirds, matches, isProject=0, window)
- *     (ORBmatcher.cc:1602-1760), live form isProject=0                        */
+ *     (ORBmatcher.cc:1602-1760), live form isProject=0.
+ *     NOT BUILT: the isProject != 0 branch (ORBmatcher.cc:1617-1655: search centre = the reference MapPointBird projected
+ *     with Tbc * Tcw, |z| <= 0.2 m gate, no level filter).  No call site of the reference uses it (Tracking.cc:384,407,
+ *     450,959,2728 all pass 0); a caller that needs projected bird search has fb_match_bird_mappoints (M9), which is that
+ *     projection + window search (BirdMapPointMatch, ORBmatcher.cc:1763-1902).                                        */
 typedef struct fb_birdview_args {
   int32_t batch;
   int32_t cur_stride;
