@@ -68,6 +68,7 @@ struct LinBuf {  // linearisation at one state
   double *Hpp;   // [P6][P6] dense
   double *bp;    // [P6]
   double *chiPart;  // [nLinBlocks + 1] (last = odom chi2)
+  double *maxPart;  // [nLinBlocks] max |diag Hll| of the block's landmarks (lambda_0 = 1e-5 max diag; device-resident schedule)
 };
 
 struct State {
@@ -166,7 +167,7 @@ __device__ __forceinline__ void edge_jacobians(const BADev &D, int type, const S
 template <int TH>
 __device__ __forceinline__ void linearize_body(const BADev &D, const State &S, const LinBuf &B, int robust, double *s_part) {
   const int l = blockIdx.x * TH + threadIdx.x;
-  double chi = 0;
+  double chi = 0, hmax = 0;
   if (l < D.npt) {
     const double X[3] = {S.pt[3 * l], S.pt[3 * l + 1], S.pt[3 * l + 2]};
     double H[9], b3[3] = {0, 0, 0};
@@ -252,14 +253,18 @@ __device__ __forceinline__ void linearize_body(const BADev &D, const State &S, c
     for (int i = 0; i < 9; i++) B.Hll[(size_t)9 * l + i] = H[i];
 #pragma unroll
     for (int i = 0; i < 3; i++) B.bl[(size_t)3 * l + i] = b3[i];
+    hmax = fmax(fmax(fabs(H[0]), fabs(H[4])), fabs(H[8]));
   }
   const double ws = wave_sum_d(chi);
-  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = ws;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) hmax = fmax(hmax, __shfl_xor(hmax, o, 64));
+  if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6] = ws; s_part[TH / 64 + (threadIdx.x >> 6)] = hmax; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double s = 0;
-    for (int i = 0; i < TH / 64; i++) s += s_part[i];
+    double s = 0, m = 0;
+    for (int i = 0; i < TH / 64; i++) { s += s_part[i]; m = fmax(m, s_part[TH / 64 + i]); }
     B.chiPart[blockIdx.x] = s;
+    if (B.maxPart) B.maxPart[blockIdx.x] = m;
   }
 }
 
@@ -978,7 +983,7 @@ __device__ __forceinline__ void gate_edge(const BADev &D, const State &S, int se
 // ---- __global__ entry points of the bodies above: explicit arguments (host-driven Levenberg-Marquardt: sharded BA, the
 //      HBM-resident reduced system of ba_big.inc, FB_BA_TRACE) ---------------------------------------------------------
 __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BADev D, State S, LinBuf B, int robust) {
-  __shared__ double s_part[LIN_THREADS / 64];
+  __shared__ double s_part[2 * LIN_THREADS / 64];
   linearize_body<LIN_THREADS>(D, S, B, robust, s_part);
 }
 __global__ __launch_bounds__(POSE_THREADS) void k_ba_pose(BADev D, State S, LinBuf B, int robust, int P6) {
@@ -1115,7 +1120,7 @@ __global__ __launch_bounds__(256) void k_ba_prex(BADev D, Lb2 lb, const BACtl *c
   }
   const LinBuf &B = lb.b[t];
   double m = 0;
-  if (init) for (int i = tid; i < D.npt * 3; i += 256) m = fmax(m, fabs(B.Hll[(size_t)9 * (i / 3) + 4 * (i % 3)]));
+  if (init) for (int i = tid; i < nLin; i += 256) m = fmax(m, B.maxPart[i]);
   s_m[tid] = m;
   __syncthreads();
   if (tid != 0) return;
@@ -1164,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_ba_control(BADev D, Lb2 lb, BACtl *c, B
   if (!SHARDED) {
     for (int i = tid; i < min(nLin, 512); i += 256) s_chiP[i] = B.chiPart[i];
     if (!init) for (int i = tid; i < min(nScale, 512); i += 256) s_scaleP[i] = scalePart[i];
-    if (init) for (int i = tid; i < D.npt * 3; i += 256) m = fmax(m, fabs(B.Hll[(size_t)9 * (i / 3) + 4 * (i % 3)]));
+    if (init) for (int i = tid; i < nLin; i += 256) m = fmax(m, B.maxPart[i]);
   }
   s_m[tid] = m;
   __syncthreads();
@@ -1502,45 +1507,52 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   memcpy(h_poseIdx, poseIdx.data(), (size_t)n_kf * 4);
   memcpy(hs + o_fixed, A->kf_fixed, n_kf);
   memcpy(hs + o_kfT, A->kf_Tcw, (size_t)n_kf * 48);
+  // one pass over the observations fills the per-edge arrays and counts the two CSR structures, a second one scatters
+  for (int l = 0; l <= npt; l++) lm_start[l] = 0;
+  for (int k = 0; k <= np; k++) ps_start[k] = 0;
+  const double wFd = (double)A->wF, wBd = (double)A->wB;
   for (int i = 0; i < nF; i++) {
-    FB_ARG(A->obs_mp[i] >= 0 && A->obs_mp[i] < n_mp && A->obs_kf[i] >= 0 && A->obs_kf[i] < n_kf);
-    e_pt[i] = A->obs_mp[i]; e_kf[i] = A->obs_kf[i]; e_type[i] = T_PROJ;
+    const int pt = A->obs_mp[i], kf = A->obs_kf[i];
+    FB_ARG(pt >= 0 && pt < n_mp && kf >= 0 && kf < n_kf);
+    e_pt[i] = pt; e_kf[i] = kf; e_type[i] = T_PROJ;
     e_meas[3 * i] = A->obs_uv[2 * i]; e_meas[3 * i + 1] = A->obs_uv[2 * i + 1]; e_meas[3 * i + 2] = 0.0;
-    e_info[i] = odom ? (1.0 * (double)A->obs_inv_sigma2[i]) * (double)A->wF : (double)A->obs_inv_sigma2[i];
+    e_info[i] = odom ? (1.0 * (double)A->obs_inv_sigma2[i]) * wFd : (double)A->obs_inv_sigma2[i];
+    e_level[i] = (sharded && pt % world != rank) ? 2 : 0;  // 2 = not this rank's landmark
+    const int pj = poseIdx[kf];
+    e_pj[i] = pj;
+    lm_start[pt + 1]++;
+    if (pj >= 0) ps_start[pj + 1]++;
   }
   for (int i = 0; i < nB; i++) {
     FB_ARG(A->bobs_mpb[i] >= 0 && A->bobs_mpb[i] < A->n_mpb && A->bobs_kf[i] >= 0 && A->bobs_kf[i] < n_kf);
-    const int e = nF + i;
-    e_pt[e] = n_mp + A->bobs_mpb[i]; e_kf[e] = A->bobs_kf[i]; e_type[e] = T_XYZ;
+    const int e = nF + i, pt = n_mp + A->bobs_mpb[i], kf = A->bobs_kf[i];
+    e_pt[e] = pt; e_kf[e] = kf; e_type[e] = T_XYZ;
     for (int k = 0; k < 3; k++) e_meas[3 * e + k] = A->bobs_xc[3 * i + k];
-    e_info[e] = (1.0 * (double)A->bobs_inv_sigma2[i]) * (double)A->wB;
+    e_info[e] = (1.0 * (double)A->bobs_inv_sigma2[i]) * wBd;
+    e_level[e] = (sharded && pt % world != rank) ? 2 : 0;
+    const int pj = poseIdx[kf];
+    e_pj[e] = pj;
+    lm_start[pt + 1]++;
+    if (pj >= 0) ps_start[pj + 1]++;
   }
-  for (int e = 0; e < nE; e++) {
-    e_level[e] = (sharded && e_pt[e] % world != rank) ? 2 : 0;  // 2 = not this rank's landmark
-    e_pj[e] = poseIdx[e_kf[e]];
-  }
-  for (int l = 0; l <= npt; l++) lm_start[l] = 0;
-  for (int e = 0; e < nE; e++) lm_start[e_pt[e] + 1]++;
   for (int l = 0; l < npt; l++) lm_start[l + 1] += lm_start[l];
+  for (int k = 0; k < np; k++) ps_start[k + 1] += ps_start[k];
   {
-    std::vector<int> fill(lm_start, lm_start + npt);
-    for (int e = 0; e < nE; e++) lm_edges[fill[e_pt[e]]++] = e;
-  }
-  {  // a keyframe observes a point at most once (map<KeyFrame*,size_t>): stamp per key frame = last landmark seen
-    std::vector<int> seen(n_kf, -1);
+    static thread_local std::vector<int> fillL, fillP, seen;
+    fillL.assign(lm_start, lm_start + npt);
+    fillP.assign(ps_start, ps_start + np);
+    for (int e = 0; e < nE; e++) {
+      lm_edges[fillL[e_pt[e]]++] = e;
+      if (e_pj[e] >= 0) ps_edges[fillP[e_pj[e]]++] = e;
+    }
+    // a keyframe observes a point at most once (map<KeyFrame*,size_t>): stamp per key frame = last landmark seen
+    seen.assign(n_kf, -1);
     for (int l = 0; l < npt; l++)
       for (int c = lm_start[l]; c < lm_start[l + 1]; c++) {
         int &sk = seen[e_kf[lm_edges[c]]];
         if (sk == l) { fb::set_error("fb_local_ba: duplicate (keyframe, point) observation"); return FB_ERR_ARG; }
         sk = l;
       }
-  }
-  for (int k = 0; k <= np; k++) ps_start[k] = 0;
-  for (int e = 0; e < nE; e++) if (e_pj[e] >= 0) ps_start[e_pj[e] + 1]++;
-  for (int k = 0; k < np; k++) ps_start[k + 1] += ps_start[k];
-  {
-    std::vector<int> fill(ps_start, ps_start + np);
-    for (int e = 0; e < nE; e++) if (e_pj[e] >= 0) ps_edges[fill[e_pj[e]]++] = e;
   }
   for (int k = 0; k < n_kf; k++) poses[k] = fb::se3_from_float12(A->kf_Tcw + 12 * k);
   for (int i = 0; i < 3 * n_mp; i++) pts[i] = A->mp_xw[i];
@@ -1578,10 +1590,10 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   auto carve = [&](size_t bytes) { const size_t off = scratchBytes; scratchBytes += (bytes + 255) & ~(size_t)255; return off; };
   const size_t c_echi2 = carve((size_t)nE1 * 8);
   size_t c_pose1 = carve((size_t)n_kf * sizeof(SE3)), c_pt1 = carve((size_t)std::max(npt, 1) * 24);
-  size_t c_Hll[2], c_bl[2], c_W[2], c_Hpp[2], c_bp[2], c_chi[2];
+  size_t c_Hll[2], c_bl[2], c_W[2], c_Hpp[2], c_bp[2], c_chi[2], c_max[2];
   for (int q = 0; q < 2; q++) {
     c_Hll[q] = carve((size_t)std::max(npt, 1) * 72); c_bl[q] = carve((size_t)std::max(npt, 1) * 24); c_W[q] = carve((size_t)nE1 * 144);
-    c_Hpp[q] = carve((size_t)std::max(P6 * P6, 1) * 8); c_bp[q] = carve((size_t)std::max(P6, 1) * 8); c_chi[q] = carve((size_t)(nLinBlocks + 1) * 8);
+    c_Hpp[q] = carve((size_t)std::max(P6 * P6, 1) * 8); c_bp[q] = carve((size_t)std::max(P6, 1) * 8); c_chi[q] = carve((size_t)(nLinBlocks + 1) * 8); c_max[q] = carve((size_t)(nLinBlocks + 1) * 8);
   }
   FB_TRY(d_scratch.alloc(scratchBytes));
   uint8_t *dc = d_scratch.as<uint8_t>();
@@ -1609,7 +1621,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   st[1].pose = reinterpret_cast<SE3 *>(dc + c_pose1); st[1].pt = reinterpret_cast<double *>(dc + c_pt1);
   for (int q = 0; q < 2; q++) {
     lb[q].Hll = reinterpret_cast<double *>(dc + c_Hll[q]); lb[q].bl = reinterpret_cast<double *>(dc + c_bl[q]); lb[q].W = reinterpret_cast<double *>(dc + c_W[q]);
-    lb[q].Hpp = reinterpret_cast<double *>(dc + c_Hpp[q]); lb[q].bp = reinterpret_cast<double *>(dc + c_bp[q]); lb[q].chiPart = reinterpret_cast<double *>(dc + c_chi[q]);
+    lb[q].Hpp = reinterpret_cast<double *>(dc + c_Hpp[q]); lb[q].bp = reinterpret_cast<double *>(dc + c_bp[q]); lb[q].chiPart = reinterpret_cast<double *>(dc + c_chi[q]); lb[q].maxPart = reinterpret_cast<double *>(dc + c_max[q]);
   }
   const size_t schurLds = (size_t)2 * rows * KPAD * 8;
   const size_t solveLds = ((size_t)(P6 + 1) * (P6 + 1) + (size_t)(P6 + 1) * 6 + 48 + P6 + 2) * 8;  // the larger of k_ba_solve / solve_lookahead
