@@ -165,13 +165,25 @@ def local_ba_leg(L, rank, world_size, local_rank, reps=3):
     p = synth.make_ba_problem(4000, n_kf=20, n_mp=8000, n_mpb=2000)
     cb, comm, transport = None, None, "1 GPU"
     if world_size > 1:
-        try:  # RCCL inside the library; the host-staged callback only if no communicator can be made
-            comm = fbd.RcclComm(L, rank, world_size, device=torch.device("cuda", local_rank))
+        import torch.distributed as dist
+        gloo = dist.get_backend() == "gloo"   # rehearsal on one GPU: RCCL cannot put two ranks on one device
+        ok, err = 1.0, ""
+        if not gloo:
+            try:  # RCCL inside the library
+                comm = fbd.RcclComm(L, rank, world_size, device=torch.device("cuda", local_rank))
+            except Exception as e:
+                comm, ok, err = None, 0.0, str(e)[:120]
+        # every rank takes the same transport: the host-staged callback if ANY rank has no communicator
+        flag = torch.tensor([ok if not gloo else 0.0], dtype=torch.float64, device="cpu" if gloo else torch.device("cuda", local_rank))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) > 0.0:
             transport = fbd.TRANSPORT_RCCL
-        except Exception as e:
-            comm = None
-            cb = fbd.make_allreduce(stage_device=torch.device("cuda", local_rank))
-            transport = fbd.TRANSPORT_HOST + " (RCCL communicator failed: %s)" % str(e)[:120]
+        else:
+            if comm is not None:
+                comm.close()
+                comm = None
+            cb = fbd.make_allreduce(stage_device=None if gloo else torch.device("cuda", local_rank))
+            transport = fbd.TRANSPORT_HOST + (" (gloo rehearsal)" if gloo else " (no RCCL communicator: %s)" % err)
 
     def run(a):
         if world_size == 1:
@@ -302,9 +314,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
+    # FB_BENCH_REHEARSAL=1: several ranks on ONE GPU with gloo (the multi-rank control flow on a one-GPU box; not a measurement)
+    rehearsal = os.environ.get("FB_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
+        torch.cuda.set_device(0)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import fishbirdeyevisualslam_amd as fb
     from fishbirdeyevisualslam_amd import cabi
@@ -363,7 +383,7 @@ def main():
     L.fb_prof_enable(0)
     L.fb_prof_only(None)
     if world_size > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -371,11 +391,30 @@ def main():
     kern = {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n)}
     res = pipe.results_host()
     ba = None
+    ba_hung = False
     if not a.no_ba:
-        try:
-            ba = local_ba_leg(L, rank, world_size, local_rank)
-        except Exception as e:  # the secondary leg must never take the headline line down
-            ba = {"error": str(e)}
+        # the secondary leg must never take the headline line down: exceptions are caught, and with several ranks (collectives
+        # inside the BA) it runs under a deadline -- a rank stuck in an exchange is reported instead of waited for
+        box = {}
+
+        def _ba():
+            try:
+                fb.check(L.fb_set_device(local_rank), "fb_set_device")  # the HIP device is per thread
+                torch.cuda.set_device(local_rank)
+                box["ba"] = local_ba_leg(L, rank, world_size, local_rank)
+            except Exception as e:
+                box["ba"] = {"error": str(e)}
+        if world_size > 1:
+            import threading
+            th = threading.Thread(target=_ba, daemon=True)
+            th.start()
+            th.join(timeout=120.0)
+            if th.is_alive():
+                ba_hung = True
+                box["ba"] = {"error": "the sharded local-BA leg did not finish within 120 s on rank %d" % rank}
+        else:
+            _ba()
+        ba = box.get("ba")
 
     rc = 0
     if rank == 0:
@@ -469,9 +508,23 @@ def main():
         print(json.dumps(out), flush=True)
         if rc:
             print("bench.py: GPU results differ from the oracle: %s" % out["parity_check"]["details"], file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    if ba_hung:  # a thread of this process is stuck inside a collective: leave without waiting for it
+        os._exit(rc)
     if world_size > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        # orderly shutdown when every rank gets here; a peer that left through the branch above must not hold this one
+        import threading
+        done = threading.Event()
+
+        def _bye():
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            finally:
+                done.set()
+        threading.Thread(target=_bye, daemon=True).start()
+        if not done.wait(timeout=60.0):
+            os._exit(rc)
     pipe.close()
     sys.exit(rc)
 

@@ -912,9 +912,15 @@ __device__ __forceinline__ void update_body(const BADev &D, const LinBuf &B, con
 }
 
 // Spart[0] = sum over the workgroup partials (sharded BA: the local sum that goes through the all-reduce)
-__device__ __forceinline__ void sumparts_body(double *Spart, int nWg, int n) {
+// rows > 0: the buffers are [rows][rows] matrices of which only the upper 16x16 tiles (and with them column P6, the reduced
+// right-hand side) are ever written and read: the lower tiles are skipped
+__device__ __forceinline__ void sumparts_body(double *Spart, int nWg, int n, int rows = 0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (rows > 0) {
+    const int r = i / rows, c = i - r * rows;
+    if ((r >> 4) > (c >> 4)) return;
+  }
   // 8 independent chains: a single running sum serialises nWg memory latencies per thread
   double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int w = 0;
@@ -1054,9 +1060,9 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur_c(BADev D, Lb2 lb, c
   if (c->phase == 2 || c->needInit) return;
   schur_body<MAXT>(D, lb.b[c->cur], c->lambda, Dinv, Spart, P6, NT, lmPerWg, smem);
 }
-__global__ void k_ba_sumparts_c(const BACtl *c, double *Spart, int nWg, int n) {
+__global__ void k_ba_sumparts_c(const BACtl *c, double *Spart, int nWg, int n, int rows) {
   if (c->phase == 2 || c->needInit) return;
-  sumparts_body(Spart, nWg, n);
+  sumparts_body(Spart, nWg, n, rows);
 }
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve_c(Lb2 lb, const BACtl *c, const double *Spart, int P6, int NT, double *xp, double *okFlag,
                                                               XBLay xb) {
@@ -1719,6 +1725,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
     FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(schurC), hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
     FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve_c), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
     const int nS = rows * rows;
+    FB_HIP(hipMemsetAsync(d_Spart.p, 0, (size_t)nS * 8, s0));  // the lower tiles of the summed system are never written: keep them finite
     const int nLin256 = (npt + 255) / 256;
     XBLay xb;
     xb.oH = np * POSE_PARTS * 27; xb.oB = xb.oH + P6 * P6; xb.oS = xb.oB + P6; xb.oM = xb.oS + 4; xb.stride = xb.oM + world;
@@ -1739,7 +1746,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
       { fb::ProfScope pr(fb::P_BA_SCHUR, s0);
         schurC<<<nWg, SCHUR_THREADS, schurLds, s0>>>(D, lb2, ctl, d_Dinv.as<double>(), d_Spart.as<double>(), P6, NT, lmPerWg); }
       { fb::ProfScope pr(fb::P_BA_SOLVE, s0);
-        k_ba_sumparts_c<<<(nS + 255) / 256, 256, 0, s0>>>(ctl, d_Spart.as<double>(), nWg, nS);
+        k_ba_sumparts_c<<<(nS + 255) / 256, 256, 0, s0>>>(ctl, d_Spart.as<double>(), nWg, nS, rows);
         if (sharded) rcSlot = X.sum_dev(d_Spart.as<double>(), (size_t)nS, s0, hostScratch);  // exchange 1: the Schur-reduced system
         k_ba_solve_c<<<1, SOLVE_THREADS, solveLds, s0>>>(lb2, ctl, d_Spart.as<double>(), P6, NT, d_xp.as<double>(), d_scal.as<double>() + 3, xr); }
       { fb::ProfScope pr(fb::P_BA_UPDATE, s0);

@@ -85,3 +85,44 @@ def test_local_ba_rejects_duplicate_observation():
     a, out, keep = ba_problem.local_ba_args(p, with_odom=1)
     with pytest.raises(fb.FishbirdError):
         H.call("fb_local_ba", a)
+
+
+def test_local_ba_structure_only_and_no_bird():
+    """Edge cases of the device-resident schedule: every key frame fixed (no pose system at all: structure-only BA), and a
+    graph without bird points / odometry edges."""
+    p = synth.make_ba_problem(4004, n_kf=5, n_mp=300, n_mpb=60)
+    p["kf_fixed"] = np.ones_like(p["kf_fixed"])
+    out_o, out_h, _, _ = _run(p, with_odom=1)
+    _compare(p, out_o, out_h, 1)
+    assert np.abs(out_h["mp_xw"] - p["mp_xw"]).max() > 0          # the points did move
+    q = synth.make_ba_problem(4005, n_kf=6, n_mp=400, n_mpb=80)
+    for k in ("bobs_kf", "bobs_mpb", "bobs_inv_sigma2", "odom_kf_i", "odom_kf_j", "odom_info"):
+        q[k] = q[k][:0]
+    q["bobs_xc"] = q["bobs_xc"][:0]
+    q["odom_Tij"] = q["odom_Tij"][:0]
+    out_o, out_h, _, _ = _run(q, with_odom=1)
+    assert _rel(out_h["kf_Tcw"], out_o["kf_Tcw"]) <= REL_TOL and _rel(out_h["mp_xw"], out_o["mp_xw"]) <= REL_TOL
+    np.testing.assert_array_equal(out_h["obs_outlier"], out_o["obs_outlier"])
+
+
+def test_local_ba_host_driven_schedule_still_matches(monkeypatch):
+    """FB_BA_HOST_LM=1 selects the host-driven Levenberg-Marquardt loop (the path of > 23 free key frames) on a small problem."""
+    monkeypatch.setenv("FB_BA_HOST_LM", "1")
+    p = synth.make_ba_problem(4006, n_kf=6, n_mp=500, n_mpb=120)
+    out_o, out_h, _, _ = _run(p, with_odom=1)
+    _compare(p, out_o, out_h, 1)
+
+
+def test_local_ba_stop_flag_raised_while_running():
+    """pbStopFlag set from another thread while the schedule runs: the call returns early with a valid (finite) state; the same
+    call without the flag does more work."""
+    import threading
+    p = synth.make_ba_problem(4000, n_kf=20, n_mp=8000, n_mpb=2000)
+    stop = np.zeros(1, np.uint8)
+    a, out, keep = ba_problem.local_ba_args(p, with_odom=1, stop_flag=stop)
+    t = threading.Timer(0.0008, lambda: stop.__setitem__(0, 1))
+    t.start()
+    H.call("fb_local_ba", a)
+    t.join()
+    assert np.isfinite(out["kf_Tcw"]).all() and np.isfinite(out["mp_xw"]).all()
+    assert set(np.unique(out["obs_outlier"]).tolist()) <= {0, 1}
