@@ -313,12 +313,11 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
     # FB_BENCH_REHEARSAL=1: several ranks on ONE GPU with gloo (the multi-rank control flow on a one-GPU box; not a measurement)
     rehearsal = os.environ.get("FB_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-        torch.cuda.set_device(0)
+    torch.cuda.set_device(local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
