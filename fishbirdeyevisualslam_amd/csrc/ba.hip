@@ -161,6 +161,129 @@ __device__ __forceinline__ void edge_jacobians(const BADev &D, int type, const S
   }
 }
 
+// one point-pose edge of the landmark at X: chi2, Huber weight, its terms of Hll / bl, and its 6x3 block W
+__device__ __forceinline__ void lin_edge(const BADev &D, const LinBuf &B, const double (&X)[3], int e, int kf, int lvl, int type, double info,
+                                         const double (&measv)[3], const SE3 &T, int robust, double (&H)[9], double (&b3)[3], double &chi) {
+  double *W = B.W + (size_t)e * 18;
+  const int pj = D.poseIdx[kf];
+  if (lvl != 0) {
+#pragma unroll
+    for (int i = 0; i < 18; i++) W[i] = 0;
+    return;
+  }
+  const double meas[3] = {measv[0], measv[1], measv[2]};
+  double p[3];
+  EdgeLin L;
+  edge_residual(D, type, T, X, meas, p, L.err);
+  edge_jacobians(D, type, T, p, L);
+  double chi2 = 0;
+#pragma unroll
+  for (int r = 0; r < 3; r++) chi2 += L.err[r] * (info * L.err[r]);
+  D.e_chi2[e] = chi2;
+  double rho0 = chi2, rho1 = 1.;
+  if (robust) fb::huber(chi2, D.delta, rho0, rho1);
+  chi += rho0;
+  const double w = rho1 * info;
+  double orr[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) orr[r] = -(info * L.err[r]) * rho1;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    double s = 0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) s += L.Ji[r][i] * orr[r];
+    b3[i] += s;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double h = 0;
+#pragma unroll
+      for (int r = 0; r < 3; r++) h += L.Ji[r][i] * w * L.Ji[r][j];
+      H[3 * i + j] += h;
+    }
+  }
+  if (pj >= 0) {
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        double h = 0;
+#pragma unroll
+        for (int r = 0; r < 3; r++) h += L.Jj[r][i] * w * L.Ji[r][j];
+        W[i * 3 + j] = h;
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 18; i++) W[i] = 0;
+  }
+}
+
+template <int CTRL>
+__device__ __forceinline__ double ba_dpp_f64(double v) {  // v of the lane selected by the DPP control
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// The same with FOUR lanes per landmark (device-resident schedule): lane `sub` of a quad takes the landmark's edges sub,
+// sub + 4, ...; Hll, bl and chi2 are summed over the quad with two DPP quad permutes ((a0 + a1) + (a2 + a3)).  A landmark has
+// 2..10 observers, so one lane per landmark walked them serially with three dependent gathers each: the landmark role was
+// the long pole of the linearisation launch.
+template <int TH>
+__device__ __forceinline__ void linearize_quad_body(const BADev &D, const State &S, const LinBuf &B, int robust, double *s_part) {
+  const int g = blockIdx.x * TH + threadIdx.x, l = g >> 2, sub = g & 3;
+  double chi = 0, hmax = 0;
+  double H[9], b3[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 9; i++) H[i] = 0;
+  if (l < D.npt) {
+    const double X[3] = {S.pt[3 * l], S.pt[3 * l + 1], S.pt[3 * l + 2]};
+    const int cBeg = D.lm_start[l], cEnd = D.lm_start[l + 1];
+    for (int c0 = cBeg + sub; c0 < cEnd; c0 += 8) {  // two edges of this lane per trip, their gathers issued together
+      int ee[2], kfv[2], lvl[2], typ[2];
+      double infov[2], measv[2][3];
+      SE3 Tv[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) ee[u] = D.lm_edges[min(c0 + 4 * u, cEnd - 1)];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        kfv[u] = D.e_kf[ee[u]]; lvl[u] = D.e_level[ee[u]]; typ[u] = D.e_type[ee[u]]; infov[u] = D.e_info[ee[u]];
+        measv[u][0] = D.e_meas[3 * ee[u]]; measv[u][1] = D.e_meas[3 * ee[u] + 1]; measv[u][2] = D.e_meas[3 * ee[u] + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) Tv[u] = S.pose[kfv[u]];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (c0 + 4 * u >= cEnd) break;
+        lin_edge(D, B, X, ee[u], kfv[u], lvl[u], typ[u], infov[u], measv[u], Tv[u], robust, H, b3, chi);
+      }
+    }
+  }
+  // quad sums (every lane of the wave takes part: lanes beyond npt carry zeros)
+#pragma unroll
+  for (int i = 0; i < 9; i++) { H[i] += ba_dpp_f64<0xB1>(H[i]); H[i] += ba_dpp_f64<0x4E>(H[i]); }
+#pragma unroll
+  for (int i = 0; i < 3; i++) { b3[i] += ba_dpp_f64<0xB1>(b3[i]); b3[i] += ba_dpp_f64<0x4E>(b3[i]); }
+  if (l < D.npt && sub == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) B.Hll[(size_t)9 * l + i] = H[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) B.bl[(size_t)3 * l + i] = b3[i];
+    hmax = fmax(fmax(fabs(H[0]), fabs(H[4])), fabs(H[8]));
+  }
+  const double ws = wave_sum_d(chi);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) hmax = fmax(hmax, __shfl_xor(hmax, o, 64));
+  if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6] = ws; s_part[TH / 64 + (threadIdx.x >> 6)] = hmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0, m = 0;
+    for (int i = 0; i < TH / 64; i++) { s += s_part[i]; m = fmax(m, s_part[TH / 64 + i]); }
+    B.chiPart[blockIdx.x] = s;
+    if (B.maxPart) B.maxPart[blockIdx.x] = m;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_ba_linearize: one lane per landmark
 // ------------------------------------------------------------------------------------------
@@ -192,61 +315,7 @@ __device__ __forceinline__ void linearize_body(const BADev &D, const State &S, c
 #pragma unroll
       for (int u = 0; u < 4; u++) {
       if (c0 + u >= cEnd) break;
-      const int e = ee[u];
-      double *W = B.W + (size_t)e * 18;
-      const int pj = D.poseIdx[kfv[u]];
-      if (lvl[u] != 0) {
-#pragma unroll
-        for (int i = 0; i < 18; i++) W[i] = 0;
-        continue;
-      }
-      const int type = typ[u];
-      const SE3 T = Tv[u];
-      const double meas[3] = {measv[u][0], measv[u][1], measv[u][2]};
-      double p[3];
-      EdgeLin L;
-      edge_residual(D, type, T, X, meas, p, L.err);
-      edge_jacobians(D, type, T, p, L);
-      const double info = infov[u];
-      double chi2 = 0;
-#pragma unroll
-      for (int r = 0; r < 3; r++) chi2 += L.err[r] * (info * L.err[r]);
-      D.e_chi2[e] = chi2;
-      double rho0 = chi2, rho1 = 1.;
-      if (robust) fb::huber(chi2, D.delta, rho0, rho1);
-      chi += rho0;
-      const double w = rho1 * info;
-      double orr[3];
-#pragma unroll
-      for (int r = 0; r < 3; r++) orr[r] = -(info * L.err[r]) * rho1;
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        double s = 0;
-#pragma unroll
-        for (int r = 0; r < 3; r++) s += L.Ji[r][i] * orr[r];
-        b3[i] += s;
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-          double h = 0;
-#pragma unroll
-          for (int r = 0; r < 3; r++) h += L.Ji[r][i] * w * L.Ji[r][j];
-          H[3 * i + j] += h;
-        }
-      }
-      if (pj >= 0) {
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-          for (int j = 0; j < 3; j++) {
-            double h = 0;
-#pragma unroll
-            for (int r = 0; r < 3; r++) h += L.Jj[r][i] * w * L.Ji[r][j];
-            W[i * 3 + j] = h;
-          }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 18; i++) W[i] = 0;
-      }
+      lin_edge(D, B, X, ee[u], kfv[u], lvl[u], typ[u], infov[u], measv[u], Tv[u], robust, H, b3, chi);
       }
     }
 #pragma unroll
@@ -351,9 +420,11 @@ struct OdomLin { double A[36], Bm[36], err[6]; };
 
 template <bool GLOBAL>  // GLOBAL: the per-edge linearisations live in HBM scratch (they do not fit LDS)
 __device__ __forceinline__ void odom_body(const BADev &D, const State &S, const LinBuf &B, int P6, int chiSlot, OdomLin *ol, double *s_chi,
-                                          double *Hout, double *bout, bool zeroFirst) {
+                                          double *Hout, double *bout, bool zeroFirst, double *tmp = nullptr) {
   const int tid = threadIdx.x;
   double chi = 0;
+  // tmp != nullptr (LDS, 108 doubles per edge: adj(T2) | adj(T1^-1) | J adj(T2)): the two 6x6x6 products of an edge are
+  // spread over 36 lanes each instead of running serially on the edge's lane (same sums in the same order)
   for (int e = tid; e < D.nO; e += 256) {
     const SE3 T1 = S.pose[D.o_i[e]], T2 = S.pose[D.o_j[e]];
     const SE3 d = fb::se3_mul(fb::se3_mul(D.o_Zinv[e], T1), fb::se3_inverse(T2));
@@ -373,22 +444,45 @@ __device__ __forceinline__ void odom_body(const BADev &D, const State &S, const 
     for (int i = 0; i < 6; i++) J[i * 6 + i] += 1.0;
     fb::se3_adj(T2, a2);
     fb::se3_adj(fb::se3_inverse(T1), a1);
-    for (int i = 0; i < 6; i++)
-      for (int j = 0; j < 6; j++) {
-        double s = 0;
-        for (int k = 0; k < 6; k++) s += J[i * 6 + k] * a2[k * 6 + j];
-        t1[i * 6 + j] = s;
-      }
-    for (int i = 0; i < 6; i++)
-      for (int j = 0; j < 6; j++) {
-        double s = 0;
-        for (int k = 0; k < 6; k++) s += t1[i * 6 + k] * a1[k * 6 + j];
-        ol[e].A[i * 6 + j] = s;
-      }
+    if (tmp) {
+      double *q = tmp + (size_t)e * 108;
+      for (int i = 0; i < 36; i++) { q[i] = a2[i]; q[36 + i] = a1[i]; }
+    } else {
+      for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+          double s = 0;
+          for (int k = 0; k < 6; k++) s += J[i * 6 + k] * a2[k * 6 + j];
+          t1[i * 6 + j] = s;
+        }
+      for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+          double s = 0;
+          for (int k = 0; k < 6; k++) s += t1[i * 6 + k] * a1[k * 6 + j];
+          ol[e].A[i * 6 + j] = s;
+        }
+    }
     for (int i = 0; i < 36; i++) ol[e].Bm[i] = -J[i];
     const double info = D.o_info[e];
     const bool act = !(D.poseIdx[D.o_i[e]] < 0 && D.poseIdx[D.o_j[e]] < 0);  // allVerticesFixed edges are not active
     for (int i = 0; i < 6; i++) { ol[e].err[i] = er[i]; if (act) chi += er[i] * (info * er[i]); }
+  }
+  if (tmp) {
+    __syncthreads();
+    for (int idx = tid; idx < D.nO * 36; idx += 256) {  // J adj(T2), J = -Bm
+      const int e = idx / 36, ij = idx - e * 36, i = ij / 6, j = ij - i * 6;
+      const double *q = tmp + (size_t)e * 108;
+      double s2 = 0;
+      for (int k = 0; k < 6; k++) s2 += (-ol[e].Bm[i * 6 + k]) * q[k * 6 + j];
+      tmp[(size_t)e * 108 + 72 + ij] = s2;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < D.nO * 36; idx += 256) {  // (J adj(T2)) adj(T1^-1)
+      const int e = idx / 36, ij = idx - e * 36, i = ij / 6, j = ij - i * 6;
+      const double *q = tmp + (size_t)e * 108;
+      double s2 = 0;
+      for (int k = 0; k < 6; k++) s2 += q[72 + i * 6 + k] * q[36 + k * 6 + j];
+      ol[e].A[ij] = s2;
+    }
   }
   s_chi[tid] = chi;
   if (GLOBAL) __threadfence_block();
@@ -398,13 +492,16 @@ __device__ __forceinline__ void odom_body(const BADev &D, const State &S, const 
     for (int i = 0; i < 256; i++) s += s_chi[i];
     B.chiPart[chiSlot] = s;
   }
-  // phase b: lane (k, i) = row i of free pose k
+  // phase b: lane (k, i) = row i of free pose k.  The row's diagonal block and right-hand side entry are accumulated in
+  // registers over the incident edges and written once; an off-diagonal block is loaded, updated and stored as a group of six
+  // (one memory round trip per block: the 72 dependent read-modify-writes per row this replaces were most of the role's time)
+  if (zeroFirst) {  // Hout / bout are this role's own scratch: clear it with coalesced stores
+    for (int i = tid; i < P6 * P6; i += 256) Hout[i] = 0;
+    __syncthreads();
+  }
   for (int row = tid; row < P6; row += 256) {
     const int k = row / 6, i = row % 6;
-    if (zeroFirst) {  // Hout / bout are this kernel's own scratch (merged into Hpp / bp by k_ba_control)
-      for (int j = 0; j < P6; j++) Hout[(size_t)row * P6 + j] = 0;
-      bout[row] = 0;
-    }
+    double dg[6] = {0, 0, 0, 0, 0, 0}, bacc = 0;
     for (int cc = D.od_start[k]; cc < D.od_start[k + 1]; cc++) {  // incident edges only, in edge order
       const int e = D.od_edges[cc];
       const int pi = D.poseIdx[D.o_i[e]], pj = D.poseIdx[D.o_j[e]];
@@ -414,22 +511,38 @@ __device__ __forceinline__ void odom_body(const BADev &D, const State &S, const 
       const double *Mine = (pi == k) ? o.A : o.Bm;
       double bsum = 0;
       for (int r = 0; r < 6; r++) bsum += Mine[r * 6 + i] * (-(info * o.err[r]));
-      bout[row] += bsum;
+      bacc += bsum;
       for (int side = 0; side < 2; side++) {
         const int pc = side == 0 ? pi : pj;
         if (pc < 0) continue;
         const double *Oth = side == 0 ? o.A : o.Bm;
+        double v[6];
         for (int j = 0; j < 6; j++) {
           double s = 0;
           for (int r = 0; r < 6; r++) s += Mine[r * 6 + i] * info * Oth[r * 6 + j];
-          Hout[(size_t)row * P6 + 6 * pc + j] += s;
+          v[j] = s;
+        }
+        if (pc == k) {
+          for (int j = 0; j < 6; j++) dg[j] += v[j];
+        } else {
+          double *dst = Hout + (size_t)row * P6 + 6 * pc, t6[6];
+          for (int j = 0; j < 6; j++) t6[j] = dst[j];
+          for (int j = 0; j < 6; j++) dst[j] = t6[j] + v[j];
         }
       }
       if (pi == k && pj == k) {  // degenerate self edge: also the Bm rows
         double b2 = 0;
         for (int r = 0; r < 6; r++) b2 += o.Bm[r * 6 + i] * (-(info * o.err[r]));
-        bout[row] += b2;
+        bacc += b2;
       }
+    }
+    double *dd = Hout + (size_t)row * P6 + 6 * k;
+    if (zeroFirst) {
+      for (int j = 0; j < 6; j++) dd[j] = dg[j];
+      bout[row] = bacc;
+    } else {
+      for (int j = 0; j < 6; j++) dd[j] += dg[j];
+      bout[row] += bacc;
     }
   }
 }
@@ -1098,13 +1211,14 @@ __global__ __launch_bounds__(256) void k_ba_lin_c(BADev D, St2 st, Lb2 lb, const
   const int robust = c->phase == 0 ? sc.robust1 : 0;
   const int bx = blockIdx.x;
   if (bx < nLin) {
-    linearize_body<256>(D, st.s[t], lb.b[t], robust, s_buf);
+    linearize_quad_body<256>(D, st.s[t], lb.b[t], robust, s_buf);
   } else if (bx < nLin + POSE_PARTS * D.np) {
     const int q = bx - nLin, k = q / POSE_PARTS, part = q - k * POSE_PARTS;
     pose_body(D, st.s[t], lb.b[t], robust, P6, reinterpret_cast<double(*)[27]>(s_buf), k, part, POSE_PARTS, xb.at(t) + (size_t)q * 27);
   } else {
-    odom_body<GLOBAL>(D, st.s[t], lb.b[t], P6, chiSlot, GLOBAL ? olGlobal : reinterpret_cast<OdomLin *>(smem), s_buf, xb.at(t) + xb.oH, xb.at(t) + xb.oB,
-                      true);
+    OdomLin *ol = GLOBAL ? olGlobal : reinterpret_cast<OdomLin *>(smem);
+    double *tmp = GLOBAL ? nullptr : reinterpret_cast<double *>(ol + max(D.nO, 1));  // the launch reserves 108 doubles per edge behind the records
+    odom_body<GLOBAL>(D, st.s[t], lb.b[t], P6, chiSlot, ol, s_buf, xb.at(t) + xb.oH, xb.at(t) + xb.oB, true, tmp);
   }
 }
 
@@ -1599,7 +1713,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   size_t c_Hll[2], c_bl[2], c_W[2], c_Hpp[2], c_bp[2], c_chi[2], c_max[2];
   for (int q = 0; q < 2; q++) {
     c_Hll[q] = carve((size_t)std::max(npt, 1) * 72); c_bl[q] = carve((size_t)std::max(npt, 1) * 24); c_W[q] = carve((size_t)nE1 * 144);
-    c_Hpp[q] = carve((size_t)std::max(P6 * P6, 1) * 8); c_bp[q] = carve((size_t)std::max(P6, 1) * 8); c_chi[q] = carve((size_t)(nLinBlocks + 1) * 8); c_max[q] = carve((size_t)(nLinBlocks + 1) * 8);
+    c_Hpp[q] = carve((size_t)std::max(P6 * P6, 1) * 8); c_bp[q] = carve((size_t)std::max(P6, 1) * 8); c_chi[q] = carve((size_t)(2 * nLinBlocks + 2) * 8); c_max[q] = carve((size_t)(2 * nLinBlocks + 2) * 8);
   }
   FB_TRY(d_scratch.alloc(scratchBytes));
   uint8_t *dc = d_scratch.as<uint8_t>();
@@ -1726,7 +1840,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
     FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_solve_c), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
     const int nS = rows * rows;
     FB_HIP(hipMemsetAsync(d_Spart.p, 0, (size_t)nS * 8, s0));  // the lower tiles of the summed system are never written: keep them finite
-    const int nLin256 = (npt + 255) / 256;
+    const int nLin256 = (4 * npt + 255) / 256;  // four lanes per landmark; chi2 slot of the odometry role = nLin256
     XBLay xb;
     xb.oH = np * POSE_PARTS * 27; xb.oB = xb.oH + P6 * P6; xb.oS = xb.oB + P6; xb.oM = xb.oS + 4; xb.stride = xb.oM + world;
     // sharded: the kernels of a linearisation fill the RAW blocks; exchange 2 sums BOTH raw blocks into the REDUCED ones out of
@@ -1737,7 +1851,15 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
     xb.base = d_xb.as<double>();
     XBLay xr = xb;  // reduced
     if (sharded) xr.base = xb.base + (size_t)2 * xb.stride;
-    if (!olGlobal) FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_lin_c<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)odomLds));
+    const size_t linLds = olGlobal ? 0 : odomLds + (size_t)std::max(nO, 1) * 108 * 8;
+    bool linGlobal = olGlobal != nullptr;
+    fb::DevBuf d_olDev;
+    if (!linGlobal && linLds > 150 * 1024) {  // the products' scratch does not fit next to the records: HBM records, serial products
+      FB_TRY(d_olDev.alloc((size_t)std::max(nO, 1) * sizeof(OdomLin)));
+      olGlobal = d_olDev.as<OdomLin>();
+      linGlobal = true;
+    }
+    if (!linGlobal) FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_lin_c<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)linLds));
     const int linGrid = nLin256 + POSE_PARTS * np + 1;
     std::vector<double> hostScratch;
     int rcSlot = FB_OK;
@@ -1752,16 +1874,16 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
       { fb::ProfScope pr(fb::P_BA_UPDATE, s0);
         k_ba_update_c<<<nUpdBlocks, LIN_THREADS, 0, s0>>>(D, lb2, st2, ctl, d_Dinv.as<double>(), d_xp.as<double>(), d_scale.as<double>(), rank == 0 ? 1 : 0); }
       { fb::ProfScope pr(fb::P_BA_LINEARIZE, s0);
-        if (olGlobal) k_ba_lin_c<true><<<linGrid, 256, 0, s0>>>(D, st2, lb2, ctl, sched, P6, nLin256, nLinBlocks, olGlobal, xb);
-        else k_ba_lin_c<false><<<linGrid, 256, odomLds, s0>>>(D, st2, lb2, ctl, sched, P6, nLin256, nLinBlocks, nullptr, xb); }
+        if (linGlobal) k_ba_lin_c<true><<<linGrid, 256, 0, s0>>>(D, st2, lb2, ctl, sched, P6, nLin256, nLin256, olGlobal, xb);
+        else k_ba_lin_c<false><<<linGrid, 256, linLds, s0>>>(D, st2, lb2, ctl, sched, P6, nLin256, nLin256, nullptr, xb); }
       { fb::ProfScope pr(fb::P_BA_MISC, s0);
         if (sharded) {
-          k_ba_prex<<<1, 256, 0, s0>>>(D, lb2, ctl, nLin256, nLinBlocks, d_scale.as<double>(), nUpdBlocks, xb, d_abort.as<int>(), rank, world);
+          k_ba_prex<<<1, 256, 0, s0>>>(D, lb2, ctl, nLin256, nLin256, d_scale.as<double>(), nUpdBlocks, xb, d_abort.as<int>(), rank, world);
           // exchange 2: both raw blocks -> the reduced blocks, one all-reduce
           if (rcSlot == FB_OK) rcSlot = X.sum_dev(xr.at(0), (size_t)2 * xb.stride, s0, hostScratch, xb.at(0));
-          k_ba_control<true><<<1, 256, 0, s0>>>(D, lb2, ctl, sched, nLin256, nLinBlocks, d_scale.as<double>(), nUpdBlocks, d_scal.as<double>() + 3, P6, xr, d_abort.as<int>(), world);
+          k_ba_control<true><<<1, 256, 0, s0>>>(D, lb2, ctl, sched, nLin256, nLin256, d_scale.as<double>(), nUpdBlocks, d_scal.as<double>() + 3, P6, xr, d_abort.as<int>(), world);
         } else {
-          k_ba_control<false><<<1, 256, 0, s0>>>(D, lb2, ctl, sched, nLin256, nLinBlocks, d_scale.as<double>(), nUpdBlocks, d_scal.as<double>() + 3, P6, xb, d_abort.as<int>(), world);
+          k_ba_control<false><<<1, 256, 0, s0>>>(D, lb2, ctl, sched, nLin256, nLin256, d_scale.as<double>(), nUpdBlocks, d_scal.as<double>() + 3, P6, xb, d_abort.as<int>(), world);
         } }
     };
     FB_TRY(d_flags.alloc(std::max(nE, 1)));
