@@ -88,3 +88,26 @@ def test_sharded_local_ba_rccl_single_rank_vs_oracle():
         np.testing.assert_array_equal(out_s["bobs_outlier"][: len(p["bobs_kf"])], out_1["bobs_outlier"][: len(p["bobs_kf"])])
     finally:
         comm.close()
+
+
+@pytest.mark.gpu
+def test_sharded_rccl_single_rank_hbm_resident_system():
+    """30 key frames: the reduced system lives in HBM and the Levenberg-Marquardt loop is host-driven; the exchanges of that
+    path go through the same transport (RCCL: staged through a device buffer)."""
+    import numpy as np
+    import fishbirdeyevisualslam_amd as fb
+    import oracle_lib as O
+    from fishbirdeyevisualslam_amd import ba_problem, synth, dist as fbd
+    L = fb.lib()
+    comm = fbd.RcclComm(L, 0, 1)
+    try:
+        p = synth.make_ba_problem(4010, n_kf=30, n_fixed=2, n_mp=1500, n_mpb=300)
+        a, out_s, keep = ba_problem.local_ba_args(p, with_odom=1)
+        fbd.local_ba_sharded_rccl(L, a, 0, 1, comm)
+        a1, out_1, keep1 = ba_problem.local_ba_args(p, with_odom=1)
+        O.call("orc_local_ba", a1)
+        for k in ("kf_Tcw", "mp_xw", "mpb_xw"):
+            assert float(np.abs(out_s[k] - out_1[k]).max() / max(1.0, np.abs(out_1[k]).max())) <= 1e-4, k
+        np.testing.assert_array_equal(out_s["obs_outlier"], out_1["obs_outlier"])
+    finally:
+        comm.close()
