@@ -836,27 +836,62 @@ __device__ __forceinline__ void solve_body(const LinBuf &B, double lambda, const
 //    trailing matrix; every thread used to factor the block redundantly BETWEEN the barriers;
 //  * two barriers per key frame instead of three.
 // HppO as in solve_body.
+#ifdef FB_BA_STAMPS
+__device__ unsigned long long g_ba_stamps[16];
+#define BA_T0() unsigned long long bt_ = 0; if (threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); bt_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define BA_TICK(slot_) if (threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); g_ba_stamps[slot_] += t_ - bt_; bt_ = t_; }
+#else
+#define BA_T0()
+#define BA_TICK(slot_)
+#endif
+template <int TS>  // threads of the workgroup
 __device__ __forceinline__ void solve_lookahead(const LinBuf &B, double lambda, const double *Spart, int P6, int NT, double *xp, double *okFlag,
                                                 uint8_t *smem, int &s_ok, const double *HppO) {
   const int ld = P6 + 1, rows = NT * 16, tid = threadIdx.x;
+  BA_T0()
   double *A = reinterpret_cast<double *>(smem);   // [P6 + 1][ld], lower triangle; row P6 = right-hand side
   double *Up = A + (size_t)(P6 + 1) * ld;         // [P6 + 1][6] panel u = l * d of the current step
-  double *fact = Up + (size_t)(P6 + 1) * 6;       // 36 L (row-major, lower) | 6 d | 6 1/d of the current diagonal block
-  double *rhs = fact + 48;                        // [P6] backward substitution
+  double *fact2 = Up + (size_t)(P6 + 1) * 6;      // two buffers (even / odd block) of 36 L (row-major, lower) | 6 d | 6 1/d
+  double *rhs = fact2 + 96;                       // [P6] backward substitution
   if (tid == 0) s_ok = 1;
-  for (int idx = tid; idx < P6 * P6; idx += SOLVE_THREADS) {
-    const int i = idx / P6, j = idx - i * P6;
-    if (j > i) continue;  // lower triangle: A[i][j] = S[j][i] (upper, as g2o's solver reads it)
-    double h = (i / 6 == j / 6 ? B.Hpp[(size_t)j * P6 + i] : 0.0) + HppO[(size_t)j * P6 + i];
-    if (i == j) h += lambda;
-    A[(size_t)i * ld + j] = h - Spart[(size_t)j * rows + i];
+  {
+    // A[i][j] = S[j][i] for i >= j (the upper triangle, as g2o's solver reads it): 16 lanes walk a row j of the upper
+    // triangle (contiguous in memory), 16 row groups, four rows in flight per thread.  (The phase stamps had a quarter of the
+    // solve in this loop when it divided a flat index and waited for each element's three loads in turn.)
+    const int tr = tid >> 4, tc = tid & 15;
+    constexpr int MAXM = 9;  // ceil(138 / 16): the LDS-resident system has at most 23 free key frames
+    for (int j = tr; j < P6; j += TS / 16) {
+      const int jb = j / 6;
+      const double *srow = Spart + (size_t)j * rows, *orow = HppO + (size_t)j * P6, *hrow = B.Hpp + (size_t)j * P6;
+      // every load of the row segment is issued before the first use: unconditional loads at clamped indices (a predicated
+      // load makes the compiler wait for each element in turn), the selection happens on the values
+      double o[MAXM], sv[MAXM], hv[MAXM];
+#pragma unroll
+      for (int m = 0; m < MAXM; m++) o[m] = orow[min(j + tc + 16 * m, P6 - 1)];
+#pragma unroll
+      for (int m = 0; m < MAXM; m++) sv[m] = srow[min(j + tc + 16 * m, P6 - 1)];
+#pragma unroll
+      for (int m = 0; m < MAXM; m++) hv[m] = hrow[min(j + tc + 16 * m, P6 - 1)];
+#pragma unroll
+      for (int m = 0; m < MAXM; m++) {
+        const int i = j + tc + 16 * m;
+        double h = o[m] - sv[m];
+        if (i < 6 * jb + 6) h += hv[m];  // same key frame: the diagonal block
+        if (i == j) h += lambda;
+        if (i < P6) A[(size_t)i * ld + j] = h;
+      }
+    }
   }
-  for (int i = tid; i < P6; i += SOLVE_THREADS) A[(size_t)P6 * ld + i] = B.bp[i] - Spart[(size_t)i * rows + P6];
+  for (int i = tid; i < P6; i += TS) A[(size_t)P6 * ld + i] = B.bp[i] - Spart[(size_t)i * rows + P6];
   __syncthreads();
   const int nb6 = P6 / 6;
   // factor the 6x6 diagonal block at c0 (wave-redundant in registers), lane `wlane` 0 publishes it
   auto factor_block = [&](int c0) {
-    double Lb[6][6], d[6], dinv[6];
+#pragma clang fp contract(fast)
+    double *fact = fact2 + 48 * ((c0 / 6) & 1);  // wave 0 publishes block J + 1 while slower waves may still read block J's
+    // the dependent chain of this routine is the critical path of every block step: fused multiply-adds and the products
+    // U[c][m] = L[c][m] d[m] kept next to L halve its length (the BA is tolerance-held)
+    double Lb[6][6], Ub[6][6], d[6], dinv[6];
 #pragma unroll
     for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -866,7 +901,7 @@ __device__ __forceinline__ void solve_lookahead(const LinBuf &B, double lambda, 
     for (int c = 0; c < 6; c++) {
       double dc = Lb[c][c];
 #pragma unroll
-      for (int m = 0; m < c; m++) dc -= Lb[c][m] * Lb[c][m] * d[m];
+      for (int m = 0; m < c; m++) dc -= Lb[c][m] * Ub[c][m];
       if (dc < 0) neg = true;
       d[c] = dc;
       const double inv = dc != 0 ? ba_rcp(dc) : 0.0;
@@ -875,7 +910,8 @@ __device__ __forceinline__ void solve_lookahead(const LinBuf &B, double lambda, 
       for (int r = c + 1; r < 6; r++) {
         double v = Lb[r][c];
 #pragma unroll
-        for (int m = 0; m < c; m++) v -= Lb[r][m] * Lb[c][m] * d[m];
+        for (int m = 0; m < c; m++) v -= Lb[r][m] * Ub[c][m];
+        Ub[r][c] = v;          // u = l d
         Lb[r][c] = v * inv;
       }
     }
@@ -891,10 +927,15 @@ __device__ __forceinline__ void solve_lookahead(const LinBuf &B, double lambda, 
       }
     }
   };
+  // (Measured and dropped: wave 0 running ahead -- taking the next block's panel rows itself so that its factor chain
+  // overlaps the panel of the others, with a software barrier among the panel waves.  Same time: the chain
+  // [factor read -> panel rows -> block update -> 6x6 factor] of the next block is the critical path either way.)
   if (tid < 64 && nb6 > 0) factor_block(0);
   __syncthreads();
+  BA_TICK(1)  // first factor
   for (int J = 0; J < nb6; J++) {
     const int c0 = 6 * J, c1 = c0 + 6;
+    const double *fact = fact2 + 48 * (J & 1);
     double Lb[6][6], dinv[6];
 #pragma unroll
     for (int r = 1; r < 6; r++)
@@ -902,7 +943,7 @@ __device__ __forceinline__ void solve_lookahead(const LinBuf &B, double lambda, 
       for (int c = 0; c < r; c++) Lb[r][c] = fact[r * 6 + c];
 #pragma unroll
     for (int c = 0; c < 6; c++) dinv[c] = fact[42 + c];
-    for (int i = c1 + tid; i <= P6; i += SOLVE_THREADS) {  // panel: row i of L below the block (row P6: forward substitution)
+    for (int i = c1 + tid; i <= P6; i += TS) {  // panel: row i of L below the block (row P6: forward substitution)
       double u[6];
 #pragma unroll
       for (int c = 0; c < 6; c++) {
@@ -917,7 +958,9 @@ __device__ __forceinline__ void solve_lookahead(const LinBuf &B, double lambda, 
         A[(size_t)i * ld + c0 + c] = u[c] * dinv[c];  // dinv = 0 for a zero pivot
       }
     }
+    BA_TICK(2)  // read fact + panel
     __syncthreads();
+    BA_TICK(3)  // barrier after panel
     if (tid < 64) {  // wave 0: the next diagonal block first, then its factorisation
       if (c1 < P6) {
         if (tid < 21) {
@@ -931,9 +974,10 @@ __device__ __forceinline__ void solve_lookahead(const LinBuf &B, double lambda, 
         }
         factor_block(c1);
       }
-    } else {  // waves 1..3: the rest of the trailing matrix, rows c1 + 6 .. P6 (row P6: columns < P6)
+      BA_TICK(4)  // wave 0: next diagonal block update + factorisation
+    } else {  // the other waves: the rest of the trailing matrix, rows c1 + 6 .. P6 (row P6: columns < P6)
       const int q = tid - 64, tr = q >> 4, tc = q & 15;
-      for (int i = c1 + 6 + tr; i <= P6; i += (SOLVE_THREADS - 64) / 16) {
+      for (int i = c1 + 6 + tr; i <= P6; i += (TS - 64) / 16) {
         double u[6];
 #pragma unroll
         for (int c = 0; c < 6; c++) u[c] = Up[(size_t)i * 6 + c];
@@ -947,32 +991,40 @@ __device__ __forceinline__ void solve_lookahead(const LinBuf &B, double lambda, 
       }
     }
     __syncthreads();
+    BA_TICK(5)  // wait for the trailing update of the other waves
   }
-  // row P6 now holds z = D^-1 L^-1 b
-  for (int i = tid; i < P6; i += SOLVE_THREADS) rhs[i] = A[(size_t)P6 * ld + i];
-  __syncthreads();
-  for (int J = nb6 - 1; J >= 0; J--) {  // backward: L^T x = z
-    const int c0 = 6 * J;
-    double xJ[6];
+  // row P6 now holds z = D^-1 L^-1 b.  Backward substitution L^T x = z on ONE wave: 18 dependent block steps with two
+  // workgroup barriers each cost more in barriers than in arithmetic; inside a wave the LDS operations are ordered, so the
+  // steps need no barrier at all.
+  if (tid < 64) {
+    for (int i = tid; i < P6; i += 64) rhs[i] = A[(size_t)P6 * ld + i];
+    for (int J = nb6 - 1; J >= 0; J--) {
+      const int c0 = 6 * J;
+      double xJ[6];
 #pragma unroll
-    for (int r = 5; r >= 0; r--) {
-      double v = rhs[c0 + r];
+      for (int r = 5; r >= 0; r--) {
+        double v = rhs[c0 + r];
 #pragma unroll
-      for (int m = 5; m > r; m--) v -= A[(size_t)(c0 + m) * ld + c0 + r] * xJ[m];
-      xJ[r] = v;
+        for (int m = 5; m > r; m--) v -= A[(size_t)(c0 + m) * ld + c0 + r] * xJ[m];
+        xJ[r] = v;
+      }
+      __builtin_amdgcn_wave_barrier();  // every lane has read rhs[c0..c0+6) before it is overwritten below
+      if (tid < 6) rhs[c0 + tid] = xJ[tid];
+      for (int i = tid; i < c0; i += 64) {
+        double v = rhs[i];
+#pragma unroll
+        for (int c = 0; c < 6; c++) v -= A[(size_t)(c0 + c) * ld + i] * xJ[c];
+        rhs[i] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    if (tid < 6) rhs[c0 + tid] = xJ[tid];
-    for (int i = tid; i < c0; i += SOLVE_THREADS) {
-      double v = rhs[i];
-#pragma unroll
-      for (int c = 0; c < 6; c++) v -= A[(size_t)(c0 + c) * ld + i] * xJ[c];
-      rhs[i] = v;
-    }
-    __syncthreads();
+    for (int i = tid; i < P6; i += 64) xp[i] = rhs[i];
   }
-  for (int i = tid; i < P6; i += SOLVE_THREADS) xp[i] = rhs[i];
   __syncthreads();
+  BA_TICK(6)  // backward substitution
+#ifdef FB_BA_STAMPS
+  if (tid == 0) g_ba_stamps[15] += 1;
+#endif
   if (tid == 0) *okFlag = s_ok ? 1.0 : 0.0;
 }
 
@@ -1177,12 +1229,13 @@ __global__ void k_ba_sumparts_c(const BACtl *c, double *Spart, int nWg, int n, i
   if (c->phase == 2 || c->needInit) return;
   sumparts_body(Spart, nWg, n, rows);
 }
-__global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve_c(Lb2 lb, const BACtl *c, const double *Spart, int P6, int NT, double *xp, double *okFlag,
-                                                              XBLay xb) {
+constexpr int SOLVE_C_THREADS = 512;  // wave 0 factors the next diagonal block, seven waves share the trailing update
+__global__ __launch_bounds__(SOLVE_C_THREADS) void k_ba_solve_c(Lb2 lb, const BACtl *c, const double *Spart, int P6, int NT, double *xp, double *okFlag,
+                                                                XBLay xb) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int s_ok;
   if (c->phase == 2 || c->needInit) return;
-  solve_lookahead(lb.b[c->cur], c->lambda, Spart, P6, NT, xp, okFlag, smem, s_ok, xb.at(c->cur) + xb.oH);
+  solve_lookahead<SOLVE_C_THREADS>(lb.b[c->cur], c->lambda, Spart, P6, NT, xp, okFlag, smem, s_ok, xb.at(c->cur) + xb.oH);
 }
 __global__ __launch_bounds__(LIN_THREADS) void k_ba_update_c(BADev D, Lb2 lb, St2 st, const BACtl *c, const double *Dinv, const double *xp, double *scalePart,
                                                              int countPoses) {
@@ -1477,6 +1530,16 @@ struct Xchg {
 };
 }  // namespace
 
+#ifdef FB_BA_STAMPS
+extern "C" int fb_ba_debug_stamps(uint64_t *dst16) {  // probe build only: copies and clears the phase accumulators of the solve
+  unsigned long long h[16], z[16] = {0};
+  FB_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ba_stamps), sizeof(h)));
+  FB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ba_stamps), z, sizeof(z)));
+  for (int i = 0; i < 16; i++) dst16[i] = h[i];
+  return FB_OK;
+}
+#endif
+
 extern "C" int fb_rccl_get_unique_id(fb_rccl_unique_id *id) {
   FB_ARG(id);
   RcclApi *r = rccl_api();
@@ -1744,7 +1807,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
     lb[q].Hpp = reinterpret_cast<double *>(dc + c_Hpp[q]); lb[q].bp = reinterpret_cast<double *>(dc + c_bp[q]); lb[q].chiPart = reinterpret_cast<double *>(dc + c_chi[q]); lb[q].maxPart = reinterpret_cast<double *>(dc + c_max[q]);
   }
   const size_t schurLds = (size_t)2 * rows * KPAD * 8;
-  const size_t solveLds = ((size_t)(P6 + 1) * (P6 + 1) + (size_t)(P6 + 1) * 6 + 48 + P6 + 2) * 8;  // the larger of k_ba_solve / solve_lookahead
+  const size_t solveLds = ((size_t)(P6 + 1) * (P6 + 1) + (size_t)(P6 + 1) * 6 + 96 + P6 + 2) * 8;  // the larger of k_ba_solve / solve_lookahead
   // beyond ~23 free key frames the reduced system no longer fits LDS: HBM-resident path of ba_big.inc
   const bool big = schurLds > 160 * 1024 || solveLds > 160 * 1024 || P6 + 1 > 256;
   fb::DevBuf d_Dinv, d_Spart, d_xp, d_ok, d_scale, d_scal, d_bigS, d_bigM, d_bigU, d_bigR;
@@ -1870,7 +1933,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
       { fb::ProfScope pr(fb::P_BA_SOLVE, s0);
         k_ba_sumparts_c<<<(nS + 255) / 256, 256, 0, s0>>>(ctl, d_Spart.as<double>(), nWg, nS, rows);
         if (sharded) rcSlot = X.sum_dev(d_Spart.as<double>(), (size_t)nS, s0, hostScratch);  // exchange 1: the Schur-reduced system
-        k_ba_solve_c<<<1, SOLVE_THREADS, solveLds, s0>>>(lb2, ctl, d_Spart.as<double>(), P6, NT, d_xp.as<double>(), d_scal.as<double>() + 3, xr); }
+        k_ba_solve_c<<<1, SOLVE_C_THREADS, solveLds, s0>>>(lb2, ctl, d_Spart.as<double>(), P6, NT, d_xp.as<double>(), d_scal.as<double>() + 3, xr); }
       { fb::ProfScope pr(fb::P_BA_UPDATE, s0);
         k_ba_update_c<<<nUpdBlocks, LIN_THREADS, 0, s0>>>(D, lb2, st2, ctl, d_Dinv.as<double>(), d_xp.as<double>(), d_scale.as<double>(), rank == 0 ? 1 : 0); }
       { fb::ProfScope pr(fb::P_BA_LINEARIZE, s0);
