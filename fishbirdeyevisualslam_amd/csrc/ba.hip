@@ -1346,16 +1346,22 @@ __global__ __launch_bounds__(256) void k_ba_control(BADev D, Lb2 lb, BACtl *c, B
   }
   s_m[tid] = m;
   __syncthreads();
-  if (tid != 0) return;
   double chi = 0, scale = 0;
+  if (!SHARDED && tid < 64) {
+    // the partials in a fixed order: lane t adds entries t, t + 64, ..., then the butterfly over the wave (deterministic,
+    // and a few hundred dependent additions on one lane were a third of this kernel)
+    for (int i = tid; i < nLin; i += 64) chi += i < 512 ? s_chiP[i] : B.chiPart[i];
+    if (!init) for (int i = tid; i < nScale; i += 64) scale += i < 512 ? s_scaleP[i] : scalePart[i];
+    chi = wave_sum_d(chi);
+    scale = wave_sum_d(scale);
+  }
+  if (tid != 0) return;
   int abortReq;
   if (SHARDED) {  // reduced over the ranks: identical on all of them, and so is every decision below
     chi = XB[xb.oS]; scale = XB[xb.oS + 1];
     abortReq = XB[xb.oS + 2] > 0.0;
   } else {
-    for (int i = 0; i < nLin; i++) chi += i < 512 ? s_chiP[i] : B.chiPart[i];
     chi += B.chiPart[chiSlot];
-    if (!init) for (int i = 0; i < nScale; i++) scale += i < 512 ? s_scaleP[i] : scalePart[i];
     abortReq = *abortLocal;
   }
   double maxDiag = 0;
@@ -1959,7 +1965,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
     bool abortSent = false;
     static const int one = 1;
     // a typical schedule takes one trial per iteration: its1 + its2 trials + the two opening linearisations
-    int batch = anything ? sc.its1 + (sc.gate ? sc.its2 + 1 : 0) + 1 + 3 : 0;
+    int batch = anything ? sc.its1 + (sc.gate ? sc.its2 + 1 : 0) + 1 + 2 : 0;
     int rcLoop = FB_OK;
     lap("buffers ready");
     for (int round = 0; round < 64; round++) {
