@@ -19,6 +19,8 @@ def _vp(t):
 
 
 class FramePipeline:
+    _streams = {}  # device -> (front, bird, pose) streams
+
     def __init__(self, batch, front_wh=(1280, 720), bird_wh=(512, 512), n_last=2000, n_ref=1000, device="cuda:0",
                  fx=500.0, fy=500.0, orb=None):
         self.L = lib()
@@ -53,20 +55,30 @@ class FramePipeline:
         self.last = dict(valid=z(B, n_last), obs=z(B, n_last), xw=z(B, n_last, 3, dt=torch.float32), desc=z(B, n_last, 32),
                          octave=z(B, n_last, dt=torch.int32), angle=z(B, n_last, dt=torch.float32), n=z(B, dt=torch.int32))
         self.ref = dict(valid=z(B, n_ref), xw=z(B, n_ref, 3, dt=torch.float32), desc=z(B, n_ref, 32), n=z(B, dt=torch.int32))
-        self.Tcw0, self.Tcw = z(B, 12, dt=torch.float32), z(B, 12, dt=torch.float32)
-        # match + pose buffers
+        self.Tcw0 = z(B, 12, dt=torch.float32)
+        # match buffers
         self.m_front, self.nm_front = z(B, cap, dt=torch.int32), z(B, dt=torch.int32)
         self.m_bird, self.nm_bird = z(B, cap, dt=torch.int32), z(B, dt=torch.int32)
-        self.e_fxw, self.e_fobs = z(B, cap, 3, dt=torch.float32), z(B, cap, 2, dt=torch.float32)
-        self.e_finf, self.e_fvalid, self.e_fout = z(B, cap, dt=torch.float32), z(B, cap), z(B, cap)
-        self.e_bxw, self.e_bxc = z(B, cap, 3, dt=torch.float32), z(B, cap, 3, dt=torch.float32)
-        self.e_binf, self.e_bvalid, self.e_bout = z(B, cap, dt=torch.float32), z(B, cap), z(B, cap)
-        self.ninl = z(B, dt=torch.int32)
-        self.e_nf, self.e_nb = z(B, dt=torch.int32), z(B, dt=torch.int32)  # slot counts seen by the pose stage
+        # pose stage: edge arrays, pose, outlier flags and counts exist TWICE (set k & 1 belongs to step k), so that the edge
+        # gather of step k + 1 does not have to wait for the pose kernel of step k to let go of its inputs: consecutive pose
+        # kernels run back to back (at B = 1 the wait was 60 us of a 398 us step)
+        self._sets = []
+        for _ in range(2):
+            self._sets.append(dict(
+                Tcw=z(B, 12, dt=torch.float32), e_fxw=z(B, cap, 3, dt=torch.float32), e_fobs=z(B, cap, 2, dt=torch.float32),
+                e_finf=z(B, cap, dt=torch.float32), e_fvalid=z(B, cap), e_fout=z(B, cap), e_bxw=z(B, cap, 3, dt=torch.float32),
+                e_bxc=z(B, cap, 3, dt=torch.float32), e_binf=z(B, cap, dt=torch.float32), e_bvalid=z(B, cap), e_bout=z(B, cap),
+                ninl=z(B, dt=torch.int32), e_nf=z(B, dt=torch.int32), e_nb=z(B, dt=torch.int32), evP=torch.cuda.Event(), pending=False))
+        self._k = 0  # step counter; results_host() reads the set of the last step
         # three streams: front chain, bird chain, pose optimisation (latency-bound, overlaps the next extraction)
-        self.sF, self.sB, self.sP = (torch.cuda.Stream(device=d) for _ in range(3))
-        self.evF, self.evB, self.evP = (torch.cuda.Event() for _ in range(3))
-        self._pose_pending = False
+        # (the three streams are shared by every pipeline of a device: the HIP runtime folds streams onto a few hardware queues,
+        # and streams that land on one queue serialise -- a second pipeline with streams of its own measured 0.72 instead of
+        # 0.47 ms per step at B = 8)
+        key = str(d)
+        if key not in FramePipeline._streams:
+            FramePipeline._streams[key] = tuple(torch.cuda.Stream(device=d) for _ in range(3))
+        self.sF, self.sB, self.sP = FramePipeline._streams[key]
+        self.evF, self.evB = (torch.cuda.Event() for _ in range(2))
         self._inv_sigma2 = (C.c_float * cabi.FB_MAX_LEVELS)(*self.tables.inv_level_sigma2)
         self._Tcb12 = (C.c_float * 12)(*[float(x) for x in self.Tcb[:3, :4].reshape(12)])
         self._build_args()
@@ -101,13 +113,14 @@ class FramePipeline:
         m.grid = self.geom_b
         fill(m.matcher, nnratio=0.9, check_orientation=1)  # Tracking.cc:2008
         self.a_m9 = m
-        p = cabi.PoseOptArgs()
-        fill(p, batch=B, mode=cabi.FB_POSE_FRONT_BIRD, front_stride=cap, bird_stride=cap, fx=self.fx, fy=self.fy,
-             cx=self.cx, cy=self.cy, wF=1.0, wB=1.0, n_front=self.e_nf, front_xw=self.e_fxw, front_obs=self.e_fobs,
-             front_inv_sigma2=self.e_finf, front_valid=self.e_fvalid, n_bird=self.e_nb, bird_xw=self.e_bxw,
-             bird_xc=self.e_bxc, bird_inv_sigma2=self.e_binf, bird_valid=self.e_bvalid, bird_outlier=self.e_bout,
-             Tcw=self.Tcw, front_outlier=self.e_fout, ninliers=self.ninl)
-        self.a_pose = p
+        for S in self._sets:
+            p = cabi.PoseOptArgs()
+            fill(p, batch=B, mode=cabi.FB_POSE_FRONT_BIRD, front_stride=cap, bird_stride=cap, fx=self.fx, fy=self.fy,
+                 cx=self.cx, cy=self.cy, wF=1.0, wB=1.0, n_front=S["e_nf"], front_xw=S["e_fxw"], front_obs=S["e_fobs"],
+                 front_inv_sigma2=S["e_finf"], front_valid=S["e_fvalid"], n_bird=S["e_nb"], bird_xw=S["e_bxw"],
+                 bird_xc=S["e_bxc"], bird_inv_sigma2=S["e_binf"], bird_valid=S["e_bvalid"], bird_outlier=S["e_bout"],
+                 Tcw=S["Tcw"], front_outlier=S["e_fout"], ninliers=S["ninl"])
+            S["a_pose"] = p
 
     # ---- stages ----
     def extract(self, s, which="both"):
@@ -135,28 +148,29 @@ class FramePipeline:
         self.m_bird.fill_(-1)  # mvpMapPointsBird starts empty for a new frame
         check(self.L.fb_match_bird_mappoints_dev(C.byref(self.a_m9), s), "M9")
 
-    def gather_front(self, s):
+    def gather_front(self, s, S):
         L, B, cap, nl = self.L, self.B, self.cap, self.params.nlevels
-        self.e_nf.copy_(self.f_n)
+        S["e_nf"].copy_(self.f_n)
+        S["Tcw"].copy_(self.Tcw0)   # SetPose(prediction), Tracking.cc:1314-1320
         check(L.fb_pose_gather_front_dev(B, cap, self.nl, _vp(self.f_n), _vp(self.f_kps), _vp(self.m_front), _vp(self.last["xw"]),
-                                         self._inv_sigma2, nl, _vp(self.e_fxw), _vp(self.e_fobs), _vp(self.e_finf), _vp(self.e_fvalid), s), "gather front")
+                                         self._inv_sigma2, nl, _vp(S["e_fxw"]), _vp(S["e_fobs"]), _vp(S["e_finf"]), _vp(S["e_fvalid"]), s), "gather front")
 
-    def gather_bird(self, s):
+    def gather_bird(self, s, S):
         L, B, cap, nl = self.L, self.B, self.cap, self.params.nlevels
-        self.e_nb.copy_(self.b_n)
+        S["e_nb"].copy_(self.b_n)
+        S["e_bout"].zero_()         # mvBirdOutlier of a fresh Frame
         check(L.fb_pose_gather_bird_dev(B, cap, self.nr, _vp(self.b_n), _vp(self.b_kps), _vp(self.b_cam), _vp(self.m_bird), _vp(self.ref["xw"]),
-                                        self._inv_sigma2, nl, _vp(self.e_bxw), _vp(self.e_bxc), _vp(self.e_binf), _vp(self.e_bvalid), s), "gather bird")
+                                        self._inv_sigma2, nl, _vp(S["e_bxw"]), _vp(S["e_bxc"]), _vp(S["e_binf"]), _vp(S["e_bvalid"]), s), "gather bird")
 
-    def pose(self, s):
-        self.Tcw.copy_(self.Tcw0)   # SetPose(prediction), Tracking.cc:1314-1320
-        self.e_bout.zero_()         # mvBirdOutlier of a fresh Frame
-        check(self.L.fb_pose_opt_batch_dev(C.byref(self.a_pose), s), "pose opt")
+    def pose(self, s, S):
+        check(self.L.fb_pose_opt_batch_dev(C.byref(S["a_pose"]), s), "pose opt")
 
     def step(self):
         """One pass of the hot path over the batch.  The front chain and the bird chain run on their own streams;
         the pose optimisation (one workgroup per frame, latency bound) runs on a third one so that it overlaps the
         next step's extraction.  Callers synchronise with torch.cuda.synchronize() / results_host()."""
         cur = torch.cuda.current_stream(self.dev)
+        S = self._sets[self._k & 1]
         self.sF.wait_stream(cur)
         self.sB.wait_stream(cur)
         with torch.cuda.stream(self.sF):
@@ -164,36 +178,41 @@ class FramePipeline:
             self.extract(s, "front")
             self.grids(s, "front")
             self.match_front(s)
-            if self._pose_pending:
-                self.sF.wait_event(self.evP)  # the previous step's pose kernel still reads the edge arrays
-            self.gather_front(s)
+            if S["pending"]:
+                self.sF.wait_event(S["evP"])  # the pose kernel of two steps ago read this set's edge arrays
+            self.gather_front(s, S)
             self.evF.record(self.sF)
         with torch.cuda.stream(self.sB):
             s = C.c_void_p(self.sB.cuda_stream)
             self.extract(s, "bird")
             self.grids(s, "bird")
             self.match_bird(s)
-            if self._pose_pending:
-                self.sB.wait_event(self.evP)
-            self.gather_bird(s)
+            if S["pending"]:
+                self.sB.wait_event(S["evP"])
+            self.gather_bird(s, S)
             self.evB.record(self.sB)
         with torch.cuda.stream(self.sP):
             self.sP.wait_event(self.evF)
             self.sP.wait_event(self.evB)
-            self.pose(C.c_void_p(self.sP.cuda_stream))
-            self.evP.record(self.sP)
-            self._pose_pending = True
+            self.pose(C.c_void_p(self.sP.cuda_stream), S)
+            S["evP"].record(self.sP)
+            S["pending"] = True
+        self._last = S
+        self._k += 1
 
     def step_serial(self):
         """The same pass on torch's current stream only (used by tests and for single-stream timing)."""
         s = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        S = self._sets[self._k & 1]
         self.extract(s)
         self.grids(s)
         self.match_front(s)
         self.match_bird(s)
-        self.gather_front(s)
-        self.gather_bird(s)
-        self.pose(s)
+        self.gather_front(s, S)
+        self.gather_bird(s, S)
+        self.pose(s, S)
+        self._last = S
+        self._k += 1
 
     # ---- synthetic world (untimed setup) ----
     def set_images(self, front, bird):
@@ -272,7 +291,8 @@ class FramePipeline:
 
     def results_host(self):
         torch.cuda.synchronize()
+        S = self._last
         return dict(n_front=self.f_n.cpu().numpy(), n_bird=self.b_n.cpu().numpy(), nm_front=self.nm_front.cpu().numpy(),
-                    nm_bird=self.nm_bird.cpu().numpy(), ninliers=self.ninl.cpu().numpy(), Tcw=self.Tcw.cpu().numpy(),
-                    front_outlier=self.e_fout.cpu().numpy(), bird_outlier=self.e_bout.cpu().numpy(),
+                    nm_bird=self.nm_bird.cpu().numpy(), ninliers=S["ninl"].cpu().numpy(), Tcw=S["Tcw"].cpu().numpy(),
+                    front_outlier=S["e_fout"].cpu().numpy(), bird_outlier=S["e_bout"].cpu().numpy(),
                     m_front=self.m_front.cpu().numpy(), m_bird=self.m_bird.cpu().numpy())
