@@ -291,6 +291,13 @@ __device__ __forceinline__ int block_excl_scan256(int v, int *s_w /*[4]*/, int *
   return base + inc - v;
 }
 
+// one 2-byte LDS store from the lanes of `mask` (exec is put back afterwards)
+__device__ __forceinline__ void lds_store_u16_masked(uint32_t addr, uint32_t val, unsigned long long mask) {
+  unsigned long long save;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tds_write_b16 %1, %2\n\ts_mov_b64 exec, %0"
+               : "=&s"(save) : "v"(addr), "v"(val), "s"(mask) : "memory");
+}
+
 constexpr int FAST_MAX_TILE = 72;  // cell window <= wCell+6 <= 65 px, +3 alignment slack
 
 // One WAVE per run of FAST_CPW consecutive cells (64-thread workgroups, no cross-wave barriers, up to 31 waves per CU).
@@ -409,60 +416,78 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
     // ---- ONE sweep over the cell: compact every pixel that can be a corner (necessary compass test) into two lists
     //      sharing one array: from the front the pixels that pass at iniThFAST, from the back those that only pass
     //      at minThFAST (needed only when the cell has to be redone at the lower threshold)
-    int nlA = 0, nlB = 0;
     const int cap = K.fastMaxPix;
     // Lanes map to (row-pair, column): 32 columns x 2 row pairs per iteration for the usual <= 32 px wide cells, 64 x 1
     // otherwise, so the LDS offset advances by a constant and no index division is needed.  A lane tests TWO vertically
-    // adjacent pixels at once in packed 16-bit arithmetic (v_pk_sub/min/max_i16).  The compass test for ANY threshold T
-    // is "strength > T" with strength = max(max over adjacent compass pairs of min(d_i, d_j), -(min over adjacent pairs
-    // of max(d_i, d_j))): two adjacent compass points brighter, or two darker, by more than T.
+    // adjacent pixels at once in packed 16-bit arithmetic.  With the compass pixels n0 (below), n4 (right), n8 (above),
+    // n12 (left) of centre v, "two ADJACENT compass points brighter than v + T" is "one of {n0, n8} AND one of {n4, n12}"
+    // (every such pair is adjacent), i.e. v + T < B with B = min(max(n0, n8), max(n4, n12)); likewise two darker ones are
+    // v - T > A with A = max(min(n0, n8), min(n4, n12)).  strength = max(v - A, B - v) > T is the test for ANY threshold:
+    // 9 packed operations for two pixels.
     (void)npix;
     typedef short s16x2 __attribute__((ext_vector_type(2)));
-    const int G = dwid <= 32 ? 32 : 64, ppi = dwid <= 32 ? 2 : 1;  // row pairs per iteration
-    const int sxx = lane & (G - 1), spr = dwid <= 32 ? (lane >> 5) : 0;
-    const bool colok = sxx < dwid;
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const bool two = dwid <= 32;  // two row pairs per iteration
+    const int G = two ? 32 : 64, ppi = two ? 2 : 1;
+    const int sxx = lane & (G - 1);
+    const bool hiHalf = two && lane >= 32, colok = sxx < dwid;
     const int tp3 = 3 * tp, sstep = 2 * ppi * tp;
-    int off = (3 + 2 * spr) * tp + ox + 3 + sxx;  // upper pixel of the lane's pair
-    for (int y = 0; y < dhei; y += 2 * ppi, off += sstep) {
-      const int r0 = y + 2 * spr;
-      int s0 = -1, s1 = -1;
-      if (colok && r0 < dhei) {
-        // rows r0 and r0+1 (the lower one may lie below the cell: its reads stay inside the LDS tile + score tile and the
-        // result is discarded)
-        const uint8_t *c = &tile[off];
-        const s16x2 v = {(short)c[0], (short)c[tp]};
-        const s16x2 n0 = {(short)c[tp3], (short)c[tp3 + tp]}, n8 = {(short)c[-tp3], (short)c[-tp3 + tp]};
-        const s16x2 n4 = {(short)c[3], (short)c[tp + 3]}, n12 = {(short)c[-3], (short)c[tp - 3]};
-        const s16x2 d0 = v - n0, d4 = v - n4, d8 = v - n8, d12 = v - n12;
+    const int off = (3 + (hiHalf ? 2 : 0)) * tp + ox + 3 + sxx;  // upper pixel of the lane's pair
+    // the two lists are addressed in LDS bytes: the next free slot of A (growing up) and of B (growing down) are
+    // wave-uniform, a lane's slot = base +- 2 * (its rank among the lanes that pass)
+    const uint32_t listBase = (uint32_t)(uintptr_t)s_list;
+    uint32_t baseA = listBase, baseB = listBase + 2u * (uint32_t)(cap - 1);
+    const short iniT = (short)K.iniTh, minT = (short)K.minTh;
+    const int iniHi = (K.iniTh + 1) << 16, minHi = (K.minTh + 1) << 16;  // the upper pixel's strength leads the packed word
+    // lane masks of the valid columns / of the two half waves (64-bit scalars: all the validity logic is scalar)
+    const unsigned long long colMask = __builtin_amdgcn_ballot_w64(colok);
+    const unsigned long long loMask = two ? 0xffffffffull : ~0ull, hiMask = ~loMask;
+    // mA / mAB = lanes whose pixel passes at iniThFAST / minThFAST: rank among the set lanes (v_mbcnt), one 2-byte LDS
+    // store under exec = mask.  Skipped (wave-uniform) when no lane passes.
+    auto emit = [&](unsigned long long mA, unsigned long long mAB, int offp) {
+      if (mAB == 0ull) return;
+      if (mA != 0ull) {
+        const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u));
+        lds_store_u16_masked(baseA + 2u * r, (uint32_t)offp, mA);
+        baseA += 2u * (uint32_t)__popcll(mA);
+      }
+      const unsigned long long mB = mAB & ~mA;
+      if (mB != 0ull) {
+        const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u));
+        uint32_t ad;
+        asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(ad) : "v"(r), "s"(baseB));
+        lds_store_u16_masked(ad, (uint32_t)offp, mB);
+        baseB -= 2u * (uint32_t)__popcll(mB);
+      }
+    };
+    // all ten taps at non-negative constant distances from the lane's lowest tap (3 rows up, 3 columns left is the
+    // corner of that box), so that every LDS read is base + immediate
+    int lo = off - tp3 - 3;
+    for (int y = 0; y < dhei; y += 2 * ppi, lo += sstep) {
+      // rows r0 = y (+2 for the upper half wave) and r0 + 1; a row below the cell reads inside the LDS tile + score tile
+      // and its result is masked
+      asm volatile("" : "+v"(lo));
+      const uint8_t *c = &tile[lo];
+      constexpr int Cc = 3 * TP + 3;  // the centre (upper pixel of the pair)
+      const uint32_t b0 = c[Cc], b1 = c[Cc + TP], b2 = c[Cc + 3 * TP], b3 = c[Cc + 4 * TP], b4 = c[Cc - 3 * TP], b5 = c[Cc - 2 * TP];
+      const uint32_t b6 = c[Cc + 3], b7 = c[Cc + TP + 3], b8 = c[Cc - 3], b9 = c[Cc + TP - 3];
+      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);  // the ten LDS reads back to back, then the arithmetic
+      auto pair = [&](uint32_t x, uint32_t yv) { return __builtin_bit_cast(u16x2, x | (yv << 16)); };
+      const u16x2 v = pair(b0, b1), n0 = pair(b2, b3), n8 = pair(b4, b5), n4 = pair(b6, b7), n12 = pair(b8, b9);
   #define PMIN(a, b) __builtin_elementwise_min(a, b)
   #define PMAX(a, b) __builtin_elementwise_max(a, b)
-        const s16x2 hi = PMAX(PMAX(PMIN(d0, d4), PMIN(d4, d8)), PMAX(PMIN(d8, d12), PMIN(d12, d0)));
-        const s16x2 lo = PMIN(PMIN(PMAX(d0, d4), PMAX(d4, d8)), PMIN(PMAX(d8, d12), PMAX(d12, d0)));
-        const s16x2 zero = {0, 0};
-        const s16x2 st = PMAX(hi, zero - lo);
+      const u16x2 A = PMAX(PMIN(n0, n8), PMIN(n4, n12)), Bv = PMIN(PMAX(n0, n8), PMAX(n4, n12));
+      const s16x2 st = PMAX(__builtin_bit_cast(s16x2, (u16x2)(v - A)), __builtin_bit_cast(s16x2, (u16x2)(Bv - v)));
   #undef PMIN
   #undef PMAX
-        s0 = st.x;
-        s1 = (r0 + 1 < dhei) ? (int)st.y : -1;
-      }
-  #pragma unroll
-      for (int h2 = 0; h2 < 2; h2++) {
-        const int strength = h2 == 0 ? s0 : s1;
-        const int offp = off + h2 * tp;
-        const bool c9i = strength > K.iniTh, c9 = strength > K.minTh;
-        // branch-free two-ended compaction: rank among the ini-threshold lanes (front) / among the others (back)
-        const unsigned long long mA = __ballot(c9i), mAB = __ballot(c9);
-        const int pA = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u));
-        const int pAB = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mAB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mAB, 0u));
-        const int idxA = nlA + pA, idxB = cap - 1 - nlB - (pAB - pA);
-        int idx;  // plain select on the ballot mask (the compiler turns the ternary into two divergent branches)
-        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(idx) : "v"(idxB), "v"(idxA), "s"(mA));
-        if (c9) s_list[idx] = (unsigned short)offp;
-        const int cA = __popcll(mA);
-        nlA += cA;
-        nlB += __popcll(mAB) - cA;
-      }
+      const int pk = __builtin_bit_cast(int, st);
+      const unsigned long long ok0 = colMask & (loMask | (y + 2 < dhei ? hiMask : 0ull));
+      const unsigned long long ok1 = colMask & ((y + 1 < dhei ? loMask : 0ull) | (y + 3 < dhei ? hiMask : 0ull));
+      emit(__builtin_amdgcn_ballot_w64(st.x > iniT) & ok0, __builtin_amdgcn_ballot_w64(st.x > minT) & ok0, lo + Cc);
+      emit(__builtin_amdgcn_ballot_w64(pk >= iniHi) & ok1, __builtin_amdgcn_ballot_w64(pk >= minHi) & ok1, lo + Cc + TP);
     }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the list stores are issued from inline assembly
+    const int nlA = (int)((baseA - listBase) >> 1), nlB = (int)((listBase + 2u * (uint32_t)(cap - 1) - baseB) >> 1);
     __syncthreads();
     FAST_TICK(2)  // sweep
       if (K.dbg == 4) { if (nlA + nlB == 123456) cand[0] = 1; return; }
@@ -527,6 +552,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
       stage(g);
       if (timed) { if (tile[lane] == 255 && sc[lane] == 7) cand[0] = 1; }  // forces the wait for the staged tile
       FAST_TICK(0)  // wait for the tile + LDS writes
+      // Nothing is outstanding here (the tile has landed), but the compiler cannot see that for the lanes that skipped a
+      // row: without this explicit vmcnt(0) it protects their registers with vmcnt(0) waits AFTER the prefetch below,
+      // i.e. the wave would sit out the next tile's latency before it starts on this one.
+      __builtin_amdgcn_s_waitcnt(0x0F70);
       if (haveNext && gn.ok && aligned) issue(gn);  // in flight while this cell is processed
       FAST_TICK(1)  // prefetch issue
       process(g, cell);
