@@ -291,11 +291,15 @@ __device__ __forceinline__ int block_excl_scan256(int v, int *s_w /*[4]*/, int *
   return base + inc - v;
 }
 
-// one 2-byte LDS store from the lanes of `mask` (exec is put back afterwards)
-__device__ __forceinline__ void lds_store_u16_masked(uint32_t addr, uint32_t val, unsigned long long mask) {
-  unsigned long long save;
-  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tds_write_b16 %1, %2\n\ts_mov_b64 exec, %0"
-               : "=&s"(save) : "v"(addr), "v"(val), "s"(mask) : "memory");
+// inclusive scan over the 64 lanes in the VALU (DPP row shifts, then the row broadcasts of gfx9)
+__device__ __forceinline__ int wave_incl_scan_dpp(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
+  return v;
 }
 
 constexpr int FAST_MAX_TILE = 72;  // cell window <= wCell+6 <= 65 px, +3 alignment slack
@@ -313,9 +317,12 @@ constexpr int FAST_MAX_TILE = 72;  // cell window <= wCell+6 <= 65 px, +3 alignm
 //     Candidate order is irrelevant downstream (the quadtree breaks response ties with an order key derived from x,y).
 // TP = tile pitch in bytes, a compile-time constant so that every LDS access of the sweep / score / NMS is
 // base + immediate offset (44 covers cells up to 35 px wide, i.e. every level of the usual image sizes).
+#ifndef FB_FAST_WPE44
+#define FB_FAST_WPE44 6  // register budget of the 44-byte instantiation, in waves per SIMD
+#endif
 constexpr int FAST_CPW = 4;  // consecutive cells per wave; the tile of cell i+1 is in flight while cell i is processed
 template <int TP, bool TIMED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_fast(OrbK K, const uint8_t *__restrict__ img0, long long imgStride, int pitch0,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? FB_FAST_WPE44 : 4, 8))) void k_fast(OrbK K, const uint8_t *__restrict__ img0, long long imgStride, int pitch0,
                                              const uint8_t *__restrict__ pyr, uint32_t *__restrict__ cand,
                                              int *__restrict__ cellCount) {
   // LDS carve (sized on the host for the largest cell of this image size): tile (later: survivors) | sc | list
@@ -329,10 +336,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
   const int b = blockIdx.y, lane = threadIdx.x;
   // FB_FAST_DBG=20: one workgroup in 16 accumulates its phase times in registers and adds them once, at the end
   const bool timed = TIMED && (blockIdx.x & 15) == 0;  // the TIMED instantiation is launched for FB_FAST_DBG=20 only
-  unsigned long long t_mark = 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (timed) { __builtin_amdgcn_sched_barrier(0); t_mark = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-  const unsigned long long t_start = t_mark;
-#define FAST_TICK(slot_) if (TIMED && timed) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); t_acc[slot_] += t_ - t_mark; t_mark = t_; }
+  uint32_t t_mark = 0, t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // shader clock, low 32 bits
+  if (timed) { __builtin_amdgcn_sched_barrier(0); t_mark = (uint32_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+  const uint32_t t_start = t_mark;
+#define FAST_TICK(slot_) if (TIMED && timed) { __builtin_amdgcn_sched_barrier(0); const uint32_t t_ = (uint32_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); t_acc[slot_] += t_ - t_mark; t_mark = t_; }
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one), so give each
   // XCD a contiguous run of cell groups -- neighbouring cells overlap by 6 px and share lines in that XCD's L2
   int grp, l = 0;
@@ -406,16 +413,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
         tile[yy * tp + xx] = img[(long long)(g.y0 + yy) * pitch + g.x0 + xx];
       }
     }
-    for (int i = lane; i < (tp * g.ch + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(sc)[i] = 0;
+    FAST_TICK(13)  // the tile has landed and is in LDS
+    {  // score tile <- 0, 16 bytes per lane and store (the tile sizes are multiples of 16, the carve is 16-byte aligned)
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      for (int i = lane; i < (tp * g.ch + 15) / 16; i += 64) reinterpret_cast<u32x4 *>(sc)[i] = z;
+    }
     __syncthreads();
   };
   auto process = [&](const Geo &g, int cell) {
     const int x0 = g.x0, y0 = g.y0, cw = g.cw, ch = g.ch, ox = g.ox;
     if (K.dbg == 1) { if (tile[lane] == 255 && sc[lane] == 7) cand[0] = 1; return; }
     const int dwid = cw - 6, dhei = ch - 6, npix = dwid * dhei;
-    // ---- ONE sweep over the cell: compact every pixel that can be a corner (necessary compass test) into two lists
-    //      sharing one array: from the front the pixels that pass at iniThFAST, from the back those that only pass
-    //      at minThFAST (needed only when the cell has to be redone at the lower threshold)
+    // ---- ONE sweep over the cell: every pixel that can be a corner (necessary compass test) becomes a bit of a
+    //      per-lane mask, one mask for iniThFAST (A) and one for minThFAST only (B); the A masks are expanded into a
+    //      list of tile offsets (front of s_list), the B masks only if the cell has to be redone at minThFAST (back of
+    //      s_list, growing down).  No cross-lane work and no scalar bookkeeping inside the sweep.
     const int cap = K.fastMaxPix;
     // Lanes map to (row-pair, column): 32 columns x 2 row pairs per iteration for the usual <= 32 px wide cells, 64 x 1
     // otherwise, so the LDS offset advances by a constant and no index division is needed.  A lane tests TWO vertically
@@ -423,78 +436,94 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
     // n12 (left) of centre v, "two ADJACENT compass points brighter than v + T" is "one of {n0, n8} AND one of {n4, n12}"
     // (every such pair is adjacent), i.e. v + T < B with B = min(max(n0, n8), max(n4, n12)); likewise two darker ones are
     // v - T > A with A = max(min(n0, n8), min(n4, n12)).  strength = max(v - A, B - v) > T is the test for ANY threshold:
-    // 9 packed operations for two pixels.
+    // 9 packed operations for two pixels; the sign bits of T - strength shift into the masks (3 operations per threshold).
     (void)npix;
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) unsigned short lds_u16;
     const bool two = dwid <= 32;  // two row pairs per iteration
     const int G = two ? 32 : 64, ppi = two ? 2 : 1;
     const int sxx = lane & (G - 1);
     const bool hiHalf = two && lane >= 32, colok = sxx < dwid;
     const int tp3 = 3 * tp, sstep = 2 * ppi * tp;
-    const int off = (3 + (hiHalf ? 2 : 0)) * tp + ox + 3 + sxx;  // upper pixel of the lane's pair
-    // the two lists are addressed in LDS bytes: the next free slot of A (growing up) and of B (growing down) are
-    // wave-uniform, a lane's slot = base +- 2 * (its rank among the lanes that pass)
-    const uint32_t listBase = (uint32_t)(uintptr_t)s_list;
-    uint32_t baseA = listBase, baseB = listBase + 2u * (uint32_t)(cap - 1);
-    const short iniT = (short)K.iniTh, minT = (short)K.minTh;
-    const int iniHi = (K.iniTh + 1) << 16, minHi = (K.minTh + 1) << 16;  // the upper pixel's strength leads the packed word
-    // lane masks of the valid columns / of the two half waves (64-bit scalars: all the validity logic is scalar)
-    const unsigned long long colMask = __builtin_amdgcn_ballot_w64(colok);
-    const unsigned long long loMask = two ? 0xffffffffull : ~0ull, hiMask = ~loMask;
-    // mA / mAB = lanes whose pixel passes at iniThFAST / minThFAST: rank among the set lanes (v_mbcnt), one 2-byte LDS
-    // store under exec = mask.  Skipped (wave-uniform) when no lane passes.
-    auto emit = [&](unsigned long long mA, unsigned long long mAB, int offp) {
-      if (mAB == 0ull) return;
-      if (mA != 0ull) {
-        const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u));
-        lds_store_u16_masked(baseA + 2u * r, (uint32_t)offp, mA);
-        baseA += 2u * (uint32_t)__popcll(mA);
+    const int rLane = hiHalf ? 2 : 0;                        // first row of the lane
+    const int off = (3 + rLane) * tp + ox + 3 + sxx;         // its upper pixel
+    const uint32_t listBase = (uint32_t)(uintptr_t)s_list;  // LDS byte address
+    uint32_t baseA = listBase, baseB = listBase + 2u * (uint32_t)(cap - 1);  // next free slot: A grows up, B down
+    const u16x2 iniV = {(unsigned short)K.iniTh, (unsigned short)K.iniTh}, minV = {(unsigned short)K.minTh, (unsigned short)K.minTh};
+    constexpr int Cc = 3 * TP + 3;  // the centre (upper pixel of the pair) seen from the lane's lowest tap
+    // a mask word: bit p of the low half = upper pixel of chunk iteration p - (16 - n), high half = lower pixel
+    auto expand = [&](uint32_t W, uint32_t &base, const bool up, int cj) {
+      const int cnt = __popc(W);
+      const int incl = wave_incl_scan_dpp(cnt);
+      const int total = __builtin_amdgcn_readlane(incl, 63);
+      if (total == 0) return;  // wave-uniform
+      const uint32_t e = 2u * (uint32_t)(incl - cnt);
+      uint32_t a = up ? base + e : base - e;
+      while (W != 0u) {  // one listed pixel per lane and trip
+        const int bpos = __builtin_ctz(W);
+        W &= W - 1u;
+        const int offp = cj + (bpos & 15) * sstep + (bpos >> 4) * tp;
+        *reinterpret_cast<lds_u16 *>((uintptr_t)a) = (unsigned short)offp;
+        a = up ? a + 2u : a - 2u;
       }
-      const unsigned long long mB = mAB & ~mA;
-      if (mB != 0ull) {
-        const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u));
-        uint32_t ad;
-        asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(ad) : "v"(r), "s"(baseB));
-        lds_store_u16_masked(ad, (uint32_t)offp, mB);
-        baseB -= 2u * (uint32_t)__popcll(mB);
-      }
+      base = up ? base + 2u * (uint32_t)total : base - 2u * (uint32_t)total;
     };
     // all ten taps at non-negative constant distances from the lane's lowest tap (3 rows up, 3 columns left is the
     // corner of that box), so that every LDS read is base + immediate
     int lo = off - tp3 - 3;
-    for (int y = 0; y < dhei; y += 2 * ppi, lo += sstep) {
-      // rows r0 = y (+2 for the upper half wave) and r0 + 1; a row below the cell reads inside the LDS tile + score tile
-      // and its result is masked
-      asm volatile("" : "+v"(lo));
-      const uint8_t *c = &tile[lo];
-      constexpr int Cc = 3 * TP + 3;  // the centre (upper pixel of the pair)
-      const uint32_t b0 = c[Cc], b1 = c[Cc + TP], b2 = c[Cc + 3 * TP], b3 = c[Cc + 4 * TP], b4 = c[Cc - 3 * TP], b5 = c[Cc - 2 * TP];
-      const uint32_t b6 = c[Cc + 3], b7 = c[Cc + TP + 3], b8 = c[Cc - 3], b9 = c[Cc + TP - 3];
-      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);  // the ten LDS reads back to back, then the arithmetic
-      auto pair = [&](uint32_t x, uint32_t yv) { return __builtin_bit_cast(u16x2, x | (yv << 16)); };
-      const u16x2 v = pair(b0, b1), n0 = pair(b2, b3), n8 = pair(b4, b5), n4 = pair(b6, b7), n12 = pair(b8, b9);
+    const int nIt = __builtin_amdgcn_readfirstlane((dhei + 2 * ppi - 1) >> ppi);  // 2 * ppi = 1 << ppi rows per iteration
+    uint32_t WB[2] = {0u, 0u};  // the minThFAST-only masks of the (at most two) chunks of 16 iterations
+    int cjB[2] = {0, 0};
+    for (int it0 = 0, ck = 0; it0 < nIt; it0 += 16, ck++) {
+      const int n = min(16, nIt - it0);
+      uint32_t accA = 0u, accB = 0u;
+      const int cj = lo + Cc - (16 - n) * sstep;  // tile offset of bit 0
+      for (int j = 0; j < n; j++, lo += sstep) {
+        // rows beyond the cell read inside the LDS tile + score tile; their bits are masked below
+        asm volatile("" : "+v"(lo));
+        const uint8_t *c = &tile[lo];
+        const uint32_t b0 = c[Cc], b1 = c[Cc + TP], b2 = c[Cc + 3 * TP], b3 = c[Cc + 4 * TP], b4 = c[Cc - 3 * TP], b5 = c[Cc - 2 * TP];
+        const uint32_t b6 = c[Cc + 3], b7 = c[Cc + TP + 3], b8 = c[Cc - 3], b9 = c[Cc + TP - 3];
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);  // the ten LDS reads back to back, then the arithmetic
+        auto pair = [&](uint32_t x, uint32_t yv) { return __builtin_bit_cast(u16x2, x | (yv << 16)); };
+        const u16x2 v = pair(b0, b1), n0 = pair(b2, b3), n8 = pair(b4, b5), n4 = pair(b6, b7), n12 = pair(b8, b9);
   #define PMIN(a, b) __builtin_elementwise_min(a, b)
   #define PMAX(a, b) __builtin_elementwise_max(a, b)
-      const u16x2 A = PMAX(PMIN(n0, n8), PMIN(n4, n12)), Bv = PMIN(PMAX(n0, n8), PMAX(n4, n12));
-      const s16x2 st = PMAX(__builtin_bit_cast(s16x2, (u16x2)(v - A)), __builtin_bit_cast(s16x2, (u16x2)(Bv - v)));
+        const u16x2 A = PMAX(PMIN(n0, n8), PMIN(n4, n12)), Bv = PMIN(PMAX(n0, n8), PMAX(n4, n12));
+        const s16x2 st = PMAX(__builtin_bit_cast(s16x2, (u16x2)(v - A)), __builtin_bit_cast(s16x2, (u16x2)(Bv - v)));
   #undef PMIN
   #undef PMAX
-      const int pk = __builtin_bit_cast(int, st);
-      const unsigned long long ok0 = colMask & (loMask | (y + 2 < dhei ? hiMask : 0ull));
-      const unsigned long long ok1 = colMask & ((y + 1 < dhei ? loMask : 0ull) | (y + 3 < dhei ? hiMask : 0ull));
-      emit(__builtin_amdgcn_ballot_w64(st.x > iniT) & ok0, __builtin_amdgcn_ballot_w64(st.x > minT) & ok0, lo + Cc);
-      emit(__builtin_amdgcn_ballot_w64(pk >= iniHi) & ok1, __builtin_amdgcn_ballot_w64(pk >= minHi) & ok1, lo + Cc + TP);
+        const u16x2 stu = __builtin_bit_cast(u16x2, st);
+        const uint32_t sA = __builtin_bit_cast(uint32_t, (u16x2)(iniV - stu)), sB = __builtin_bit_cast(uint32_t, (u16x2)(minV - stu));
+        accA = (accA >> 1) | (sA & 0x80008000u);  // T - strength < 0  <=>  strength > T
+        accB = (accB >> 1) | (sB & 0x80008000u);
+      }
+      // valid bits of this lane: its column inside the cell, its rows inside the cell
+      const int avail = dhei - (it0 * 2 * ppi + rLane);  // rows from the lane's first upper pixel of the chunk to the cell's end
+      const int nU = min(max((avail + 2 * ppi - 1) >> ppi, 0), n), nL = min(max((avail + 2 * ppi - 2) >> ppi, 0), n);
+      const uint32_t sh = (uint32_t)(16 - n);
+      const uint32_t valid = colok ? ((((1u << nU) - 1u) << sh) | (((1u << nL) - 1u) << (sh + 16u))) : 0u;
+      accA &= valid;
+      WB[ck] = accB & valid & ~accA;
+      cjB[ck] = cj;
+      expand(accA, baseA, true, cj);
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the list stores are issued from inline assembly
-    const int nlA = (int)((baseA - listBase) >> 1), nlB = (int)((listBase + 2u * (uint32_t)(cap - 1) - baseB) >> 1);
+    const int nlA = (int)((baseA - listBase) >> 1);
+    int nlB = 0;
     __syncthreads();
     FAST_TICK(2)  // sweep
-      if (K.dbg == 4) { if (nlA + nlB == 123456) cand[0] = 1; return; }
+      if (K.dbg == 4) { if (nlA + (int)WB[0] == 123456) cand[0] = 1; return; }
     for (int pass = 0; pass < 2; pass++) {
       const int T = pass == 0 ? K.iniTh : K.minTh;
       // ---- scores, stored thresholded (below T = 0) so that the NMS compares raw bytes: pass 0 scores list A at
       //      iniThFAST, pass 1 (cells without a corner at iniThFAST) scores A again and B at minThFAST
+      if (pass == 1) {  // the cell is redone at minThFAST: now its B masks become the B list
+        expand(WB[0], baseB, false, cjB[0]);
+        if (nIt > 16) expand(WB[1], baseB, false, cjB[1]);
+        nlB = (int)((listBase + 2u * (uint32_t)(cap - 1) - baseB) >> 1);
+        __syncthreads();
+      }
       const int nl = pass == 0 ? nlA : nlA + nlB;  // pass 1 visits A then B
       for (int i = lane; i < nl; i += 64) {
         const int o = i < nlA ? s_list[i] : s_list[cap - nlB + (i - nlA)];
@@ -548,6 +577,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
   for (int cell = cFirst; cell < cEnd; cell++) {
     const bool haveNext = cell + 1 < cEnd;
     const Geo gn = geo(haveNext ? cell + 1 : cell);
+    if (timed) { if (gn.cw + gn.ch + gn.x0 + gn.y0 == 123456789) cand[0] = 1; }
+    FAST_TICK(12)  // loop back: barrier after the previous cell + decode of the next one
     if (g.ok) {
       stage(g);
       if (timed) { if (tile[lane] == 255 && sc[lane] == 7) cand[0] = 1; }  // forces the wait for the staged tile
@@ -567,8 +598,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
   }
   if (TIMED && timed && lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 10; i++) atomicAdd(&K.timers[i], t_acc[i]);
-    atomicAdd(&K.timers[10], t_mark - t_start);
+    for (int i = 0; i < 10; i++) atomicAdd(&K.timers[i], (unsigned long long)t_acc[i]);
+#pragma unroll
+    for (int i = 12; i < 16; i++) atomicAdd(&K.timers[i], (unsigned long long)t_acc[i]);
+    atomicAdd(&K.timers[10], (unsigned long long)(t_mark - t_start));
     atomicAdd(&K.timers[11], 1ull);
   }
 #undef FAST_TICK
