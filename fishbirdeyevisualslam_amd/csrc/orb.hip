@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
   const int b = blockIdx.y, lane = threadIdx.x;
   // FB_FAST_DBG=20: one workgroup in 16 accumulates its phase times in registers and adds them once, at the end
   const bool timed = TIMED && (blockIdx.x & 15) == 0;  // the TIMED instantiation is launched for FB_FAST_DBG=20 only
-  uint32_t t_mark = 0, t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // shader clock, low 32 bits
+  uint32_t t_mark = 0, t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // shader clock, low 32 bits
   if (timed) { __builtin_amdgcn_sched_barrier(0); t_mark = (uint32_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
   const uint32_t t_start = t_mark;
 #define FAST_TICK(slot_) if (TIMED && timed) { __builtin_amdgcn_sched_barrier(0); const uint32_t t_ = (uint32_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); t_acc[slot_] += t_ - t_mark; t_mark = t_; }
@@ -413,7 +413,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
         tile[yy * tp + xx] = img[(long long)(g.y0 + yy) * pitch + g.x0 + xx];
       }
     }
-    FAST_TICK(13)  // the tile has landed and is in LDS
     {  // score tile <- 0, 16 bytes per lane and store (the tile sizes are multiples of 16, the carve is 16-byte aligned)
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
       const u32x4 z = {0u, 0u, 0u, 0u};
@@ -474,7 +473,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
     int lo = off - tp3 - 3;
     const int nIt = __builtin_amdgcn_readfirstlane((dhei + 2 * ppi - 1) >> ppi);  // 2 * ppi = 1 << ppi rows per iteration
     uint32_t WB[2] = {0u, 0u};  // the minThFAST-only masks of the (at most two) chunks of 16 iterations
-    int cjB[2] = {0, 0};
     for (int it0 = 0, ck = 0; it0 < nIt; it0 += 16, ck++) {
       const int n = min(16, nIt - it0);
       uint32_t accA = 0u, accB = 0u;
@@ -506,7 +504,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
       const uint32_t valid = colok ? ((((1u << nU) - 1u) << sh) | (((1u << nL) - 1u) << (sh + 16u))) : 0u;
       accA &= valid;
       WB[ck] = accB & valid & ~accA;
-      cjB[ck] = cj;
       expand(accA, baseA, true, cj);
     }
     const int nlA = (int)((baseA - listBase) >> 1);
@@ -519,8 +516,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
       // ---- scores, stored thresholded (below T = 0) so that the NMS compares raw bytes: pass 0 scores list A at
       //      iniThFAST, pass 1 (cells without a corner at iniThFAST) scores A again and B at minThFAST
       if (pass == 1) {  // the cell is redone at minThFAST: now its B masks become the B list
-        expand(WB[0], baseB, false, cjB[0]);
-        if (nIt > 16) expand(WB[1], baseB, false, cjB[1]);
+        // tile offset of bit 0 of a chunk (as in the sweep): the lane's first tap + the centre - (16 - n) iterations
+        const int lo0 = off - tp3 - 3 + Cc;
+        expand(WB[0], baseB, false, lo0 - (16 - min(16, nIt)) * sstep);
+        if (nIt > 16) expand(WB[1], baseB, false, lo0 + 16 * sstep - (16 - min(16, nIt - 16)) * sstep);
         nlB = (int)((listBase + 2u * (uint32_t)(cap - 1) - baseB) >> 1);
         __syncthreads();
       }
@@ -564,6 +563,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
       // runs of a level.  (One returning atomic per cell on a per-level counter was a third of a wave's life time: the
       // ~900 cells of a level queue up on one address.)
       uint32_t *out = cand + (long long)b * K.candStride + Lv.candBase + (long long)cell * Lv.slotCap;
+#pragma unroll 1
       for (int i = lane; i < total; i += 64) out[i] = s_out[i];
       if (lane == 0) cellCount[(long long)b * K.totalCells + Lv.cellBase + cell] = total;
       if (pass == 0) { FAST_TICK(5) } else { FAST_TICK(8) }  // emission
@@ -577,8 +577,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
   for (int cell = cFirst; cell < cEnd; cell++) {
     const bool haveNext = cell + 1 < cEnd;
     const Geo gn = geo(haveNext ? cell + 1 : cell);
-    if (timed) { if (gn.cw + gn.ch + gn.x0 + gn.y0 == 123456789) cand[0] = 1; }
-    FAST_TICK(12)  // loop back: barrier after the previous cell + decode of the next one
     if (g.ok) {
       stage(g);
       if (timed) { if (tile[lane] == 255 && sc[lane] == 7) cand[0] = 1; }  // forces the wait for the staged tile
@@ -599,8 +597,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
   if (TIMED && timed && lane == 0) {
 #pragma unroll
     for (int i = 0; i < 10; i++) atomicAdd(&K.timers[i], (unsigned long long)t_acc[i]);
-#pragma unroll
-    for (int i = 12; i < 16; i++) atomicAdd(&K.timers[i], (unsigned long long)t_acc[i]);
     atomicAdd(&K.timers[10], (unsigned long long)(t_mark - t_start));
     atomicAdd(&K.timers[11], 1ull);
   }

@@ -15,7 +15,7 @@ L = fb.lib()
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for _ in range(3): pipe.extract(s)
 torch.cuda.synchronize()
-names = ["sc clear+barrier", "prefetch issue", "sweep", "score ini", "nms ini", "emit ini", "score min", "nms min", "emit min", "group decode", "", "", "loop+geo", "tile wait+write"]
+names = ["decode+tile wait+stage", "prefetch issue", "sweep", "score ini", "nms ini", "emit ini", "score min", "nms min", "emit min", "group decode"]
 for which, orb in (("front", pipe.orb_f), ("bird", pipe.orb_b)):
     t = (C.c_uint64 * 16)()
     fb.check(L.fb_orb_debug_timers(orb, t), "timers")   # reset
@@ -23,8 +23,8 @@ for which, orb in (("front", pipe.orb_f), ("bird", pipe.orb_b)):
     fb.check(L.fb_orb_debug_timers(orb, t), "timers")
     n = max(t[11], 1)
     print(which, "timed waves", t[11], "cycles/wave", round(t[10] / n))
-    for i in (9, 12, 13, 0, 1, 2, 3, 4, 5, 6, 7, 8):
-        print("   %-18s %8.0f cycles/wave  %5.1f %%" % (names[i], t[i] / n, 100.0 * t[i] / max(t[10], 1)))
+    for i in (9, 0, 1, 2, 3, 4, 5, 6, 7, 8):
+        print("   %-24s %8.0f cycles/wave  %5.1f %%" % (names[i], t[i] / n, 100.0 * t[i] / max(t[10], 1)))
 from fishbirdeyevisualslam_amd import cabi
 L.fb_prof_reset(); L.fb_prof_enable(1)
 for _ in range(5): pipe.extract(s)
