@@ -581,12 +581,12 @@ __device__ __forceinline__ fb::SE3 se3_mul_fast(const fb::SE3 &a, const fb::SE3 
   return r;
 }
 
-// (R, t): the pose of the evaluation as a rotation MATRIX (made once per evaluation): 9 multiply-adds per edge instead of the
-// ~24 operations of the quaternion rotation the decision arithmetic (and g2o's SE3Quat::map) uses
-__device__ __forceinline__ void front_edge_acc(const double (&R)[9], const double (&t)[3], float x0, float x1, float x2, float o0, float o1, double info,
+__device__ __forceinline__ void front_edge_acc(const fb::SE3 &T, float x0, float x1, float x2, float o0, float o1, double info,
                                                bool robust, double delta, double fx, double fy, double cx, double cy,
                                                double (&acc)[NACC]) {
-  const double p[3] = {R[0] * x0 + R[1] * x1 + R[2] * x2 + t[0], R[3] * x0 + R[4] * x1 + R[5] * x2 + t[1], R[6] * x0 + R[7] * x1 + R[8] * x2 + t[2]};
+  const double Xw[3] = {x0, x1, x2};
+  double p[3];
+  fb::se3_map(T, Xw, p);
   const double X = p[0], Y = p[1], invz = rcp_fast(p[2]), invz_2 = invz * invz;
   const double err[2] = {(double)o0 - ((X * invz) * fx + cx), (double)o1 - ((Y * invz) * fy + cy)};
   const double J[2][6] = {{X * Y * invz_2 * fx, -(1 + (X * X * invz_2)) * fx, Y * invz * fx, -invz * fx, 0, X * invz_2 * fx},
@@ -594,9 +594,11 @@ __device__ __forceinline__ void front_edge_acc(const double (&R)[9], const doubl
   accumulate_edge<2, (1u << 4) | (1u << 9)>(J, err, info, robust, delta, acc);
 }
 
-__device__ __forceinline__ void bird_edge_acc(const double (&R)[9], const double (&t)[3], float x0, float x1, float x2, float c0, float c1, float c2, double info,
+__device__ __forceinline__ void bird_edge_acc(const fb::SE3 &T, float x0, float x1, float x2, float c0, float c1, float c2, double info,
                                               bool robust, double delta, double (&acc)[NACC]) {
-  const double p[3] = {R[0] * x0 + R[1] * x1 + R[2] * x2 + t[0], R[3] * x0 + R[4] * x1 + R[5] * x2 + t[1], R[6] * x0 + R[7] * x1 + R[8] * x2 + t[2]};
+  const double Xw[3] = {x0, x1, x2};
+  double p[3];
+  fb::se3_map(T, Xw, p);
   const double err[3] = {(double)c0 - p[0], (double)c1 - p[1], (double)c2 - p[2]};
   accumulate_bird_edge(p, err, info, robust, delta, acc);
 }
@@ -764,18 +766,15 @@ __global__ __launch_bounds__(NT) void k_pose_opt_reg(fb_pose_opt_args A) {
     for (int i = 0; i < NACC; i++) acc[i] = 0;
     POSE_T0()
     POSE_COUNT(15)
-    double R[9];
-    fb::quat_to_R(T.r, R);
-    const double tt[3] = {T.t[0], T.t[1], T.t[2]};
 #pragma unroll
     for (int s = 0; s < EF; s++)
       if (((flev >> (2 * s)) & 3u) == 0u)
-        front_edge_acc(R, tt, fx0[s], fx1[s], fx2[s], fo0[s], fo1[s], (double)fin[s] * wf, robust, delta, fx, fy, cx, cy, acc);
+        front_edge_acc(T, fx0[s], fx1[s], fx2[s], fo0[s], fo1[s], (double)fin[s] * wf, robust, delta, fx, fy, cx, cy, acc);
     POSE_TICK(0)
 #pragma unroll
     for (int s = 0; s < EB; s++)
       if (((blev >> (2 * s)) & 3u) == 0u)
-        bird_edge_acc(R, tt, bx0[s], bx1[s], bx2[s], bc0[s], bc1[s], bc2[s], (double)bin[s] * wb, robust, delta, acc);
+        bird_edge_acc(T, bx0[s], bx1[s], bx2[s], bc0[s], bc1[s], bc2[s], (double)bin[s] * wb, robust, delta, acc);
     POSE_TICK(1)
 #pragma unroll
     for (int i = 0; i < NACC; i++) s_part[i * RS + tid] = acc[i];
