@@ -513,8 +513,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
       if (K.dbg == 4) { if (nlA + (int)WB[0] == 123456) cand[0] = 1; return; }
     for (int pass = 0; pass < 2; pass++) {
       const int T = pass == 0 ? K.iniTh : K.minTh;
-      // ---- scores, stored thresholded (below T = 0) so that the NMS compares raw bytes: pass 0 scores list A at
-      //      iniThFAST, pass 1 (cells without a corner at iniThFAST) scores A again and B at minThFAST
+      // ---- scores, stored RAW (the score does not depend on the threshold; clamped at 0): pass 0 scores list A, pass 1
+      //      (cells without a corner at iniThFAST) only list B.  The NMS asks "score >= T" of the centre only: a neighbour
+      //      below T loses against the centre whether it is stored raw or as the 0 cv::FAST keeps for non-corners, and
+      //      a pixel in neither list (score < minThFAST) holds 0
       if (pass == 1) {  // the cell is redone at minThFAST: now its B masks become the B list
         // tile offset of bit 0 of a chunk (as in the sweep): the lane's first tap + the centre - (16 - n) iterations
         const int lo0 = off - tp3 - 3 + Cc;
@@ -523,17 +525,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
         nlB = (int)((listBase + 2u * (uint32_t)(cap - 1) - baseB) >> 1);
         __syncthreads();
       }
-      const int nl = pass == 0 ? nlA : nlA + nlB;  // pass 1 visits A then B
-      for (int i = lane; i < nl; i += 64) {
+      const int nl = pass == 0 ? nlA : nlA + nlB;  // the NMS of pass 1 visits A then B
+      for (int i = (pass == 0 ? 0 : nlA) + lane; i < nl; i += 64) {
         const int o = i < nlA ? s_list[i] : s_list[cap - nlB + (i - nlA)];
-        const int scv = fast_score16(&tile[o], tp);
-        sc[o] = (uint8_t)(scv >= T ? scv : 0);
+        sc[o] = (uint8_t)max(fast_score16(&tile[o], tp), 0);
       }
+      const int Tk = max(T, 1);  // a corner has score >= T and score != 0
       __syncthreads();
       if (pass == 0) { FAST_TICK(3) } else { FAST_TICK(6) }  // score
       if (K.dbg == 2) { if (sc[lane] == 255) cand[0] = 1; return; }
       // ---- 3x3 strict non-max suppression over the candidate list (only listed pixels can hold a score >= T);
-      //      neighbours below T were stored as 0, the rim holds 0
+      //      the rim holds 0
       int total = 0;
       for (int base = 0; base < nl; base += 64) {
         const int i = base + lane;
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
           const int o = i < nlA ? s_list[i] : s_list[cap - nlB + (i - nlA)];
           const uint8_t *q = &sc[o];
           const int sv = q[0];
-          if (sv != 0) {
+          if (sv >= Tk) {
             const int mx = max(max(max(max((int)q[-1], (int)q[1]), (int)q[-tp - 1]), max((int)q[-tp], (int)q[-tp + 1])),
                                max(max((int)q[tp - 1], (int)q[tp]), (int)q[tp + 1]));
             keep = sv > mx;
