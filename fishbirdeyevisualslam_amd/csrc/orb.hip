@@ -369,7 +369,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
   struct Geo { int x0, y0, x1, y1, cw, ch, xa, ox, wpr; bool ok; };  // wave-uniform
   auto geo = [&](int cell) {
     Geo g;
-    const int ci = cell / Lv.nCols, cj = cell - ci * Lv.nCols;
+    // (the quotient comes out of the vector ALU; everything derived from it would stay there)
+    const int ci = __builtin_amdgcn_readfirstlane(cell / Lv.nCols), cj = cell - ci * Lv.nCols;
     g.x0 = BORDER + cj * Lv.wCell; g.y0 = BORDER + ci * Lv.hCell;
     g.x1 = min(g.x0 + Lv.wCell + 6, maxBX); g.y1 = min(g.y0 + Lv.hCell + 6, maxBY);
     g.cw = g.x1 - g.x0; g.ch = g.y1 - g.y0;
@@ -420,6 +421,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
     }
     __syncthreads();
   };
+  uint32_t validKept = 0u;  // the sweep's valid-pixel mask of the last cell size seen (process)
+  int validKey = -1;
   auto process = [&](const Geo &g, int cell) {
     const int x0 = g.x0, y0 = g.y0, cw = g.cw, ch = g.ch, ox = g.ox;
     if (K.dbg == 1) { if (tile[lane] == 255 && sc[lane] == 7) cand[0] = 1; return; }
@@ -470,17 +473,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
     };
     // all ten taps at non-negative constant distances from the lane's lowest tap (3 rows up, 3 columns left is the
     // corner of that box), so that every LDS read is base + immediate
-    int lo = off - tp3 - 3;
+    typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
+    const uint32_t tileAddr = (uint32_t)(uintptr_t)tile;
+    uint32_t lo = tileAddr + (uint32_t)(off - tp3 - 3);  // LDS byte address of the lane's lowest tap
     const int nIt = __builtin_amdgcn_readfirstlane((dhei + 2 * ppi - 1) >> ppi);  // 2 * ppi = 1 << ppi rows per iteration
     uint32_t WB[2] = {0u, 0u};  // the minThFAST-only masks of the (at most two) chunks of 16 iterations
     for (int it0 = 0, ck = 0; it0 < nIt; it0 += 16, ck++) {
-      const int n = min(16, nIt - it0);
+      const int n = __builtin_amdgcn_readfirstlane(min(16, nIt - it0));
       uint32_t accA = 0u, accB = 0u;
-      const int cj = lo + Cc - (16 - n) * sstep;  // tile offset of bit 0
-      for (int j = 0; j < n; j++, lo += sstep) {
+      const int cj = (int)(lo - tileAddr) + Cc - (16 - n) * sstep;  // tile offset of bit 0
+      for (int j = 0; j < n; j++, lo += (uint32_t)sstep) {
         // rows beyond the cell read inside the LDS tile + score tile; their bits are masked below
         asm volatile("" : "+v"(lo));
-        const uint8_t *c = &tile[lo];
+        lds_cu8 *c = reinterpret_cast<lds_cu8 *>((uintptr_t)lo);
         const uint32_t b0 = c[Cc], b1 = c[Cc + TP], b2 = c[Cc + 3 * TP], b3 = c[Cc + 4 * TP], b4 = c[Cc - 3 * TP], b5 = c[Cc - 2 * TP];
         const uint32_t b6 = c[Cc + 3], b7 = c[Cc + TP + 3], b8 = c[Cc - 3], b9 = c[Cc + TP - 3];
         __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);  // the ten LDS reads back to back, then the arithmetic
@@ -497,11 +502,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
         accA = (accA >> 1) | (sA & 0x80008000u);  // T - strength < 0  <=>  strength > T
         accB = (accB >> 1) | (sB & 0x80008000u);
       }
-      // valid bits of this lane: its column inside the cell, its rows inside the cell
-      const int avail = dhei - (it0 * 2 * ppi + rLane);  // rows from the lane's first upper pixel of the chunk to the cell's end
-      const int nU = min(max((avail + 2 * ppi - 1) >> ppi, 0), n), nL = min(max((avail + 2 * ppi - 2) >> ppi, 0), n);
-      const uint32_t sh = (uint32_t)(16 - n);
-      const uint32_t valid = colok ? ((((1u << nU) - 1u) << sh) | (((1u << nL) - 1u) << (sh + 16u))) : 0u;
+      // valid bits of this lane: its column inside the cell, its rows inside the cell (kept from the previous cell of the
+      // wave when that had the same size, i.e. nearly always)
+      uint32_t valid;
+      const int key = (dwid << 8) | dhei;
+      if (it0 == 0 && key == validKey) {
+        valid = validKept;
+      } else {
+        const int avail = dhei - (it0 * 2 * ppi + rLane);  // rows from the lane's first upper pixel of the chunk to the cell's end
+        const int nU = min(max((avail + 2 * ppi - 1) >> ppi, 0), n), nL = min(max((avail + 2 * ppi - 2) >> ppi, 0), n);
+        const uint32_t sh = (uint32_t)(16 - n);
+        valid = colok ? ((((1u << nU) - 1u) << sh) | (((1u << nL) - 1u) << (sh + 16u))) : 0u;
+        if (it0 == 0) { validKept = valid; validKey = key; }
+      }
       accA &= valid;
       WB[ck] = accB & valid & ~accA;
       expand(accA, baseA, true, cj);
