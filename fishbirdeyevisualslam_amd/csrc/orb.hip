@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
 // 256 columns x BLUR_ROWS rows: a lane filters 4 adjacent pixels and walks down the rows with the last seven
 // horizontal results in registers.  Horizontal pass = 2 x v_dot4_u32_u8 per pixel on a 12-byte window.
 // ------------------------------------------------------------------------------------------
-constexpr int BLUR_ROWS = 16;
+constexpr int BLUR_ROWS = 32;
 
 __device__ __forceinline__ int reflect101(int i, int n) {
   if (i < 0) i = -i;
@@ -1016,8 +1016,13 @@ __global__ __launch_bounds__(256) void k_blur(OrbK K, const uint8_t *__restrict_
       for (int k = 0; k < 4; k++) {
         const int c0 = ring[(r + 1) % 7][k], c1 = ring[(r + 2) % 7][k], c2 = ring[(r + 3) % 7][k], c3 = ring[(r + 4) % 7][k];
         const int c4 = ring[(r + 5) % 7][k], c5 = ring[(r + 6) % 7][k], c6 = ring[r % 7][k];
-        const int sum = __mul24(18, c0 + c6) + __mul24(34, c1 + c5) + __mul24(49, c2 + c4) + __mul24(55, c3);
-        packed |= (uint32_t)min((sum + (1 << 15)) >> 16, 255) << (8 * k);
+        // one multiply + three multiply-adds (v_mad_i32_i24); written as a chain so that the sums are not regrouped
+        int sum;
+        asm("v_mad_i32_i24 %0, %1, 55, %2" : "=v"(sum) : "v"(c3), "v"(1 << 15));
+        asm("v_mad_i32_i24 %0, %1, 49, %0" : "+v"(sum) : "v"(c2 + c4));
+        asm("v_mad_i32_i24 %0, %1, 34, %0" : "+v"(sum) : "v"(c1 + c5));
+        asm("v_mad_i32_i24 %0, %1, 18, %0" : "+v"(sum) : "v"(c0 + c6));
+        packed |= (uint32_t)min(sum >> 16, 255) << (8 * k);
       }
       *reinterpret_cast<uint32_t *>(out + (uint32_t)(__mul24(yo, L.pitch) + x0)) = packed;
     }
