@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src0
 // constants (window offset, byte offsets, packed weights) live in registers for the whole walk; per source row the
 // lane fetches one 12-byte window (3 dword loads) and does the horizontal pass with v_alignbyte + v_perm + v_dot2;
 // a source row shared by two successive destination rows (4 of 5 at scale 1.2) is filtered once.
-constexpr int RESIZE_ROWS = 4;
+constexpr int RESIZE_ROWS = 8;
 
 __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t *__restrict__ src0, long long srcImgStride, int sw,
                                                      int sh, int spitch, uint8_t *__restrict__ dst0,
@@ -160,40 +160,46 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t *__restrict__
   const int dxf = min(dx4, dw - 1);
   const int a = tb.xofs[dxf] & ~3;
   const int aw = min(a, spitch - 12);  // keep the 12-byte window inside the row (only the zero-padded tail moves)
-  bool useHi[4];                       // the two taps lie in window dwords 1..2 (else 0..1)
-  uint32_t selw[4];                    // v_perm selector: tap0 -> bits 0..7, tap1 -> bits 16..23 of that dword pair
+  // The taps of the lane's 4 pixels lie within 8 bytes of the first tap (scale <= 2): two v_alignbyte bring those 8
+  // bytes to a fixed place, one v_perm per pixel spreads its two taps for v_dot2.
+  uint32_t selw[4];                    // v_perm selector: tap0 -> bits 0..7, tap1 -> bits 16..23 of the shifted pair
   uint32_t wgt[4];                     // a0 | a1 << 16
-  bool live[4];
+  uint32_t liveMask = 0;               // bytes of the packed result that are destination pixels
+  const int o0 = tb.xofs[dxf] - aw;    // byte offset of the first tap inside the 12-byte window, 0..10
+  const uint32_t sh0 = (uint32_t)o0 & 3u;
+  const int q0 = o0 >> 2;              // 0, except in the clamped window of the row's tail
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int dx = dx4 + k;
-    live[k] = dx < dw;
+    if (dx < dw) liveMask |= 0xffu << (8 * k);
     const int dxc = min(dx, dw - 1);
     const int sx = tb.xofs[dxc];
     int a0 = tb.ialpha[dxc * 2], a1 = tb.ialpha[dxc * 2 + 1];
     if (sx + 1 > sw - 1) { a0 += a1; a1 = 0; }  // right border: both taps read sx
-    const int o = sx - aw;             // byte offset of tap0 inside the 12-byte window, 0..10
-    useHi[k] = o >= 7;
-    const uint32_t ob = (uint32_t)(useHi[k] ? o - 4 : o);  // 0..6 inside the chosen 8 bytes
+    const uint32_t ob = (uint32_t)(sx - aw - o0);  // 0..6
     selw[k] = ob | (0x0cu << 8) | ((ob + 1u) << 16) | (0x0cu << 24);
     wgt[k] = (uint32_t)(a0 & 0xffff) | ((uint32_t)a1 << 16);
   }
+  const bool anyTail = __ballot(q0 != 0) != 0ull;  // wave-uniform
+  const uint32_t mq1 = q0 == 1 ? ~0u : 0u, mq2 = q0 >= 2 ? ~0u : 0u, mq12 = mq1 | mq2;
   auto loadWin = [&](int sy, uint32_t (&wv)[3]) {
     sy = sy >= 0 ? (sy < sh ? sy : sh - 1) : 0;
     const uint32_t *p = reinterpret_cast<const uint32_t *>(src + ((uint32_t)__mul24(sy, spitch) + (uint32_t)aw));
     wv[0] = p[0]; wv[1] = p[1]; wv[2] = p[2];
   };
   auto hpass = [&](const uint32_t (&wv)[3], int h[4]) {
-    const uint32_t w0 = wv[0], w1 = wv[1], w2 = wv[2];
+    uint32_t x0 = wv[0], x1 = wv[1], x2 = wv[2];
+    if (anyTail) {  // the first tap sits in dword q0 of the window (bit selects: no divergent branches)
+      x0 = (wv[0] & ~mq12) | (wv[1] & mq1) | (wv[2] & mq2);
+      x1 = (wv[1] & ~mq12) | (wv[2] & mq12);
+    }
+    const uint32_t e0 = __builtin_amdgcn_alignbyte(x1, x0, sh0), e1 = __builtin_amdgcn_alignbyte(x2, x1, sh0);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const uint32_t lo = useHi[k] ? w1 : w0, hi = useHi[k] ? w2 : w1;
-      const uint32_t spread = __builtin_amdgcn_perm(hi, lo, selw[k]);  // tap0 | tap1 << 16
-      typedef short short2_t __attribute__((ext_vector_type(2)));
-      union { uint32_t u; short2_t s; } A, B;
-      A.u = spread;
-      B.u = wgt[k];
-      h[k] = __builtin_amdgcn_sdot2(A.s, B.s, 0, false) >> 4;
+      const uint32_t spread = __builtin_amdgcn_perm(e1, e0, selw[k]);  // tap0 | tap1 << 16
+      int d;
+      asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(spread), "v"(wgt[k]));
+      h[k] = d >> 4;
     }
   };
   int h0[4], h1[4];
@@ -229,11 +235,11 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t *__restrict__
     uint32_t packed = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      int v = ((__mul24(b0, h0[k]) >> 16) + (__mul24(b1, h1[k]) >> 16) + 2) >> 2;  // |b| <= 2048, h < 2^15
-      v = min(max(v, 0), 255);
-      packed |= (live[k] ? (uint32_t)v : 0u) << (8 * k);
+      // |b| <= 2048, h <= 255 * 2048 >> 4, b0 + b1 = 2048, no negative weight: 0 <= v <= 255 without a clamp
+      const int v = ((__mul24(b0, h0[k]) >> 16) + (__mul24(b1, h1[k]) >> 16) + 2) >> 2;
+      packed |= (uint32_t)v << (8 * k);
     }
-    *reinterpret_cast<uint32_t *>(dst + (long long)dy * dpitch + dx4) = packed;
+    *reinterpret_cast<uint32_t *>(dst + (long long)dy * dpitch + dx4) = packed & liveMask;
   }
 }
 
