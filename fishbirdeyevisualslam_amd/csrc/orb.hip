@@ -1399,7 +1399,11 @@ int prepare(fb_orb *o, int w, int h, int batch) {
         ibeta[dy * 2 + 1] = (short)fb_cvround(fy * 2048.f);
       }
       bool ok = true;
-      for (int dx4 = 0; dx4 < dwd; dx4 += 4) ok = ok && (xofs[std::min(dx4 + 3, dwd - 1)] + 1 - (xofs[dx4] & ~3)) <= 11;
+      // the taps of a 4-pixel group: inside the 12-byte window, and within 8 bytes of the group's first tap (scale <= 2)
+      for (int dx4 = 0; dx4 < dwd; dx4 += 4) {
+        const int last = xofs[std::min(dx4 + 3, dwd - 1)] + 1;
+        ok = ok && (last - (xofs[dx4] & ~3)) <= 11 && (last - xofs[dx4]) <= 7;
+      }
       o->rowsOK[l] = ok;
       tabOff[l * 4 + 0] = append(xofs.data(), xofs.size() * 4);
       tabOff[l * 4 + 1] = append(ialpha.data(), ialpha.size() * 2);
