@@ -1065,14 +1065,6 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(OrbK K, const uint8_
                                                  int32_t *__restrict__ nOut) {
   __shared__ __attribute__((aligned(16))) uint32_t rawp_all[DESC_WPB][DP_RAW_ROWS * DP_RAW_DW + 4];
   __shared__ __attribute__((aligned(16))) uint32_t blp_all[DESC_WPB][DP_BL_ROWS * DP_BL_DW + 2];
-  // The sampling pattern (4 KB) and the orientation tables (2 KB) live in LDS, not in 24 registers per lane for the whole
-  // kernel: the kernel is bound by the latency of its scattered loads, and 58 instead of 82 VGPRs is 8 instead of 5 waves
-  // per SIMD with their patch loads in flight.
-  __shared__ float4 s_pat[256];
-  __shared__ uint4 s_ang[124];
-  s_pat[threadIdx.x] = reinterpret_cast<const float4 *>(c_pattern)[threadIdx.x];
-  if (threadIdx.x < 124) s_ang[threadIdx.x] = angTab[threadIdx.x];
-  __syncthreads();  // the only workgroup barrier (before any wave can leave)
   const int b = blockIdx.y, lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t *rawp = rawp_all[wv], *blp = blp_all[wv];
@@ -1099,7 +1091,11 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(OrbK K, const uint8_
       if (l < K.nlevels && ki >= lstart[l]) { kl = l; adj = K.L[l].outBase - lstart[l]; }
     recv = lvlOut[(long long)b * K.outStride + adj + ki];
   }
-  if (K.dbg == 11) { if ((int)(s_pat[lane].x) + (int)s_ang[lane].x + (int)recv == 1234567) nOut[0] = 1; return; }
+  float4 pp[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) pp[t] = reinterpret_cast<const float4 *>(c_pattern)[lane * 4 + t];
+  const uint4 angW = angTab[(lane < 62 ? lane : 0) * 2], angK = angTab[(lane < 62 ? lane : 0) * 2 + 1];
+  if (K.dbg == 11) { if ((int)(pp[0].x + pp[1].y + pp[2].z + pp[3].w) + (int)angW.x + (int)angK.y + (int)recv == 1234567) nOut[0] = 1; return; }
   // fixed lane -> (row within a group, dword) mapping: 6 rows x 10 dwords (7 x 9 for the raw patch) per pass, so the
   // global offsets and the LDS indices are constants per lane (32-bit offsets from wave-uniform bases, 24-bit
   // multiplies: 64/32-bit integer multiplies are quarter rate)
@@ -1197,7 +1193,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(OrbK K, const uint8_
       const uint32_t d0 = rowd[0], d1 = rowd[1], d2 = rowd[2], d3 = rowd[3], d4 = rowd[4];
       const uint32_t q0 = __builtin_amdgcn_alignbyte(d1, d0, sh), q1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
       const uint32_t q2 = __builtin_amdgcn_alignbyte(d3, d2, sh), q3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
-      const uint4 W = s_ang[lane * 2], Km = s_ang[lane * 2 + 1];
+      const uint4 W = angW, Km = angK;
       const uint32_t a10 = __builtin_amdgcn_udot4(q0, W.x, __builtin_amdgcn_udot4(q1, W.y, __builtin_amdgcn_udot4(q2, W.z, __builtin_amdgcn_udot4(q3, W.w, 0u, false), false), false), false);
       const uint32_t rs = __builtin_amdgcn_udot4(q0, Km.x, __builtin_amdgcn_udot4(q1, Km.y, __builtin_amdgcn_udot4(q2, Km.z, __builtin_amdgcn_udot4(q3, Km.w, 0u, false), false), false), false);
       m10 = half ? (int)a10 : -(int)a10;
@@ -1205,7 +1201,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(OrbK K, const uint8_
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
-    if (K.dbg == 12) { if (m10 + m01 == 12345678 && (int)(s_pat[lane].x) == 77777) nOut[0] = 1; continue; }
+    if (K.dbg == 12) { if (m10 + m01 == 12345678 && (int)(pp[0].x + pp[1].y + pp[2].z + pp[3].w) == 77777) nOut[0] = 1; continue; }
     const float angle = fb_fast_atan2((float)m01, (float)m10);
     // computeOrbDescriptor (ORBextractor.cc:107-147): lane computes tests 4*lane .. 4*lane+3
     const float factorPI = 0x1.1df46ap-6f;
@@ -1216,8 +1212,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(OrbK K, const uint8_
     int nib = 0;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      const float4 pt = s_pat[lane * 4 + t];
-      const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
+      const float x0 = pp[t].x, y0 = pp[t].y, x1 = pp[t].z, y1 = pp[t].w;
       const int t0 = centre[__mul24(fb_cvround(x0 * bb + y0 * a), DP_BL_DW * 4) + fb_cvround(x0 * a - y0 * bb)];
       const int t1 = centre[__mul24(fb_cvround(x1 * bb + y1 * a), DP_BL_DW * 4) + fb_cvround(x1 * a - y1 * bb)];
       nib |= (t0 < t1) << t;
