@@ -373,10 +373,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
   constexpr int NIT1 = (40 + RPI - 1) / RPI, NIT2 = (FAST_MAX_TILE + RPI - 1) / RPI - NIT1;  // usual windows: <= 40 rows
   const int r0 = lane / DW, dwc = lane - r0 * DW;
   struct Geo { int x0, y0, x1, y1, cw, ch, xa, ox, wpr; bool ok; };  // wave-uniform
-  auto geo = [&](int cell) {
+  auto geo = [&](int ci, int cj) {  // cell (row ci, column cj) of the level
     Geo g;
-    // (the quotient comes out of the vector ALU; everything derived from it would stay there)
-    const int ci = __builtin_amdgcn_readfirstlane(cell / Lv.nCols), cj = cell - ci * Lv.nCols;
     g.x0 = BORDER + cj * Lv.wCell; g.y0 = BORDER + ci * Lv.hCell;
     g.x1 = min(g.x0 + Lv.wCell + 6, maxBX); g.y1 = min(g.y0 + Lv.hCell + 6, maxBY);
     g.cw = g.x1 - g.x0; g.ch = g.y1 - g.y0;
@@ -391,9 +389,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
     if (r0 < RPI && dwc < g.wpr) {
       const uint8_t *src = img + (long long)g.y0 * pitch + g.xa;  // wave-uniform base + 32-bit lane offsets
       const uint32_t lo = (uint32_t)dwc * 4u;
+      int r0v = r0;
+      asm volatile("" : "+v"(r0v));  // keeps the NIT1 row numbers from being hoisted out of the cell loop into NIT1 registers
 #pragma unroll
       for (int it = 0; it < NIT1; it++)
-        v[it] = *reinterpret_cast<const uint32_t *>(src + ((uint32_t)__mul24(min(r0 + it * RPI, g.ch - 1), pitch) + lo));
+        v[it] = *reinterpret_cast<const uint32_t *>(src + ((uint32_t)__mul24(min(r0v + it * RPI, g.ch - 1), pitch) + lo));
     }
   };
   auto stage = [&](const Geo &g) {  // registers (+ the rows of a tall window) -> LDS tile, score tile cleared
@@ -401,8 +401,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
       if (r0 < RPI && dwc < g.wpr) {
         uint32_t *dst = reinterpret_cast<uint32_t *>(&tile[dwc * 4]);
 #pragma unroll
-        for (int it = 0; it < NIT1; it++)
-          if (r0 + it * RPI < g.ch) dst[(r0 + it * RPI) * DW] = v[it];
+        for (int it = 0; it < NIT1; it++) dst[(r0 + it * RPI) * DW] = v[it];  // rows >= ch: copies of the last row, masked later
+        // (NIT1 * RPI rows always fit tile + score tile -- the host sizes fastTileBytes for it -- and the score tile is cleared
+        // below, after these writes; unconditional stores also let the compiler count the loads it has consumed)
         if (g.ch > NIT1 * RPI) {  // tall cells of small levels
           const uint8_t *src = img + (long long)g.y0 * pitch + g.xa;
           const uint32_t lo = (uint32_t)dwc * 4u;
@@ -423,7 +424,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
     {  // score tile <- 0, 16 bytes per lane and store (the tile sizes are multiples of 16, the carve is 16-byte aligned)
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
       const u32x4 z = {0u, 0u, 0u, 0u};
-      for (int i = lane; i < (tp * g.ch + 15) / 16; i += 64) reinterpret_cast<u32x4 *>(sc)[i] = z;
+      const int n16 = (tp * g.ch + 15) / 16;
+      if (lane < n16) reinterpret_cast<u32x4 *>(sc)[lane] = z;  // the usual 44 x <= 46 bytes: two stores, no loop
+      if (lane + 64 < n16) reinterpret_cast<u32x4 *>(sc)[lane + 64] = z;
+      if (n16 > 128)
+        for (int i = lane + 128; i < n16; i += 64) reinterpret_cast<u32x4 *>(sc)[i] = z;
     }
     __syncthreads();
   };
@@ -591,13 +596,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
       break;
     }
   };
-  Geo g = geo(cFirst);
+  // the one division of the wave (its quotient comes out of the vector ALU: readfirstlane keeps what follows scalar)
+  int ci = __builtin_amdgcn_readfirstlane(cFirst / Lv.nCols), cj = cFirst - ci * Lv.nCols;
+  Geo g = geo(ci, cj);
   if (timed) { if (g.cw + g.ch + g.x0 + g.y0 == 123456789) cand[0] = 1; }  // forces the kernel-argument loads to have landed
   FAST_TICK(9)  // group decode (scalar loads of the level tables)
   if (g.ok && aligned) issue(g);
   for (int cell = cFirst; cell < cEnd; cell++) {
     const bool haveNext = cell + 1 < cEnd;
-    const Geo gn = geo(haveNext ? cell + 1 : cell);
+    if (haveNext) { cj++; if (cj == Lv.nCols) { cj = 0; ci++; } }
+    const Geo gn = geo(ci, cj);
     if (g.ok) {
       stage(g);
       if (timed) { if (tile[lane] == 255 && sc[lane] == 7) cand[0] = 1; }  // forces the wait for the staged tile
@@ -1436,6 +1444,7 @@ int prepare(fb_orb *o, int w, int h, int batch) {
     }
     K.fastTP = tpNeed <= 44 ? 44 : tpNeed <= 56 ? 56 : FAST_MAX_TILE;
     K.fastTileBytes = (std::max(K.fastTP * tileB, 4 * ((maxOut + 3) & ~3)) + 15) & ~15;
+    K.fastTileBytes = std::max(K.fastTileBytes, (21 * K.fastTP + 15) & ~15);  // k_fast stages 40 / 42 rows unconditionally into tile + score tile
     K.fastMaxOut = (maxOut + 3) & ~3;
     K.fastMaxPix = (maxPix + 7) & ~7;
   }
