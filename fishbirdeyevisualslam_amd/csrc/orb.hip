@@ -247,7 +247,12 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t *__restrict__
 // FAST-9-16 score = max over the 16 arcs of 9 of min(d) (and of min(-d)), minus 1
 // (cv::cornerScore<16>); the pixel is a corner at threshold t iff score >= t.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int fast_score16(const uint8_t *__restrict__ c, int tp) {
+// `corner` points 3 rows above and 3 columns left of the pixel: every tap is corner + a non-negative constant, i.e. one LDS
+// read with an immediate offset (taps at negative offsets from the pixel cost a vector add each).
+template <int TP>
+__device__ __forceinline__ int fast_score16(const uint8_t *__restrict__ corner) {
+  constexpr int tp = TP;
+  const uint8_t *c = corner + 3 * tp + 3;
   const int v = c[0];
   int d[16];
   d[0] = v - c[3 * tp];      d[1] = v - c[3 * tp + 1];   d[2] = v - c[2 * tp + 2];   d[3] = v - c[tp + 3];
@@ -552,7 +557,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
       const int nl = pass == 0 ? nlA : nlA + nlB;  // the NMS of pass 1 visits A then B
       for (int i = (pass == 0 ? 0 : nlA) + lane; i < nl; i += 64) {
         const int o = i < nlA ? s_list[i] : s_list[cap - nlB + (i - nlA)];
-        sc[o] = (uint8_t)max(fast_score16(&tile[o], tp), 0);
+        int oc = o - 3 * TP - 3;
+        asm volatile("" : "+v"(oc));  // keeps the compiler from re-basing the taps on the pixel
+        sc[o] = (uint8_t)max(fast_score16<TP>(&tile[oc]), 0);
       }
       const int Tk = max(T, 1);  // a corner has score >= T and score != 0
       __syncthreads();
@@ -567,7 +574,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
         uint32_t rec = 0;
         if (i < nl) {
           const int o = i < nlA ? s_list[i] : s_list[cap - nlB + (i - nlA)];
-          const uint8_t *q = &sc[o];
+          int oq = o - TP - 1;  // the upper left neighbour: all nine reads at immediate offsets
+          asm volatile("" : "+v"(oq));
+          const uint8_t *q = &sc[oq] + TP + 1;
           const int sv = q[0];
           if (sv >= Tk) {
             const int mx = max(max(max(max((int)q[-1], (int)q[1]), (int)q[-tp - 1]), max((int)q[-tp], (int)q[-tp + 1])),
