@@ -481,7 +481,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
       while (W != 0u) {  // one listed pixel per lane and trip
         const int bpos = __builtin_ctz(W);
         W &= W - 1u;
-        const int offp = cj + (bpos & 15) * sstep + (bpos >> 4) * tp;
+        // bit p of the low half = iteration p (rows advance by sstep), high half = the lower pixel of the pair (+ tp):
+        // cj + (p & 15) * sstep + (p >> 4) * tp as two multiply-adds
+        int offp;  // (in assembly: the compiler turns the 24-bit products into quarter-rate 32-bit multiplies here)
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(offp) : "v"(bpos), "v"(sstep), "v"(cj));
+        asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(offp) : "v"(bpos >> 4), "s"(__builtin_amdgcn_readfirstlane(tp - 16 * sstep)));
         *reinterpret_cast<lds_u16 *>((uintptr_t)a) = (unsigned short)offp;
         a = up ? a + 2u : a - 2u;
       }
