@@ -463,7 +463,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
     const int G = two ? 32 : 64, ppi = two ? 2 : 1;
     const int sxx = lane & (G - 1);
     const bool hiHalf = two && lane >= 32, colok = sxx < dwid;
-    const int tp3 = 3 * tp, sstep = 2 * ppi * tp;
+    const int tp3 = 3 * tp, sstep = __builtin_amdgcn_readfirstlane(2 * ppi * tp);  // scalar: products with it stay off the quarter-rate 32-bit vector multiply
     const int rLane = hiHalf ? 2 : 0;                        // first row of the lane
     const int off = (3 + rLane) * tp + ox + 3 + sxx;         // its upper pixel
     const uint32_t listBase = (uint32_t)(uintptr_t)s_list;  // LDS byte address
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
         // bit p of the low half = iteration p (rows advance by sstep), high half = the lower pixel of the pair (+ tp):
         // cj + (p & 15) * sstep + (p >> 4) * tp as two multiply-adds
         int offp;  // (in assembly: the compiler turns the 24-bit products into quarter-rate 32-bit multiplies here)
-        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(offp) : "v"(bpos), "v"(sstep), "v"(cj));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(offp) : "v"(bpos), "s"(sstep), "v"(cj));
         asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(offp) : "v"(bpos >> 4), "s"(__builtin_amdgcn_readfirstlane(tp - 16 * sstep)));
         *reinterpret_cast<lds_u16 *>((uintptr_t)a) = (unsigned short)offp;
         a = up ? a + 2u : a - 2u;
