@@ -1006,7 +1006,10 @@ __global__ __launch_bounds__(256) void k_blur(OrbK K, const uint8_t *__restrict_
   }
   const bool anyEdge = __ballot(edge) != 0ull;
   const uint32_t WA = 18u | (34u << 8) | (49u << 16) | (55u << 24), WB = 49u | (34u << 8) | (18u << 16);
-  int ring[7][4];
+  // vertical pass: the horizontal sums are 16-bit (<= 255 * 256), so two successive rows of a pixel share a register and
+  // v_dot2_u32_u16 takes two taps at once: pairs[r % 6][k] = row r-1 | row r << 16 of pixel k
+  uint32_t pairs[6][4];
+  uint32_t prevh[4] = {0u, 0u, 0u, 0u};
   // The source rows run BLUR_PF rows ahead of the arithmetic: a load -> wait -> use per row would serialise one memory
   // latency per row (22 per wave).  Row indices past the image are reflected, so every prefetch address is valid.
   constexpr int BLUR_PF = 4;
@@ -1031,28 +1034,29 @@ __global__ __launch_bounds__(256) void k_blur(OrbK K, const uint8_t *__restrict_
       const uint32_t e2 = __builtin_amdgcn_perm(w1, w0, m1[2]) | __builtin_amdgcn_perm(w2, w2, m2[2]);
       if (edge) { w0 = e0; w1 = e1; w2 = e2; }
     }
-    int *hr = ring[r % 7];
+    uint32_t hr[4];
     // taps of pixel j are window bytes 1+j .. 7+j
     hr[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), WB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), WA, 0u, false), false);
     hr[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), WB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), WA, 0u, false), false);
     hr[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), WB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), WA, 0u, false), false);
     hr[3] = __builtin_amdgcn_udot4(w2, WB, __builtin_amdgcn_udot4(w1, WA, 0u, false), false);
     if (r >= 6) {
+      typedef unsigned short u16x2b __attribute__((ext_vector_type(2)));
+      const u16x2b W01 = {18, 34}, W23 = {49, 55}, W45 = {49, 34};
       uint32_t packed = 0;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const int c0 = ring[(r + 1) % 7][k], c1 = ring[(r + 2) % 7][k], c2 = ring[(r + 3) % 7][k], c3 = ring[(r + 4) % 7][k];
-        const int c4 = ring[(r + 5) % 7][k], c5 = ring[(r + 6) % 7][k], c6 = ring[r % 7][k];
-        // one multiply + three multiply-adds (v_mad_i32_i24); written as a chain so that the sums are not regrouped
-        int sum;
-        asm("v_mad_i32_i24 %0, %1, 55, %2" : "=v"(sum) : "v"(c3), "v"(1 << 15));
-        asm("v_mad_i32_i24 %0, %1, 49, %0" : "+v"(sum) : "v"(c2 + c4));
-        asm("v_mad_i32_i24 %0, %1, 34, %0" : "+v"(sum) : "v"(c1 + c5));
-        asm("v_mad_i32_i24 %0, %1, 18, %0" : "+v"(sum) : "v"(c0 + c6));
-        packed |= (uint32_t)min(sum >> 16, 255) << (8 * k);
+        // rows r-6 .. r with weights 18 34 49 55 49 34 18: three two-tap dots on the row pairs + the new row
+        uint32_t sum = (uint32_t)__mul24(18, (int)hr[k]) + (1u << 15);
+        sum = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2b, pairs[(r + 1) % 6][k]), W01, sum, false);  // rows r-6, r-5
+        sum = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2b, pairs[(r + 3) % 6][k]), W23, sum, false);  // rows r-4, r-3
+        sum = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2b, pairs[(r + 5) % 6][k]), W45, sum, false);  // rows r-2, r-1
+        packed |= (uint32_t)min((int)(sum >> 16), 255) << (8 * k);
       }
       *reinterpret_cast<uint32_t *>(out + (uint32_t)(__mul24(yo, L.pitch) + x0)) = packed;
     }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { pairs[r % 6][k] = prevh[k] | (hr[k] << 16); prevh[k] = hr[k]; }
   }
 }
 
