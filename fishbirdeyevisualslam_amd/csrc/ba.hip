@@ -49,7 +49,7 @@ struct BADev {  // device pointers + sizes, passed by value
   const int *e_pt, *e_kf;      // [nE]
   const uint8_t *e_type;       // [nE]
   const int *e_pj;             // [nE] poseIdx[e_kf[e]] (one dependent load less on the landmark-centric paths)
-  const double *e_meas;        // [nE][3]
+  const float *e_meas;         // [nE][3] (the measurements arrive as floats: kept so, half the staging bytes)
   const double *e_info;        // [nE]
   uint8_t *e_level;            // [nE]
   double *e_chi2;              // [nE] chi2 of the last evaluation that covered the edge
@@ -1676,7 +1676,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   auto reserve = [&](size_t bytes) { const size_t off = stageBytes; stageBytes += (bytes + 255) & ~(size_t)255; return off; };
   const int nE1 = std::max(nE, 1), nO1 = std::max(nO, 1);
   const size_t o_poseIdx = reserve((size_t)n_kf * 4), o_ept = reserve((size_t)nE1 * 4), o_ekf = reserve((size_t)nE1 * 4),
-               o_epj = reserve((size_t)nE1 * 4), o_etype = reserve(nE1), o_elevel = reserve(nE1), o_emeas = reserve((size_t)nE1 * 24),
+               o_epj = reserve((size_t)nE1 * 4), o_etype = reserve(nE1), o_elevel = reserve(nE1), o_emeas = reserve((size_t)nE1 * 12),
                o_einfo = reserve((size_t)nE1 * 8), o_lms = reserve((size_t)(npt + 1) * 4), o_lme = reserve((size_t)nE1 * 4),
                o_pss = reserve((size_t)(np + 1) * 4), o_pse = reserve((size_t)nE1 * 4), o_oi = reserve((size_t)nO1 * 4),
                o_oj = reserve((size_t)nO1 * 4), o_oz = reserve((size_t)nO1 * sizeof(SE3)), o_oinfo = reserve((size_t)nO1 * 8),
@@ -1690,7 +1690,8 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
       *ps_start = reinterpret_cast<int *>(hs + o_pss), *ps_edges = reinterpret_cast<int *>(hs + o_pse), *o_i = reinterpret_cast<int *>(hs + o_oi),
       *o_j = reinterpret_cast<int *>(hs + o_oj), *od_start = reinterpret_cast<int *>(hs + o_ods), *od_edges = reinterpret_cast<int *>(hs + o_ode);
   uint8_t *e_type = hs + o_etype, *e_level = hs + o_elevel;
-  double *e_meas = reinterpret_cast<double *>(hs + o_emeas), *e_info = reinterpret_cast<double *>(hs + o_einfo), *o_info = reinterpret_cast<double *>(hs + o_oinfo);
+  float *e_meas = reinterpret_cast<float *>(hs + o_emeas);
+  double *e_info = reinterpret_cast<double *>(hs + o_einfo), *o_info = reinterpret_cast<double *>(hs + o_oinfo);
   SE3 *oZinv = reinterpret_cast<SE3 *>(hs + o_oz), *poses = reinterpret_cast<SE3 *>(hs + o_poses);
   double *pts = reinterpret_cast<double *>(hs + o_pts);
   memcpy(h_poseIdx, poseIdx.data(), (size_t)n_kf * 4);
@@ -1700,11 +1701,21 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   for (int l = 0; l <= npt; l++) lm_start[l] = 0;
   for (int k = 0; k <= np; k++) ps_start[k] = 0;
   const double wFd = (double)A->wF, wBd = (double)A->wB;
+  // Observations usually arrive grouped by point (the reference walks its local map points): then the CSR by landmark is
+  // the edge order itself and the duplicate check (a key frame sees a point at most once) rides in this pass.
+  static thread_local std::vector<int> seen;
+  seen.assign(n_kf, -1);
+  bool grouped = true, dup = false;
+  int prevPt = -1;
   for (int i = 0; i < nF; i++) {
     const int pt = A->obs_mp[i], kf = A->obs_kf[i];
     FB_ARG(pt >= 0 && pt < n_mp && kf >= 0 && kf < n_kf);
+    grouped = grouped && pt >= prevPt;
+    prevPt = pt;
+    dup = dup || seen[kf] == pt;
+    seen[kf] = pt;
     e_pt[i] = pt; e_kf[i] = kf; e_type[i] = T_PROJ;
-    e_meas[3 * i] = A->obs_uv[2 * i]; e_meas[3 * i + 1] = A->obs_uv[2 * i + 1]; e_meas[3 * i + 2] = 0.0;
+    e_meas[3 * i] = A->obs_uv[2 * i]; e_meas[3 * i + 1] = A->obs_uv[2 * i + 1]; e_meas[3 * i + 2] = 0.0f;
     e_info[i] = odom ? (1.0 * (double)A->obs_inv_sigma2[i]) * wFd : (double)A->obs_inv_sigma2[i];
     e_level[i] = (sharded && pt % world != rank) ? 2 : 0;  // 2 = not this rank's landmark
     const int pj = poseIdx[kf];
@@ -1715,6 +1726,10 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   for (int i = 0; i < nB; i++) {
     FB_ARG(A->bobs_mpb[i] >= 0 && A->bobs_mpb[i] < A->n_mpb && A->bobs_kf[i] >= 0 && A->bobs_kf[i] < n_kf);
     const int e = nF + i, pt = n_mp + A->bobs_mpb[i], kf = A->bobs_kf[i];
+    grouped = grouped && pt >= prevPt;
+    prevPt = pt;
+    dup = dup || seen[kf] == pt;
+    seen[kf] = pt;
     e_pt[e] = pt; e_kf[e] = kf; e_type[e] = T_XYZ;
     for (int k = 0; k < 3; k++) e_meas[3 * e + k] = A->bobs_xc[3 * i + k];
     e_info[e] = (1.0 * (double)A->bobs_inv_sigma2[i]) * wBd;
@@ -1727,21 +1742,30 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   for (int l = 0; l < npt; l++) lm_start[l + 1] += lm_start[l];
   for (int k = 0; k < np; k++) ps_start[k + 1] += ps_start[k];
   {
-    static thread_local std::vector<int> fillL, fillP, seen;
-    fillL.assign(lm_start, lm_start + npt);
+    static thread_local std::vector<int> fillL, fillP;
     fillP.assign(ps_start, ps_start + np);
-    for (int e = 0; e < nE; e++) {
-      lm_edges[fillL[e_pt[e]]++] = e;
-      if (e_pj[e] >= 0) ps_edges[fillP[e_pj[e]]++] = e;
-    }
-    // a keyframe observes a point at most once (map<KeyFrame*,size_t>): stamp per key frame = last landmark seen
-    seen.assign(n_kf, -1);
-    for (int l = 0; l < npt; l++)
-      for (int c = lm_start[l]; c < lm_start[l + 1]; c++) {
-        int &sk = seen[e_kf[lm_edges[c]]];
-        if (sk == l) { fb::set_error("fb_local_ba: duplicate (keyframe, point) observation"); return FB_ERR_ARG; }
-        sk = l;
+    if (grouped) {
+      for (int e = 0; e < nE; e++) {
+        lm_edges[e] = e;
+        if (e_pj[e] >= 0) ps_edges[fillP[e_pj[e]]++] = e;
       }
+    } else {
+      fillL.assign(lm_start, lm_start + npt);
+      for (int e = 0; e < nE; e++) {
+        lm_edges[fillL[e_pt[e]]++] = e;
+        if (e_pj[e] >= 0) ps_edges[fillP[e_pj[e]]++] = e;
+      }
+      // a keyframe observes a point at most once (map<KeyFrame*,size_t>): stamp per key frame = last landmark seen
+      dup = false;
+      seen.assign(n_kf, -1);
+      for (int l = 0; l < npt && !dup; l++)
+        for (int c = lm_start[l]; c < lm_start[l + 1]; c++) {
+          int &sk = seen[e_kf[lm_edges[c]]];
+          dup = dup || sk == l;
+          sk = l;
+        }
+    }
+    if (dup) { fb::set_error("fb_local_ba: duplicate (keyframe, point) observation"); return FB_ERR_ARG; }
   }
   for (int k = 0; k < n_kf; k++) poses[k] = fb::se3_from_float12(A->kf_Tcw + 12 * k);
   for (int i = 0; i < 3 * n_mp; i++) pts[i] = A->mp_xw[i];
@@ -1797,7 +1821,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   D.fx = A->fx; D.fy = A->fy; D.cx = A->cx; D.cy = A->cy; D.delta = sc.delta;
   D.e_pj = reinterpret_cast<int *>(ds + o_epj);
   D.poseIdx = reinterpret_cast<int *>(ds + o_poseIdx); D.e_pt = reinterpret_cast<int *>(ds + o_ept); D.e_kf = reinterpret_cast<int *>(ds + o_ekf);
-  D.e_type = ds + o_etype; D.e_meas = reinterpret_cast<double *>(ds + o_emeas); D.e_info = reinterpret_cast<double *>(ds + o_einfo);
+  D.e_type = ds + o_etype; D.e_meas = reinterpret_cast<float *>(ds + o_emeas); D.e_info = reinterpret_cast<double *>(ds + o_einfo);
   D.e_level = ds + o_elevel; D.e_chi2 = reinterpret_cast<double *>(dc + c_echi2);
   D.lm_start = reinterpret_cast<int *>(ds + o_lms); D.lm_edges = reinterpret_cast<int *>(ds + o_lme);
   D.ps_start = reinterpret_cast<int *>(ds + o_pss); D.ps_edges = reinterpret_cast<int *>(ds + o_pse);

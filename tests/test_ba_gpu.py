@@ -87,6 +87,27 @@ def test_local_ba_rejects_duplicate_observation():
         H.call("fb_local_ba", a)
 
 
+def test_local_ba_observations_in_any_order():
+    """The host side has a fast path for observations grouped by point (the order the reference produces); shuffled
+    observations take the general CSR build: same result as the oracle, and a duplicate is still refused there."""
+    import fishbirdeyevisualslam_amd as fb
+    p = synth.make_ba_problem(4006, n_kf=6, n_mp=400, n_mpb=80)
+    g = np.random.default_rng(7)
+    pf, pb = g.permutation(len(p["obs_kf"])), g.permutation(len(p["bobs_kf"]))
+    for k in ("obs_kf", "obs_mp", "obs_uv", "obs_inv_sigma2"):
+        p[k] = np.ascontiguousarray(p[k][pf])
+    for k in ("bobs_kf", "bobs_mpb", "bobs_xc", "bobs_inv_sigma2"):
+        p[k] = np.ascontiguousarray(p[k][pb])
+    out_o, out_h, _, _ = _run(p, with_odom=1)
+    _compare(p, out_o, out_h, 1)
+    q = dict(p)
+    q["obs_kf"] = p["obs_kf"].copy(); q["obs_mp"] = p["obs_mp"].copy()
+    q["obs_kf"][-1] = q["obs_kf"][0]; q["obs_mp"][-1] = q["obs_mp"][0]
+    a, out, keep = ba_problem.local_ba_args(q, with_odom=1)
+    with pytest.raises(fb.FishbirdError):
+        H.call("fb_local_ba", a)
+
+
 def test_local_ba_structure_only_and_no_bird():
     """Edge cases of the device-resident schedule: every key frame fixed (no pose system at all: structure-only BA), and a
     graph without bird points / odometry edges."""
