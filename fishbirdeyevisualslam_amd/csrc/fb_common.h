@@ -103,14 +103,25 @@ struct DevBuf {
 // every step (16 + 8 + 4 + 2 + 1 + 1 = 32 fp64 exchanges instead of 6 per value).  On return v[0] of lane L is the sum
 // over all lanes of column L >> 1.  (28 accumulators through plain butterflies were most of an LM evaluation: 168
 // dependent cross-lane exchanges per wave.)
+// c ? a : b on the two halves of a double, in assembly: written as a C++ select between two array elements the compiler
+// turns the pair into ONE load with a computed index, which forces the whole array out of registers into scratch memory
+__device__ __forceinline__ double select_f64(bool c, double a, double b) {
+  const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+  unsigned lo, hi;
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(lo) : "v"((unsigned)ub), "v"((unsigned)ua), "s"(m));
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hi) : "v"((unsigned)(ub >> 32)), "v"((unsigned)(ua >> 32)), "s"(m));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ double wave_column_sums32(double (&v)[32], int lane) {
 #pragma unroll
   for (int half = 16, m = 32; half >= 1; half >>= 1, m >>= 1) {
     const bool up = (lane & m) != 0;
 #pragma unroll
     for (int i = 0; i < half; i++) {
-      const double send = up ? v[i] : v[i + half];
-      const double keep = up ? v[i + half] : v[i];
+      const double send = select_f64(up, v[i], v[i + half]);
+      const double keep = select_f64(up, v[i + half], v[i]);
       v[i] = keep + __shfl_xor(send, m, 64);
     }
   }

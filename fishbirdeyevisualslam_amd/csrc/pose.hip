@@ -18,6 +18,7 @@
 // iteration when the step is accepted, so an LM iteration costs one pass per trial.  The 6x6
 // LDL^T, the exponential-map update and the lambda schedule run on lane 0.  Everything is fp64
 // like g2o; inputs/outputs are float like the reference's cv::Mat fields.
+#include <type_traits>
 #include "fb_common.h"
 #include "fb_se3.h"
 
@@ -40,7 +41,7 @@ __device__ unsigned long long g_pose_stamps[16];
 #endif
 
 struct PoseLds {  // fixed-size shared state
-  fb::SE3 T, Ttrial, Teval;
+  fb::SE3 T, Ttrial, Teval, T0;
   double H[36], b[6], x[6];
   double red[NACC];
   double part[8][NACC];  // per-wave partial sums (up to 512 threads)
@@ -768,13 +769,21 @@ __global__ __launch_bounds__(NT) void k_pose_opt_reg(fb_pose_opt_args A) {
     POSE_COUNT(15)
 #pragma unroll
     for (int s = 0; s < EF; s++)
-      if (((flev >> (2 * s)) & 3u) == 0u)
-        front_edge_acc(T, fx0[s], fx1[s], fx2[s], fo0[s], fo1[s], (double)fin[s] * wf, robust, delta, fx, fy, cx, cy, acc);
+      if (((flev >> (2 * s)) & 3u) == 0u) {
+        // (opaque copies: otherwise the float -> double conversions and the weight product of every edge are hoisted out of
+        // the LM loop and held in registers -- three times the registers of the floats themselves, i.e. spills)
+        float a0 = fx0[s], a1 = fx1[s], a2 = fx2[s], a3 = fo0[s], a4 = fo1[s], a5 = fin[s];
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5));
+        front_edge_acc(T, a0, a1, a2, a3, a4, (double)a5 * wf, robust, delta, fx, fy, cx, cy, acc);
+      }
     POSE_TICK(0)
 #pragma unroll
     for (int s = 0; s < EB; s++)
-      if (((blev >> (2 * s)) & 3u) == 0u)
-        bird_edge_acc(T, bx0[s], bx1[s], bx2[s], bc0[s], bc1[s], bc2[s], (double)bin[s] * wb, robust, delta, acc);
+      if (((blev >> (2 * s)) & 3u) == 0u) {
+        float a0 = bx0[s], a1 = bx1[s], a2 = bx2[s], a3 = bc0[s], a4 = bc1[s], a5 = bc2[s], a6 = bin[s];
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6));
+        bird_edge_acc(T, a0, a1, a2, a3, a4, a5, (double)a6 * wb, robust, delta, acc);
+      }
     POSE_TICK(1)
 #pragma unroll
     for (int i = 0; i < NACC; i++) s_part[i * RS + tid] = acc[i];
@@ -880,7 +889,9 @@ __global__ __launch_bounds__(NT) void k_pose_opt_reg(fb_pose_opt_args A) {
     for (int s = 0; s < EF; s++) {
       if (((flev >> (2 * s)) & 3u) == 2u) continue;
       const bool wasOut = (fout >> s) & 1u;
-      const float chi2 = (float)chi2_front_vals(fx0[s], fx1[s], fx2[s], fo0[s], fo1[s], (double)fin[s] * wf, wasOut ? T : Teval, fx, fy, cx, cy);
+      float a0 = fx0[s], a1 = fx1[s], a2 = fx2[s], a3 = fo0[s], a4 = fo1[s], a5 = fin[s];
+      asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5));
+      const float chi2 = (float)chi2_front_vals(a0, a1, a2, a3, a4, (double)a5 * wf, wasOut ? T : Teval, fx, fy, cx, cy);
       bool isBad;
       if (mode == FB_POSE_FRONT) isBad = chi2 > chi2Mono;
       else isBad = chi2 > chi2Mono * ((double)A.wF + 1e-9);
@@ -893,7 +904,9 @@ __global__ __launch_bounds__(NT) void k_pose_opt_reg(fb_pose_opt_args A) {
     for (int s = 0; s < EB; s++) {
       if (((blev >> (2 * s)) & 3u) == 2u) continue;
       const bool wasOut = (bout >> s) & 1u;
-      const float chi2 = (float)chi2_bird_vals(bx0[s], bx1[s], bx2[s], bc0[s], bc1[s], bc2[s], (double)bin[s] * wb, wasOut ? T : Teval);
+      float a0 = bx0[s], a1 = bx1[s], a2 = bx2[s], a3 = bc0[s], a4 = bc1[s], a5 = bc2[s], a6 = bin[s];
+      asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6));
+      const float chi2 = (float)chi2_bird_vals(a0, a1, a2, a3, a4, a5, (double)a6 * wb, wasOut ? T : Teval);
       const float chi2Bad = (float)(chi2Bird * ((double)A.wB + 1e-9));
       const bool isBad = chi2 > chi2Bad;
       A.bird_outlier[bo + bidx_[s]] = isBad ? 1 : 0;
@@ -959,6 +972,299 @@ __global__ void k_gather_bird(int kp_stride, int mp_stride, const int32_t *__res
   valid[o] = 1;
 }
 
+// ------------------------------------------------------------------------------------------
+// k_pose_opt_split -- k_pose_opt_reg with the serial part of an LM step on a wave of its own.  In k_pose_opt_reg the 6x6
+// solve and the exponential map run on lane 0 of a wave that also carries edges: the registers of the solve come on top of
+// the edge registers and ~117 of them spill (704 B of scratch per lane, reloaded in every evaluation).  Here waves
+// 0 .. NWE-1 carry the edges and the last wave does nothing but the solve: the two roles are two instantiations of one
+// generic lambda, so each is register-allocated on its own (no edge register is live in the solver's code and vice versa)
+// and they meet at the same barriers.  Same arithmetic, same order of every sum as k_pose_opt_reg.
+// ------------------------------------------------------------------------------------------
+template <int NT, int EF, int EB>
+__global__ __launch_bounds__(NT) void k_pose_opt_split(fb_pose_opt_args A) {
+  constexpr int NE = NT - 64;    // edge threads
+  constexpr int NWE = NE / 64, NWR = NT / 64;
+  constexpr int CPA = NE / NACC; // threads that share one accumulator in the column sums: NACC * CPA = NE, each adds NE / CPA values
+  static_assert(CPA == 16 && NACC * CPA == NE, "the column sums are laid out for 448 edge threads");
+  constexpr int RS = NE + CPA;   // row stride in doubles (2 * RS mod 64 = 2 * CPA: the CPA-wide windows fall into disjoint banks)
+  extern __shared__ __attribute__((aligned(16))) double s_part[];  // [NACC][RS]
+  __shared__ PoseLds S;
+  __shared__ int s_cnt[2];
+  __shared__ int s_wcnt[2][NWR];
+  const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int mode = A.mode;
+  const size_t fo = (size_t)bidx * A.front_stride, bo = (size_t)bidx * A.bird_stride;
+  const int nfs = (mode != FB_POSE_BIRD) ? A.n_front[bidx] : 0;
+  const int nbs = (mode != FB_POSE_FRONT) ? A.n_bird[bidx] : 0;
+  float *Tcw = A.Tcw + (size_t)bidx * 12;
+  // ---- edge construction (Optimizer.cc:525-602): the slots with an edge are compacted in slot order (all NWR waves scan)
+  unsigned short *s_idxF = reinterpret_cast<unsigned short *>(s_part);   // [EF * NE]
+  unsigned short *s_idxB = s_idxF + EF * NE;                             // [EB * NE]
+  const int perF = (((nfs + NWR - 1) / NWR) + 63) & ~63, perB = (((nbs + NWR - 1) / NWR) + 63) & ~63;
+  {
+    int cf = 0, cb = 0;
+    for (int i = wv * perF + lane; i < min((wv + 1) * perF, nfs); i += 64) cf += (!A.front_valid || A.front_valid[fo + i]) ? 1 : 0;
+    for (int i = wv * perB + lane; i < min((wv + 1) * perB, nbs); i += 64) cb += (!A.bird_valid || A.bird_valid[bo + i]) ? 1 : 0;
+    cf = (int)wave_sum((double)cf); cb = (int)wave_sum((double)cb);
+    if (lane == 0) { s_wcnt[0][wv] = cf; s_wcnt[1][wv] = cb; }
+  }
+  __syncthreads();
+  int nf = 0, nb = 0, baseF = 0, baseB = 0;
+#pragma unroll
+  for (int w = 0; w < NWR; w++) {
+    if (w < wv) { baseF += s_wcnt[0][w]; baseB += s_wcnt[1][w]; }
+    nf += s_wcnt[0][w]; nb += s_wcnt[1][w];
+  }
+  if (nf > EF * NE || nb > EB * NE || A.front_stride > 65535 || A.bird_stride > 65535) {
+    // more edges than register slots: the generic schedule, edges read from HBM / L2 (the level bytes take the LDS)
+    __syncthreads();
+    pose_generic<NT>(A, 0, reinterpret_cast<uint8_t *>(s_part), S, s_cnt);
+    return;
+  }
+  if (mode == FB_POSE_BIRD ? nb < 3 : nf < 3) {  // Optimizer.cc:379,607,776
+    for (int i = tid; i < nfs; i += NT)
+      if (!A.front_valid || A.front_valid[fo + i]) A.front_outlier[fo + i] = 0;
+    if (tid == 0) A.ninliers[bidx] = 0;
+    return;
+  }
+  for (int i0 = wv * perF; i0 < min((wv + 1) * perF, nfs); i0 += 64) {
+    const int i = i0 + lane;
+    const bool v = i < min((wv + 1) * perF, nfs) && (!A.front_valid || A.front_valid[fo + i]);
+    const unsigned long long m = __ballot(v);
+    if (v) s_idxF[baseF + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (unsigned short)i;
+    baseF += __popcll(m);
+  }
+  for (int i0 = wv * perB; i0 < min((wv + 1) * perB, nbs); i0 += 64) {
+    const int i = i0 + lane;
+    const bool v = i < min((wv + 1) * perB, nbs) && (!A.bird_valid || A.bird_valid[bo + i]);
+    const unsigned long long m = __ballot(v);
+    if (v) s_idxB[baseB + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (unsigned short)i;
+    baseB += __popcll(m);
+  }
+  if (tid == NE) {
+    S.T = fb::se3_from_float12(Tcw);
+    S.Teval = S.T;
+    S.T0 = S.T;
+  }
+  __syncthreads();
+
+  auto role = [&](auto edgeRole) {
+    constexpr bool EDGE = decltype(edgeRole)::value;
+    // this thread's edges -> registers (edge waves only): edge with rank r = s * NE + tid.  level 0 = active, 1 = outlier level,
+    // 2 = no edge (two bits per slot); fidx / bidx_ = the frame slot the edge came from (where its outlier flag lives)
+    float fx0[EF], fx1[EF], fx2[EF], fo0[EF], fo1[EF], fin[EF];
+    float bx0[EB], bx1[EB], bx2[EB], bc0[EB], bc1[EB], bc2[EB], bin[EB];
+    int fidx[EF], bidx_[EB];
+    unsigned flev = 0, blev = 0, fout = 0, bout = 0;
+    if constexpr (EDGE) {
+#pragma unroll
+      for (int s = 0; s < EF; s++) {
+        const int r = s * NE + tid;
+        const bool v = r < nf;
+        fx0[s] = fx1[s] = fx2[s] = fo0[s] = fo1[s] = fin[s] = 0.f;
+        fidx[s] = 0;
+        if (v) {
+          const int e = s_idxF[r];
+          fidx[s] = e;
+          const float *X = A.front_xw + (fo + e) * 3, *O = A.front_obs + (fo + e) * 2;
+          fx0[s] = X[0]; fx1[s] = X[1]; fx2[s] = X[2]; fo0[s] = O[0]; fo1[s] = O[1];
+          fin[s] = A.front_inv_sigma2[fo + e];
+          A.front_outlier[fo + e] = 0;
+        }
+        flev |= (v ? 0u : 2u) << (2 * s);
+      }
+#pragma unroll
+      for (int s = 0; s < EB; s++) {
+        const int r = s * NE + tid;
+        const bool v = r < nb;
+        bx0[s] = bx1[s] = bx2[s] = bc0[s] = bc1[s] = bc2[s] = bin[s] = 0.f;
+        bidx_[s] = 0;
+        if (v) {
+          const int e = s_idxB[r];
+          bidx_[s] = e;
+          const float *X = A.bird_xw + (bo + e) * 3, *Cc = A.bird_xc + (bo + e) * 3;
+          bx0[s] = X[0]; bx1[s] = X[1]; bx2[s] = X[2]; bc0[s] = Cc[0]; bc1[s] = Cc[1]; bc2[s] = Cc[2];
+          bin[s] = A.bird_inv_sigma2[bo + e];
+          if (A.bird_outlier[bo + e]) bout |= 1u << s;  // the incoming mvBirdOutlier decides which chi2 the first round recomputes
+        }
+        blev |= (v ? 0u : 2u) << (2 * s);
+      }
+    }
+    __syncthreads();  // s_idx lives in the buffer the evaluations overwrite
+    const double wf = (mode == FB_POSE_FRONT) ? 1.0 : (double)A.wF, wb = (double)A.wB;
+    const double fx = A.fx, fy = A.fy, cx = A.cx, cy = A.cy;
+    const double delta = (double)(float)sqrt(5.991);
+    const float chi2Mono = (mode == FB_POSE_FRONT) ? 5.991f : 1.5f;
+    const float chi2Bird = 5.991f;
+
+    // one evaluation at pose *Tp: robust chi2 + H + b over this thread's active edges, then the 28 column sums -> S.red
+    // (the solver wave only keeps the two barriers)
+    auto eval = [&](const fb::SE3 *Tp, bool robust) {
+      if constexpr (EDGE) {
+        const fb::SE3 T = *Tp;
+        double acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; i++) acc[i] = 0;
+#pragma unroll
+        for (int s = 0; s < EF; s++)
+          if (((flev >> (2 * s)) & 3u) == 0u) {
+            // (opaque copies: otherwise the float -> double conversions and the weight product of every edge are hoisted out
+            // of the LM loop and held in registers -- three times the registers of the floats themselves)
+            float a0 = fx0[s], a1 = fx1[s], a2 = fx2[s], a3 = fo0[s], a4 = fo1[s], a5 = fin[s];
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5));
+            front_edge_acc(T, a0, a1, a2, a3, a4, (double)a5 * wf, robust, delta, fx, fy, cx, cy, acc);
+          }
+#pragma unroll
+        for (int s = 0; s < EB; s++)
+          if (((blev >> (2 * s)) & 3u) == 0u) {
+            float a0 = bx0[s], a1 = bx1[s], a2 = bx2[s], a3 = bc0[s], a4 = bc1[s], a5 = bc2[s], a6 = bin[s];
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6));
+            bird_edge_acc(T, a0, a1, a2, a3, a4, a5, (double)a6 * wb, robust, delta, acc);
+          }
+#pragma unroll
+        for (int i = 0; i < NACC; i++) s_part[i * RS + tid] = acc[i];
+      }
+      __syncthreads();
+      if constexpr (EDGE) {
+        const int a = tid / CPA, c = tid - a * CPA;  // NACC * CPA = NE: every edge thread sums one window
+        const double *row = s_part + a * RS + c;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for (int k = 0; k < NE / CPA; k += 4) {
+          s0 += row[(k + 0) * CPA]; s1 += row[(k + 1) * CPA]; s2 += row[(k + 2) * CPA]; s3 += row[(k + 3) * CPA];
+        }
+        double v = (s0 + s1) + (s2 + s3);
+        v += dpp_f64<0x118>(v);  // row_shr:8: the CPA partial sums of accumulator a sit in the 16 lanes of one DPP row
+        v += dpp_f64<0x114>(v);  // row_shr:4
+        v += dpp_f64<0x112>(v);  // row_shr:2
+        v += dpp_f64<0x111>(v);  // row_shr:1
+        if (c == CPA - 1) S.red[a] = v;
+      }
+      __syncthreads();
+    };
+
+    int nBad = 0, nBadBird = 0;
+    for (int it = 0; it < 4; it++) {
+      const bool robust = it < 3;
+      if (!EDGE && tid == NE) S.T = S.T0;
+      bool mine = false;
+      if constexpr (EDGE) {
+#pragma unroll
+        for (int s = 0; s < EF; s++) mine |= ((flev >> (2 * s)) & 3u) == 0u;
+#pragma unroll
+        for (int s = 0; s < EB; s++) mine |= ((blev >> (2 * s)) & 3u) == 0u;
+      }
+      const int nact = __syncthreads_count(mine);  // also publishes S.T
+      if (nact > 0) {
+        eval(&S.T, robust);
+        if (!EDGE && tid == NE) { unpack_system(S.red, S.H, S.b); S.Teval = S.T; }
+        double currentChi = S.red[0];
+        __syncthreads();
+        double lambda = 0, ni = 2;
+        int nBadLM = 0;
+        for (int iter = 0; iter < 10; iter++) {
+          const double iniChi = currentChi;
+          if (iter == 0) {
+            double m = 0;
+            for (int j = 0; j < 6; j++) m = fmax(fabs(S.H[j * 6 + j]), m);
+            lambda = 1e-5 * m;
+            ni = 2;
+            nBadLM = 0;
+          }
+          double rho = 0;
+          int qmax = 0;
+          do {
+            if (!EDGE && tid == NE) {
+              S.ok2 = ldlt6_fast(S.H, lambda, S.b, S.x) ? 1 : 0;
+              S.Ttrial = se3_mul_fast(se3_exp_direct(S.x), S.T);  // oplus
+              S.Teval = S.Ttrial;
+            }
+            __syncthreads();
+            eval(&S.Ttrial, robust);
+            double tempChi = S.red[0];
+            if (!S.ok2) tempChi = 1.7976931348623157e308;
+            rho = currentChi - tempChi;
+            double scale = 0;
+            for (int j = 0; j < 6; j++) scale += S.x[j] * (lambda * S.x[j] + S.b[j]);
+            scale += 1e-3;
+            rho /= scale;
+            const bool accept = rho > 0 && isfinite(tempChi);
+            __syncthreads();  // everyone has read red/x/b
+            if (accept) {
+              double alpha = 1. - pow((2 * rho - 1), 3);
+              alpha = fmin(alpha, 2. / 3.);
+              const double scaleFactor = fmax(1. / 3., alpha);
+              lambda *= scaleFactor;
+              ni = 2;
+              currentChi = tempChi;
+              if (!EDGE && tid == NE) { S.T = S.Ttrial; unpack_system(S.red, S.H, S.b); }
+            } else {
+              lambda *= ni;
+              ni *= 2;
+            }
+            __syncthreads();
+            qmax++;
+          } while (rho < 0 && qmax < 10);
+          if (qmax == 10 || rho == 0) break;
+          if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++;
+          else nBadLM = 0;
+          if (nBadLM >= 3) break;
+        }
+      }
+      // ---- classify (Optimizer.cc:396-431, 627-686, 791-822)
+      int bad = 0, badb = 0;
+      if constexpr (EDGE) {
+        const fb::SE3 T = S.T, Teval = S.Teval;
+#pragma unroll
+        for (int s = 0; s < EF; s++) {
+          if (((flev >> (2 * s)) & 3u) == 2u) continue;
+          const bool wasOut = (fout >> s) & 1u;
+          float a0 = fx0[s], a1 = fx1[s], a2 = fx2[s], a3 = fo0[s], a4 = fo1[s], a5 = fin[s];
+          asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5));
+          const float chi2 = (float)chi2_front_vals(a0, a1, a2, a3, a4, (double)a5 * wf, wasOut ? T : Teval, fx, fy, cx, cy);
+          bool isBad;
+          if (mode == FB_POSE_FRONT) isBad = chi2 > chi2Mono;
+          else isBad = chi2 > chi2Mono * ((double)A.wF + 1e-9);
+          A.front_outlier[fo + fidx[s]] = isBad ? 1 : 0;
+          flev = (flev & ~(3u << (2 * s))) | ((isBad ? 1u : 0u) << (2 * s));
+          fout = (fout & ~(1u << s)) | ((isBad ? 1u : 0u) << s);
+          bad += isBad;
+        }
+#pragma unroll
+        for (int s = 0; s < EB; s++) {
+          if (((blev >> (2 * s)) & 3u) == 2u) continue;
+          const bool wasOut = (bout >> s) & 1u;
+          float a0 = bx0[s], a1 = bx1[s], a2 = bx2[s], a3 = bc0[s], a4 = bc1[s], a5 = bc2[s], a6 = bin[s];
+          asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6));
+          const float chi2 = (float)chi2_bird_vals(a0, a1, a2, a3, a4, a5, (double)a6 * wb, wasOut ? T : Teval);
+          const float chi2Bad = (float)(chi2Bird * ((double)A.wB + 1e-9));
+          const bool isBad = chi2 > chi2Bad;
+          A.bird_outlier[bo + bidx_[s]] = isBad ? 1 : 0;
+          blev = (blev & ~(3u << (2 * s))) | ((isBad ? 1u : 0u) << (2 * s));
+          bout = (bout & ~(1u << s)) | ((isBad ? 1u : 0u) << s);
+          badb += isBad;
+        }
+        const double sb = wave_sum((double)bad), sbb = wave_sum((double)badb);
+        if ((tid & 63) == 0) { S.part[0][tid >> 6] = sb; S.part[1][tid >> 6] = sbb; }
+      }
+      __syncthreads();
+      {
+        double tb = 0, tbb = 0;
+        for (int w2 = 0; w2 < NWE; w2++) { tb += S.part[0][w2]; tbb += S.part[1][w2]; }
+        nBad = (int)tb; nBadBird = (int)tbb;
+      }
+      __syncthreads();
+      if (nf + nb < 10) break;  // optimizer.edges().size()<10
+    }
+    if (!EDGE && tid == NE) {
+      fb::se3_to_float12(S.T, Tcw);
+      A.ninliers[bidx] = (mode == FB_POSE_BIRD) ? nb - nBadBird : nf - nBad;
+    }
+  };
+  if (wv < NWE) role(std::true_type{});
+  else role(std::false_type{});
+}
+
 }  // namespace
 
 extern "C" {
@@ -974,15 +1280,19 @@ int fb_pose_opt_batch_dev(const fb_pose_opt_args *A, void *stream) {
   if (A->mode != FB_POSE_FRONT)
     FB_ARG(A->n_bird && A->bird_outlier && (A->bird_stride == 0 || (A->bird_xw && A->bird_xc && A->bird_inv_sigma2)));
   if (A->batch == 0) return FB_OK;
-  // register-resident kernel (k_pose_opt_reg) whenever its in-kernel way out (level bytes of every slot in LDS) fits;
-  // FB_POSE_NT=256 / 0 selects the one-wave-per-SIMD variant / the LDS-staged kernel (measurements only)
-  static const int regNT = [] { const char *e = getenv("FB_POSE_NT"); const int v = e ? atoi(e) : 512; return v == 256 || v == 512 ? v : 0; }();
+  // register-resident kernel whenever its in-kernel way out (level bytes of every slot in LDS) fits: by default
+  // k_pose_opt_split (448 edge threads + a solver wave; 120 B of scratch per lane); FB_POSE_NT=512 / 256 / 0 selects
+  // k_pose_opt_reg with 512 threads / with one wave per SIMD / the LDS-staged kernel (measurements only)
+  static const int regNT = [] { const char *e = getenv("FB_POSE_NT"); const int v = e ? atoi(e) : 448; return v == 256 || v == 512 || v == 448 ? v : 0; }();
   if (regNT) {
-    const size_t lds = (size_t)NACC * (regNT + regNT / 32) * sizeof(double);
+    const size_t lds = regNT == 448 ? (size_t)NACC * (448 + 16) * sizeof(double) : (size_t)NACC * (regNT + regNT / 32) * sizeof(double);
     const size_t flagBytes = ((size_t)((A->front_stride + 15) & ~15)) + ((A->bird_stride + 15) & ~15);
     if (flagBytes <= lds && A->front_stride <= 65535 && A->bird_stride <= 65535) {
       fb::ProfScope prof_(fb::P_POSE, fb::as_stream(stream));
-      if (regNT == 512) {
+      if (regNT == 448) {  // 448 edge threads + the solver wave
+        FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pose_opt_split<512, 5, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_pose_opt_split<512, 5, 3><<<A->batch, 512, lds, fb::as_stream(stream)>>>(*A);
+      } else if (regNT == 512) {
         FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pose_opt_reg<512, 5, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_pose_opt_reg<512, 5, 3><<<A->batch, 512, lds, fb::as_stream(stream)>>>(*A);
       } else {
