@@ -411,13 +411,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
         // below, after these writes; unconditional stores also let the compiler count the loads it has consumed)
         if (g.ch > NIT1 * RPI) {  // tall cells of small levels
           const uint8_t *src = img + (long long)g.y0 * pitch + g.xa;
-          const uint32_t lo = (uint32_t)dwc * 4u;
+          int r0t = r0, dwct = dwc;
+          asm volatile("" : "+v"(r0t), "+v"(dwct));  // nothing of this rare path is precomputed (and spilled) outside the cell loop
+          const uint32_t lo = (uint32_t)dwct * 4u;
           uint32_t w[NIT2];
 #pragma unroll
-          for (int it = 0; it < NIT2; it++) w[it] = *reinterpret_cast<const uint32_t *>(src + ((uint32_t)__mul24(min(r0 + (NIT1 + it) * RPI, g.ch - 1), pitch) + lo));
+          for (int it = 0; it < NIT2; it++) w[it] = *reinterpret_cast<const uint32_t *>(src + ((uint32_t)__mul24(min(r0t + (NIT1 + it) * RPI, g.ch - 1), pitch) + lo));
+          uint32_t *dstt = reinterpret_cast<uint32_t *>(&tile[dwct * 4]);
 #pragma unroll
           for (int it = 0; it < NIT2; it++)
-            if (r0 + (NIT1 + it) * RPI < g.ch) dst[(r0 + (NIT1 + it) * RPI) * DW] = w[it];
+            if (r0t + (NIT1 + it) * RPI < g.ch) dstt[(r0t + (NIT1 + it) * RPI) * DW] = w[it];
         }
       }
     } else {
