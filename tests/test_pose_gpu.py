@@ -87,3 +87,16 @@ def test_pose_opt_noise_free_recovers_pose():
     _compare(out_o, out_h, cabi.FB_POSE_FRONT)
     assert out_h["ninliers"][0] == 400 and out_h["front_outlier"][0, :400].sum() == 0
     assert np.abs(out_h["Tcw"][0].reshape(3, 4) - T[:3, :4]).max() < 1e-3
+
+
+@pytest.mark.parametrize("variant", ["512", "256", "0"])
+def test_pose_opt_other_kernel_variants(variant):
+    """The default is k_pose_opt_split; FB_POSE_NT selects k_pose_opt_reg with 512 / 256 threads or the LDS-staged kernel
+    (read once per process, hence a child process; the children run one after the other).  Same parity bar for each."""
+    import os, subprocess, sys
+    env = dict(os.environ, FB_POSE_NT=variant)
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_pose_gpu.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "config3 or weights_and_masks", "-p", "no:cacheprovider"],
+                       env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
