@@ -289,6 +289,21 @@ __device__ __forceinline__ int wave_incl_scan(int v) {  // inclusive scan over t
   return v;
 }
 
+// exclusive scan of one int per thread over an NT-thread block; *total = block sum
+template <int NT>
+__device__ __forceinline__ int block_excl_scan(int v, int *s_w /*[NT / 64]*/, int *total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int inc = wave_incl_scan(v);
+  __syncthreads();
+  if (lane == 63) s_w[wv] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NT / 64; i++) { if (i < wv) base += s_w[i]; tot += s_w[i]; }
+  *total = tot;
+  return base + inc - v;
+}
+
 // exclusive scan of one int per thread over a 256-thread block; *total = block sum
 __device__ __forceinline__ int block_excl_scan256(int v, int *s_w /*[4]*/, int *total) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -678,7 +693,10 @@ __device__ __forceinline__ ONode child_of(const ONode &n, int q, int cnt) {
   return c;
 }
 
-__global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restrict__ cellCand, const int *__restrict__ cellCount,
+// NT threads: 256 when many (image, level) workgroups share the GPU, 1024 for a small batch, where the workgroup of level 0
+// (tens of thousands of candidates, ~10 rounds of three passes over them) is the latency of the whole front chain.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_octree(OrbK K, const uint32_t *__restrict__ cellCand, const int *__restrict__ cellCount,
                                                 uint32_t *__restrict__ cand, int *__restrict__ candCount, uint16_t *__restrict__ nodeOf,
                                                 uint32_t *__restrict__ lvlOut, int *__restrict__ lvlCount, int maxNodes) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -693,7 +711,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
   unsigned short *order = npos + M;                      // [M] final phase: rank -> position
   unsigned char *split = reinterpret_cast<unsigned char *>(order + M);  // [M] node is split this round
   unsigned long long *best = reinterpret_cast<unsigned long long *>(smem + (((size_t)(split + M - smem)) + 7 & ~(size_t)7));
-  __shared__ int s_w[4], s_S, s_nexp, s_jstar;
+  __shared__ int s_w[NT / 64], s_S, s_nexp, s_jstar;
   // ---- pack the per-cell candidate runs of k_fast into one dense list (order is irrelevant downstream: the quadtree
   //      breaks response ties with an order key derived from x, y).  offs[] aliases the node lists, not yet in use.
   uint32_t *cdw = cand + (long long)b * K.candStride + Lv.candBase;
@@ -704,11 +722,11 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
     const int *cc = cellCount + (long long)b * K.totalCells + Lv.cellBase;
     const uint32_t *sp = cellCand + (long long)b * K.candStride + Lv.candBase;
     int run = 0;
-    for (int c0 = 0; c0 < ncell; c0 += 256) {
+    for (int c0 = 0; c0 < ncell; c0 += NT) {
       const int c = c0 + tid;
       const int v = c < ncell ? cc[c] : 0;
       int tot;
-      const int ex = block_excl_scan256(v, s_w, &tot);
+      const int ex = block_excl_scan<NT>(v, s_w, &tot);
       if (c < ncell) offs[c] = run + ex;
       run += tot;
       __syncthreads();  // s_w is reused by the next chunk
@@ -718,11 +736,11 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
     __syncthreads();
     // dense index -> cell by binary search over the offsets; 4 independent copies per thread and step so that the
     // loads are in flight together
-    for (int k0 = tid; k0 < n; k0 += 256 * 4) {
+    for (int k0 = tid; k0 < n; k0 += NT * 4) {
       uint32_t val[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int k = min(k0 + u * 256, n - 1);
+        const int k = min(k0 + u * NT, n - 1);
         int lo = 0, hi = ncell;  // offs[lo] <= k < offs[hi]
         while (hi - lo > 1) {
           const int mid = (lo + hi) >> 1;
@@ -732,7 +750,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
       }
 #pragma unroll
       for (int u = 0; u < 4; u++)
-        if (k0 + u * 256 < n) cdw[k0 + u * 256] = val[u];
+        if (k0 + u * NT < n) cdw[k0 + u * NT] = val[u];
     }
     __threadfence_block();
     __syncthreads();  // the lists below overwrite offs[]; the dense list is read back by this block only
@@ -745,7 +763,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
   const int N = Lv.N;
   const int Hh = Lv.h - 2 * BORDER;
   // ---- initial nodes (ORBextractor.cc:543-593)
-  for (int i = tid; i < Lv.nIni; i += 256) {
+  for (int i = tid; i < Lv.nIni; i += NT) {
     ONode nd;
     nd.x0 = (short)(int)(Lv.hX * (float)i);
     nd.x1 = (short)(int)(Lv.hX * (float)(i + 1));
@@ -753,7 +771,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
     listB[i] = nd;
   }
   __syncthreads();
-  for (int k = tid; k < n; k += 256) {
+  for (int k = tid; k < n; k += NT) {
     const int rx = (int)(cd[k] & 0xFFF) - BORDER;
     int idx = (int)((float)rx / Lv.hX);
     idx = min(idx, Lv.nIni - 1);
@@ -770,7 +788,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
     s_S = S;
   }
   __syncthreads();
-  for (int k = tid; k < n; k += 256) nof[k] = npos[nof[k]];
+  for (int k = tid; k < n; k += NT) nof[k] = npos[nof[k]];
   __syncthreads();
   ONode *cur = listA, *nxt = listB;
   int S = s_S;
@@ -778,17 +796,17 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
   for (int guard = 0; guard < 64; guard++) {
     const int prevSize = S;
     // ---- count children of every expandable node
-    for (int i = tid; i < 4 * S; i += 256) ccnt[i] = 0;
+    for (int i = tid; i < 4 * S; i += NT) ccnt[i] = 0;
     __syncthreads();
     // candidate passes: 4 candidates per thread and step, all their global loads requested before the first use
-    for (int k0 = tid; k0 < n; k0 += 256 * 4) {
+    for (int k0 = tid; k0 < n; k0 += NT * 4) {
       int pk[4];
       uint32_t ck[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { const int kk = min(k0 + u * 256, n - 1); pk[u] = nof[kk]; ck[u] = cd[kk]; }
+      for (int u = 0; u < 4; u++) { const int kk = min(k0 + u * NT, n - 1); pk[u] = nof[kk]; ck[u] = cd[kk]; }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        if (k0 + u * 256 >= n) break;
+        if (k0 + u * NT >= n) break;
         const int p = pk[u];
         const ONode nd = cur[p];
         if (nd.cnt > 1) {
@@ -800,11 +818,11 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
     __syncthreads();
     // ---- choose the nodes to split
     if (!finalPhase) {
-      for (int p = tid; p < S; p += 256) split[p] = cur[p].cnt > 1;
+      for (int p = tid; p < S; p += NT) split[p] = cur[p].cnt > 1;
     } else {
       // sort expandable nodes by (count desc, list position asc) == (size, pointer) sort walked
       // from the back (ORBextractor.cc:684-686); split in that order until the list holds N
-      for (int p = tid; p < S; p += 256) {
+      for (int p = tid; p < S; p += NT) {
         split[p] = 0;
         const int c = cur[p].cnt;
         if (c > 1) {
@@ -834,7 +852,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
     // ---- new list: children of split nodes go to the front, most recently created first
     // phase 1 : creation order = list order of parents, q = 0..3  -> position = reverse of it
     // final   : creation order = rank order of parents,  q = 0..3
-    const int per = (S + 255) / 256;
+    const int per = (S + NT - 1) / NT;
     const int a0 = min(tid * per, S), a1 = min(a0 + per, S);
     int myKids = 0, myKeep = 0;
     if (!finalPhase) {
@@ -844,7 +862,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
       }
     } else {
       const int J = s_jstar;
-      const int perj = (J + 255) / 256;
+      const int perj = (J + NT - 1) / NT;
       const int r0 = min(tid * perj, J), r1 = min(r0 + perj, J);
       for (int r = r0; r < r1; r++) {
         const int p = order[r];
@@ -853,8 +871,8 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
       for (int p = a0; p < a1; p++) if (!split[p]) myKeep++;
     }
     int totalKids, totalKeep;
-    const int kidsBefore = block_excl_scan256(myKids, s_w, &totalKids);
-    const int keepBefore = block_excl_scan256(myKeep, s_w, &totalKeep);
+    const int kidsBefore = block_excl_scan<NT>(myKids, s_w, &totalKids);
+    const int keepBefore = block_excl_scan<NT>(myKeep, s_w, &totalKeep);
     // children created before mine: kidsBefore -> my first child has creation index kidsBefore,
     // list position = totalKids-1-creationIndex
     {
@@ -875,7 +893,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
         }
       } else {
         const int J = s_jstar;
-        const int perj = (J + 255) / 256;
+        const int perj = (J + NT - 1) / NT;
         const int r0 = min(tid * perj, J), r1 = min(r0 + perj, J);
         for (int r = r0; r < r1; r++) {
           const int p = order[r];
@@ -893,14 +911,14 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
     const int Snew = totalKids + totalKeep;
     __syncthreads();
     // ---- remap keypoints
-    for (int k0 = tid; k0 < n; k0 += 256 * 4) {
+    for (int k0 = tid; k0 < n; k0 += NT * 4) {
       int pk[4];
       uint32_t ck[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { const int kk = min(k0 + u * 256, n - 1); pk[u] = nof[kk]; ck[u] = cd[kk]; }
+      for (int u = 0; u < 4; u++) { const int kk = min(k0 + u * NT, n - 1); pk[u] = nof[kk]; ck[u] = cd[kk]; }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int k = k0 + u * 256;
+        const int k = k0 + u * NT;
         if (k >= n) break;
         const int p = pk[u];
         if (split[p]) {
@@ -912,12 +930,12 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
     // nToExpand of the new list = children with more than one keypoint
     int myExp = 0;
     {
-      const int pern = (Snew + 255) / 256;
+      const int pern = (Snew + NT - 1) / NT;
       const int n0 = min(tid * pern, Snew), n1 = min(n0 + pern, Snew);
       for (int p = n0; p < n1; p++) myExp += (p < totalKids && nxt[p].cnt > 1);
     }
     int nToExpand;
-    block_excl_scan256(myExp, s_w, &nToExpand);
+    block_excl_scan<NT>(myExp, s_w, &nToExpand);
     if (tid == 0) s_nexp = nToExpand;
     __syncthreads();
     ONode *t = cur; cur = nxt; nxt = t;
@@ -929,16 +947,16 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
     }
   }
   // ---- best keypoint per node: max response, first in vToDistributeKeys order on ties
-  for (int p = tid; p < S; p += 256) best[p] = 0ull;
+  for (int p = tid; p < S; p += NT) best[p] = 0ull;
   __syncthreads();
-  for (int k0 = tid; k0 < n; k0 += 256 * 4) {
+  for (int k0 = tid; k0 < n; k0 += NT * 4) {
     int pk[4];
     uint32_t ck[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const int kk = min(k0 + u * 256, n - 1); pk[u] = nof[kk]; ck[u] = cd[kk]; }
+    for (int u = 0; u < 4; u++) { const int kk = min(k0 + u * NT, n - 1); pk[u] = nof[kk]; ck[u] = cd[kk]; }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-    const int k = k0 + u * 256;
+    const int k = k0 + u * NT;
     if (k >= n) break;
     const uint32_t c = ck[u];
     const int x = c & 0xFFF, y = (c >> 12) & 0xFFF, r = c >> 24;
@@ -952,7 +970,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbK K, const uint32_t *__restri
     }
   }
   __syncthreads();
-  for (int p = tid; p < S; p += 256) out[p] = cd[(unsigned)(best[p] & 0xFFFFFFull)];
+  for (int p = tid; p < S; p += NT) out[p] = cd[(unsigned)(best[p] & 0xFFFFFFull)];
   if (tid == 0) *outCount = S;
 }
 
@@ -1602,11 +1620,16 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
     k_blur<<<dim3((K.blurStrips[nl] + 3) / 4, batch), 256, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
                                                                     o->blur.as<uint8_t>());
   }
-  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->octreeLds));
+  const bool octWide = nl * batch <= 512;  // few workgroups: 1024 threads each (two such workgroups fill a CU's wave slots)
+  FB_HIP(hipFuncSetAttribute(octWide ? reinterpret_cast<const void *>(k_octree<1024>) : reinterpret_cast<const void *>(k_octree<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->octreeLds));
   {
   fb::ProfScope prof_(fb::P_OCTREE, s);
-  k_octree<<<dim3(nl, batch), 256, o->octreeLds, s>>>(K, o->cellCand.as<uint32_t>(), o->cellCount.as<int>(), o->cand.as<uint32_t>(), candCount, o->nodeOf.as<uint16_t>(),
-                                                       o->lvlOut.as<uint32_t>(), lvlCount, o->maxNodes);
+  if (octWide)
+    k_octree<1024><<<dim3(nl, batch), 1024, o->octreeLds, s>>>(K, o->cellCand.as<uint32_t>(), o->cellCount.as<int>(), o->cand.as<uint32_t>(), candCount, o->nodeOf.as<uint16_t>(),
+                                                          o->lvlOut.as<uint32_t>(), lvlCount, o->maxNodes);
+  else
+    k_octree<256><<<dim3(nl, batch), 256, o->octreeLds, s>>>(K, o->cellCand.as<uint32_t>(), o->cellCount.as<int>(), o->cand.as<uint32_t>(), candCount, o->nodeOf.as<uint16_t>(),
+                                                         o->lvlOut.as<uint32_t>(), lvlCount, o->maxNodes);
   }
   {
   fb::ProfScope prof_(fb::P_DESCRIBE, s);
