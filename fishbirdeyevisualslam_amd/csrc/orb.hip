@@ -243,6 +243,100 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t *__restrict__
   }
 }
 
+// k_resize_rows loads BOTH source rows of every destination row although neighbours share one (at scale 1.2 eight rows ask
+// for 16 windows but need 10 or 11 different ones), and the kernel is bound by the bytes it has in flight per wave.  This one
+// walks the SOURCE rows of a run of RM_ROWS destination rows once: all RM_SRC windows are requested up front, every source row
+// is filtered horizontally once, and a destination row is written when its second source row has been filtered (each source
+// row closes at most one destination row because the scale is >= 1).  Same arithmetic as k_resize_rows; used when every run of
+// RM_ROWS destination rows spans at most RM_SRC source rows (scale factors up to 1.25), k_resize_rows otherwise.
+constexpr int RM_ROWS = 12, RM_SRC = 16;
+
+__global__ __launch_bounds__(256) void k_resize_merge(const uint8_t *__restrict__ src0, long long srcImgStride, int sw,
+                                                      int sh, int spitch, uint8_t *__restrict__ dst0,
+                                                      long long dstImgStride, int dw, int dh, int dpitch, ResizeTabs tb) {
+  const int b = blockIdx.z;
+  const int dyBase = __builtin_amdgcn_readfirstlane((blockIdx.y * blockDim.y + threadIdx.y) * RM_ROWS);
+  const int dx4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (dyBase >= dh || dx4 >= dpitch) return;
+  const int lane = threadIdx.x;  // blockDim.x = 64: a wave is one row of the block
+  const uint8_t *src = src0 + (long long)b * srcImgStride;
+  uint8_t *dst = dst0 + (long long)b * dstImgStride;
+  // column constants (as in k_resize_rows)
+  const int dxf = min(dx4, dw - 1);
+  const int a = tb.xofs[dxf] & ~3;
+  const int aw = min(a, spitch - 12);
+  uint32_t selw[4], wgt[4], liveMask = 0;
+  const int o0 = tb.xofs[dxf] - aw;
+  const uint32_t sh0 = (uint32_t)o0 & 3u;
+  const int q0 = o0 >> 2;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int dx = dx4 + k;
+    if (dx < dw) liveMask |= 0xffu << (8 * k);
+    const int dxc = min(dx, dw - 1);
+    const int sx = tb.xofs[dxc];
+    int a0 = tb.ialpha[dxc * 2], a1 = tb.ialpha[dxc * 2 + 1];
+    if (sx + 1 > sw - 1) { a0 += a1; a1 = 0; }
+    const uint32_t ob = (uint32_t)(sx - aw - o0);
+    selw[k] = ob | (0x0cu << 8) | ((ob + 1u) << 16) | (0x0cu << 24);
+    wgt[k] = (uint32_t)(a0 & 0xffff) | ((uint32_t)a1 << 16);
+  }
+  const bool anyTail = __ballot(q0 != 0) != 0ull;
+  const uint32_t mq1 = q0 == 1 ? ~0u : 0u, mq2 = q0 >= 2 ? ~0u : 0u, mq12 = mq1 | mq2;
+  // row constants: lane j of the wave holds the first source row and the two weights of destination row dyBase + j
+  const int nrows = min(RM_ROWS, dh - dyBase);
+  const int dyl = min(dyBase + min(lane, RM_ROWS - 1), dh - 1);
+  const int syLane = tb.yofs[dyl];
+  const int betaLane = (int)((uint32_t)(uint16_t)tb.ibeta[dyl * 2] | ((uint32_t)(uint16_t)tb.ibeta[dyl * 2 + 1] << 16));
+  const int base = __builtin_amdgcn_readfirstlane(syLane);  // first source row of the run
+  uint32_t w[RM_SRC][3];
+#pragma unroll
+  for (int r = 0; r < RM_SRC; r++) {
+    int sy = base + r;
+    sy = sy >= 0 ? (sy < sh ? sy : sh - 1) : 0;
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(src + ((uint32_t)__mul24(sy, spitch) + (uint32_t)aw));
+    w[r][0] = p[0]; w[r][1] = p[1]; w[r][2] = p[2];
+  }
+  int hp[4] = {0, 0, 0, 0}, hc[4];
+  int j = 0;
+#pragma unroll
+  for (int r = 0; r < RM_SRC; r++) {
+    {  // horizontal pass of source row base + r
+      uint32_t x0 = w[r][0], x1 = w[r][1];
+      const uint32_t x2 = w[r][2];
+      if (anyTail) {
+        x0 = (w[r][0] & ~mq12) | (w[r][1] & mq1) | (w[r][2] & mq2);
+        x1 = (w[r][1] & ~mq12) | (w[r][2] & mq12);
+      }
+      const uint32_t e0 = __builtin_amdgcn_alignbyte(x1, x0, sh0), e1 = __builtin_amdgcn_alignbyte(x2, x1, sh0);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t spread = __builtin_amdgcn_perm(e1, e0, selw[k]);
+        int d;
+        asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(spread), "v"(wgt[k]));
+        hc[k] = d >> 4;
+      }
+    }
+    if (r >= 1 && j < nrows) {
+      const int sy0 = __builtin_amdgcn_readlane(syLane, j);
+      if (sy0 == base + r - 1) {  // wave-uniform: this source row is the second row of destination row j
+        const int bw = __builtin_amdgcn_readlane(betaLane, j);
+        const int b0 = (int)(short)(bw & 0xffff), b1 = bw >> 16;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int v = ((__mul24(b0, hp[k]) >> 16) + (__mul24(b1, hc[k]) >> 16) + 2) >> 2;
+          packed |= (uint32_t)v << (8 * k);
+        }
+        *reinterpret_cast<uint32_t *>(dst + (long long)(dyBase + j) * dpitch + dx4) = packed & liveMask;
+        j++;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) hp[k] = hc[k];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // FAST-9-16 score = max over the 16 arcs of 9 of min(d) (and of min(-d)), minus 1
 // (cv::cornerScore<16>); the pixel is a corner at threshold t iff score >= t.
@@ -1302,6 +1396,7 @@ struct fb_orb {
   size_t octreeLds = 0;
   fb::DevBuf pyr, blur, cand, cellCand, cellCount, nodeOf, counts, lvlOut, tabs, angTab, timers;
   ResizeTabs rt[FB_MAX_LEVELS];
+  bool mergeOK[FB_MAX_LEVELS] = {};  // k_resize_merge: every run of RM_ROWS destination rows spans <= RM_SRC source rows
   bool rowsOK[FB_MAX_LEVELS] = {};  // k_resize_rows' 12-byte window covers every 4-pixel group of the level
   // last call (for fb_orb_get_level)
   const uint8_t *lastImg = nullptr;
@@ -1451,6 +1546,15 @@ int prepare(fb_orb *o, int w, int h, int batch) {
         ok = ok && (last - (xofs[dx4] & ~3)) <= 11 && (last - xofs[dx4]) <= 7;
       }
       o->rowsOK[l] = ok;
+      {
+        bool okm = ok;
+        for (int y0 = 0; y0 < dhd && okm; y0 += RM_ROWS) {
+          const int y1 = std::min(y0 + RM_ROWS, dhd) - 1;
+          okm = yofs[y0] >= 0 && yofs[y1] + 1 - yofs[y0] <= RM_SRC - 1;
+          for (int y = y0; y < y1 && okm; y++) okm = yofs[y + 1] > yofs[y];  // a source row closes at most one destination row
+        }
+        o->mergeOK[l] = okm;
+      }
       tabOff[l * 4 + 0] = append(xofs.data(), xofs.size() * 4);
       tabOff[l * 4 + 1] = append(ialpha.data(), ialpha.size() * 2);
       tabOff[l * 4 + 2] = append(yofs.data(), yofs.size() * 4);
@@ -1594,7 +1698,10 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
     dim3 blk(64, 4), grd((D.pitch / 4 + 63) / 64, (D.h + 3) / 4, batch);
     fb::ProfScope prof_(fb::P_RESIZE, s);
     const bool rows = o->rowsOK[l] && spitch >= 12 && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)spitch | (uintptr_t)sstr) & 3) == 0;
-    if (rows) {
+    if (rows && o->mergeOK[l]) {
+      dim3 grdM((D.pitch / 4 + 63) / 64, (D.h + 4 * RM_ROWS - 1) / (4 * RM_ROWS), batch);
+      k_resize_merge<<<grdM, blk, 0, s>>>(src, sstr, S.w, S.h, spitch, o->pyr.as<uint8_t>() + D.off, K.pyrStride, D.w, D.h, D.pitch, o->rt[l]);
+    } else if (rows) {
       dim3 grdR((D.pitch / 4 + 63) / 64, (D.h + 4 * RESIZE_ROWS - 1) / (4 * RESIZE_ROWS), batch);
       k_resize_rows<<<grdR, blk, 0, s>>>(src, sstr, S.w, S.h, spitch, o->pyr.as<uint8_t>() + D.off, K.pyrStride, D.w, D.h, D.pitch, o->rt[l]);
     } else {
