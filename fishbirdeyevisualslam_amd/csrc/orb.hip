@@ -57,7 +57,6 @@ struct OrbK {
   int cellBase[FB_MAX_LEVELS + 1];  // first FAST cell of each level (contiguous copy for one scalar load)
   int grpBase[FB_MAX_LEVELS + 1];   // first k_fast wave of each level (a wave = FAST_CPW consecutive cells)
   int totalGroups;
-  int grpFirst, grpEnd;  // the groups of THIS k_fast launch (a run of levels that share a tile pitch)
   long long pyrStride;   // bytes per image of levels >= 1
   long long blurStride;  // bytes per image of the blurred pyramid (all levels)
   int blurStrips[FB_MAX_LEVELS + 1];  // first k_blur strip of each level
@@ -466,8 +465,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
   int grp, l = 0;
   {
     const int nb = gridDim.x, per = (nb + 7) >> 3;
-    grp = K.grpFirst + (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (grp >= K.grpEnd) return;  // grid is padded to a multiple of 8
+    grp = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (grp >= K.totalGroups) return;  // grid is padded to a multiple of 8
   }
 #pragma unroll
   for (int i = 1; i < FB_MAX_LEVELS; i++) l += (i < K.nlevels && grp >= K.grpBase[i]) ? 1 : 0;
@@ -1397,8 +1396,6 @@ struct fb_orb {
   size_t octreeLds = 0;
   fb::DevBuf pyr, blur, cand, cellCand, cellCount, nodeOf, counts, lvlOut, tabs, angTab, timers;
   ResizeTabs rt[FB_MAX_LEVELS];
-  struct FastRun { int grpFirst, grpEnd, tp, tileBytes, maxOut, maxPix; };
-  std::vector<FastRun> fastRuns;  // k_fast launches: runs of levels with the same tile pitch class (the small top levels have wider cells)
   bool mergeOK[FB_MAX_LEVELS] = {};  // k_resize_merge: every run of RM_ROWS destination rows spans <= RM_SRC source rows
   bool rowsOK[FB_MAX_LEVELS] = {};  // k_resize_rows' 12-byte window covers every 4-pixel group of the level
   // last call (for fb_orb_get_level)
@@ -1578,39 +1575,20 @@ int prepare(fb_orb *o, int w, int h, int batch) {
   K.dbg = getenv("FB_FAST_DBG") ? atoi(getenv("FB_FAST_DBG")) : 0;
   {
     int tileB = 0, maxOut = 0, maxPix = 0, tpNeed = 0;
-    o->fastRuns.clear();
     for (int l = 0; l < p.nlevels; l++) {
       const LevelInfo &L = K.L[l];
       if (L.nCols * L.nRows == 0) continue;
       const int tpMax = (L.wCell + 6 + 3 + 3) & ~3, chMax = L.hCell + 6;
-      const int cls = tpMax <= 44 ? 44 : tpMax <= 56 ? 56 : FAST_MAX_TILE;
-      const int mo = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2), mp = L.wCell * L.hCell;
-      if (o->fastRuns.empty() || o->fastRuns.back().tp != cls || o->fastRuns.back().grpEnd != K.grpBase[l])
-        o->fastRuns.push_back({K.grpBase[l], K.grpBase[l], cls, 0, 0, 0});
-      fb_orb::FastRun &R = o->fastRuns.back();
-      R.grpEnd = K.grpBase[l + 1];
-      R.tileBytes = std::max(R.tileBytes, chMax);  // rows for now
-      R.maxOut = std::max(R.maxOut, mo);
-      R.maxPix = std::max(R.maxPix, mp);
       tpNeed = std::max(tpNeed, tpMax);
       tileB = std::max(tileB, chMax);
-      maxOut = std::max(maxOut, mo);
-      maxPix = std::max(maxPix, mp);
-    }
-    auto tileBytesOf = [](int tp, int rows, int mOut) {
-      int tb = (std::max(tp * rows, 4 * ((mOut + 3) & ~3)) + 15) & ~15;
-      return std::max(tb, (21 * tp + 15) & ~15);  // k_fast stages 40 / 42 rows unconditionally into tile + score tile
-    };
-    for (fb_orb::FastRun &R : o->fastRuns) {
-      R.tileBytes = tileBytesOf(R.tp, R.tileBytes, R.maxOut);
-      R.maxOut = (R.maxOut + 3) & ~3;
-      R.maxPix = (R.maxPix + 7) & ~7;
+      maxOut = std::max(maxOut, ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2));
+      maxPix = std::max(maxPix, L.wCell * L.hCell);
     }
     K.fastTP = tpNeed <= 44 ? 44 : tpNeed <= 56 ? 56 : FAST_MAX_TILE;
-    K.fastTileBytes = tileBytesOf(K.fastTP, tileB, maxOut);
+    K.fastTileBytes = (std::max(K.fastTP * tileB, 4 * ((maxOut + 3) & ~3)) + 15) & ~15;
+    K.fastTileBytes = std::max(K.fastTileBytes, (21 * K.fastTP + 15) & ~15);  // k_fast stages 40 / 42 rows unconditionally into tile + score tile
     K.fastMaxOut = (maxOut + 3) & ~3;
     K.fastMaxPix = (maxPix + 7) & ~7;
-    K.grpFirst = 0; K.grpEnd = K.totalGroups;
   }
   K.pyrStride = (pyrOff + 255) & ~255ll;
   K.blurStride = (blurOff + 255) & ~255ll;
@@ -1730,19 +1708,15 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
       k_resize<<<grd, blk, 0, s>>>(src, sstr, S.w, S.h, spitch, o->pyr.as<uint8_t>() + D.off, K.pyrStride, D.w, D.h, D.pitch, o->rt[l]);
     }
   }
-  for (const fb_orb::FastRun &R : o->fastRuns) {  // one launch per run of levels with the same tile pitch
-    if (R.grpEnd <= R.grpFirst) continue;
-    OrbK Kr = K;
-    Kr.grpFirst = R.grpFirst; Kr.grpEnd = R.grpEnd;
-    Kr.fastTP = R.tp; Kr.fastTileBytes = R.tileBytes; Kr.fastMaxOut = R.maxOut; Kr.fastMaxPix = R.maxPix;
-    fb::ProfScope prof_(R.tp == 44 ? fb::P_FAST : R.tp == 56 ? fb::P_FAST56 : fb::P_FAST72, s);
-    const dim3 grdF((R.grpEnd - R.grpFirst + 7) / 8 * 8, batch);
-    const size_t ldsF = (size_t)2 * Kr.fastTileBytes + 2 * Kr.fastMaxPix;
-#define FAST_LAUNCH(TP_) { if (K.dbg == 20) k_fast<TP_, true><<<grdF, 64, ldsF, s>>>(Kr, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cellCand.as<uint32_t>(), o->cellCount.as<int>()); \
-                          else k_fast<TP_, false><<<grdF, 64, ldsF, s>>>(Kr, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cellCand.as<uint32_t>(), o->cellCount.as<int>()); }
-    if (R.tp == 44)
+  if (K.totalCells > 0) {
+    fb::ProfScope prof_(K.fastTP == 44 ? fb::P_FAST : K.fastTP == 56 ? fb::P_FAST56 : fb::P_FAST72, s);
+    const dim3 grdF((K.totalGroups + 7) / 8 * 8, batch);
+    const size_t ldsF = (size_t)2 * K.fastTileBytes + 2 * K.fastMaxPix;
+#define FAST_LAUNCH(TP_) { if (K.dbg == 20) k_fast<TP_, true><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cellCand.as<uint32_t>(), o->cellCount.as<int>()); \
+                          else k_fast<TP_, false><<<grdF, 64, ldsF, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(), o->cellCand.as<uint32_t>(), o->cellCount.as<int>()); }
+    if (K.fastTP == 44)
       FAST_LAUNCH(44)
-    else if (R.tp == 56)
+    else if (K.fastTP == 56)
       FAST_LAUNCH(56)
     else
       FAST_LAUNCH(FAST_MAX_TILE)
