@@ -1910,10 +1910,21 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   //      two all-reduces per slot on this stream (the Schur-reduced system; the exchange block of the linearisation), every
   //      rank enqueues the same slots and takes the same decisions from the reduced values.
   if (!big && !getenv("FB_BA_TRACE") && !getenv("FB_BA_HOST_LM")) {
-    static hipStream_t sAux = nullptr;      // side stream for the abort request (does not synchronise with the null stream)
-    static BACtl *hCtl = nullptr;           // pinned mirror of the control block
-    if (!sAux) FB_HIP(hipStreamCreateWithFlags(&sAux, hipStreamNonBlocking));
-    if (!hCtl) FB_HIP(hipHostMalloc(reinterpret_cast<void **>(&hCtl), sizeof(BACtl), hipHostMallocDefault));
+    // per host thread and device (concurrent callers must not share the pinned mirror; a stream belongs to its device):
+    // side stream for the abort request (does not synchronise with the null stream), pinned mirror of the control block,
+    // the event the host polls
+    struct PerDev { hipStream_t sAux = nullptr; BACtl *hCtl = nullptr; hipEvent_t evDone = nullptr; };
+    static thread_local PerDev perDev[64];
+    int devId = 0;
+    FB_HIP(hipGetDevice(&devId));
+    if (devId < 0 || devId >= 64) { fb::set_error("fb_local_ba: device id %d", devId); return FB_ERR_NODEVICE; }
+    PerDev &pd = perDev[devId];
+    if (!pd.sAux) FB_HIP(hipStreamCreateWithFlags(&pd.sAux, hipStreamNonBlocking));
+    if (!pd.hCtl) FB_HIP(hipHostMalloc(reinterpret_cast<void **>(&pd.hCtl), sizeof(BACtl), hipHostMallocDefault));
+    if (!pd.evDone) FB_HIP(hipEventCreateWithFlags(&pd.evDone, hipEventDisableTiming));
+    hipStream_t sAux = pd.sAux;
+    BACtl *hCtl = pd.hCtl;
+    hipEvent_t evDone = pd.evDone;
     fb::DevBuf d_ctl, d_flags, d_kfT, d_ptOut, d_xb, d_abort, d_ex;
     BACtl init;
     memset(&init, 0, sizeof(init));
@@ -1984,8 +1995,6 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
     FB_HIP(hipMemcpyAsync(d_kfT.p, d_kfT0, (size_t)n_kf * 48, hipMemcpyDeviceToDevice, s0));
     FB_TRY(d_ptOut.alloc((size_t)std::max(npt, 1) * 12));
     if (sharded) FB_TRY(d_ex.alloc(((size_t)npt * 3 + nE + 1) * 8));
-    hipEvent_t evDone = nullptr;
-    FB_HIP(hipEventCreateWithFlags(&evDone, hipEventDisableTiming));
     bool abortSent = false;
     static const int one = 1;
     // a typical schedule takes one trial per iteration: its1 + its2 trials + the two opening linearisations
@@ -2023,7 +2032,6 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
       batch = 6;
     }
     lap("schedule finished");
-    (void)hipEventDestroy(evDone);
     if (rcLoop != FB_OK) return rcLoop;
     if (hCtl->phase != 2) { fb::set_error("fb_local_ba: the LM schedule did not finish"); return FB_ERR_HIP; }
     std::vector<uint8_t> flags(std::max(nE, 1));
