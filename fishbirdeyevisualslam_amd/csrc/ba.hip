@@ -1475,23 +1475,23 @@ struct RcclApi {
   const char *(*GetErrorString)(int) = nullptr;
 };
 RcclApi *rccl_api() {
-  static RcclApi api;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  // loaded once (a function-local static is initialised thread-safely)
+  static RcclApi api = [] {
+    RcclApi a;
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (api.lib) break;
+      a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (a.lib) break;
     }
-    if (api.lib) {
-      api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
-      api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
-      api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
-      api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
-      api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
-      if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) api.lib = nullptr;
+    if (a.lib) {
+      a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.lib, "ncclGetUniqueId"));
+      a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.lib, "ncclCommInitRank"));
+      a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+      a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(a.lib, "ncclAllReduce"));
+      a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
+      if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce) a.lib = nullptr;
     }
-  }
+    return a;
+  }();
   return api.lib ? &api : nullptr;
 }
 constexpr int kNcclDouble = 8, kNcclSum = 0;  // ncclFloat64, ncclSum (rccl.h)
