@@ -57,13 +57,14 @@ enum ProfId {
 };
 extern bool g_prof_on;
 extern int g_prof_only;  // -1 = every kernel, else only this ProfId is bracketed
-void prof_begin(int id, hipStream_t s);
-void prof_end(hipStream_t s);
-struct ProfScope {
+hipEvent_t prof_begin(int id, hipStream_t s);  // records the start event, returns the end event of this bracket
+void prof_end(hipEvent_t end, hipStream_t s);
+struct ProfScope {  // (the record list is mutex-protected and a scope closes its OWN bracket: launches from several host threads)
   hipStream_t s;
   bool on;
-  ProfScope(int id, hipStream_t st) : s(st), on(g_prof_on && (g_prof_only < 0 || g_prof_only == id)) { if (on) prof_begin(id, s); }
-  ~ProfScope() { if (on) prof_end(s); }
+  hipEvent_t end = nullptr;
+  ProfScope(int id, hipStream_t st) : s(st), on(g_prof_on && (g_prof_only < 0 || g_prof_only == id)) { if (on) end = prof_begin(id, s); }
+  ~ProfScope() { if (on) prof_end(end, s); }
 };
 
 // Device scratch that lives for one host-pointer call.

@@ -82,6 +82,7 @@ const char *kProfNames[P_COUNT] = {"k_resize", "k_fast<44>", "k_octree", "k_desc
                                    "k_ba_solve", "k_ba_update", "k_ba_misc", "k_proj_kf", "k_match_bow_kf", "k_in_frustum",
                                    "k_undistort", "k_blur", "k_kf_search", "k_distinctive", "k_bow_transform", "k_fast<56>", "k_fast<72>"};
 struct ProfRec { int id; hipEvent_t a, b; };
+std::mutex g_prof_mu;
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t take_event() {
@@ -92,12 +93,14 @@ hipEvent_t take_event() {
 }
 }  // namespace
 
-void prof_begin(int id, hipStream_t s) {
+hipEvent_t prof_begin(int id, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r{id, take_event(), take_event()};
   (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
+  return r.b;
 }
-void prof_end(hipStream_t s) { (void)hipEventRecord(g_recs.back().b, s); }
+void prof_end(hipEvent_t end, hipStream_t s) { (void)hipEventRecord(end, s); }
 
 }  // namespace fb
 
@@ -115,6 +118,7 @@ int fb_prof_only(const char *kernel_name) {
 }
 
 int fb_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(fb::g_prof_mu);
   for (auto &r : fb::g_recs) { fb::g_pool.push_back(r.a); fb::g_pool.push_back(r.b); }
   fb::g_recs.clear();
   return FB_OK;
@@ -123,6 +127,7 @@ int fb_prof_reset(void) {
 int fb_prof_report(fb_prof_entry *out, int cap) {
   double tot[fb::P_COUNT] = {0};
   int cnt[fb::P_COUNT] = {0};
+  std::lock_guard<std::mutex> lk(fb::g_prof_mu);
   for (auto &r : fb::g_recs) {
     if (hipEventSynchronize(r.b) != hipSuccess) continue;
     float ms = 0;
