@@ -12,6 +12,13 @@
  *   Entry points without the suffix take HOST pointers, copy, run the same
  *   kernels and synchronise before returning (drop-in for the reference call).
  *
+ * Threads
+ *   Calls that take no handle (matchers, pose optimisation, bundle adjustment)
+ *   may run concurrently from several host threads, each on the device that is
+ *   current for its thread.  A handle (fb_orb, fb_rccl communicator) carries
+ *   device buffers of its own: one call at a time per handle, like the
+ *   reference's ORBextractor object.  fb_last_error() is per thread.
+ *
  * Status: 0 = ok, <0 = error (fb_last_error() gives the text).
  * There is no CPU fallback: without a HIP device every compute call fails with
  * FB_ERR_NODEVICE.
