@@ -1389,6 +1389,14 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(OrbK K, const uint8_
 struct fb_orb {
   fb_orb_params p;
   fb_orb_tables t;
+  // k_blur runs on a stream of its own beside k_octree (see fb_orb_extract_batch_dev); created on first use
+  hipStream_t sideStream = nullptr;
+  hipEvent_t evFork = nullptr, evJoin = nullptr;
+  ~fb_orb() {
+    if (evFork) (void)hipEventDestroy(evFork);
+    if (evJoin) (void)hipEventDestroy(evJoin);
+    if (sideStream) (void)hipStreamDestroy(sideStream);
+  }
   // workspace, valid for (w, h, batchCap)
   int w = 0, h = 0, batchCap = 0;
   OrbK K;
@@ -1722,11 +1730,35 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
       FAST_LAUNCH(FAST_MAX_TILE)
 #undef FAST_LAUNCH
   }
-  {
-    fb::ProfScope prof_(fb::P_BLUR, s);
-    k_blur<<<dim3((K.blurStrips[nl] + 3) / 4, batch), 256, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
-                                                                    o->blur.as<uint8_t>());
+  // The Gaussian blur (vector-ALU bound, no LDS) and the quadtree (one workgroup per image level, latency bound, LDS heavy)
+  // are independent and complement each other: the blur goes to a side stream that forks here, after k_fast, and joins before
+  // k_describe.  In one stream the quadtree's 0.27 ms per image set were pure waiting: nothing else on the GPU can use the
+  // time -- k_fast and k_describe of the other streams need the LDS its workgroups hold (the step without the quadtree
+  // launch measured 3.09 instead of 3.59 ms).
+  // (When every kernel is bracketed for the per-kernel table -- fb_prof_enable without fb_prof_only -- everything stays on the
+  // caller's stream, so that the table shows each kernel on its own.)
+  static const int sideMin = [] {
+    const char* e = getenv("FB_ORB_SIDE_MIN");
+    return e ? atoi(e) : 64;
+  }();
+  const bool fork = batch >= sideMin && !(fb::g_prof_on && fb::g_prof_only < 0);
+  hipStream_t sBlur = s;
+  if (fork) {
+    if (!o->sideStream) {
+      FB_HIP(hipStreamCreateWithFlags(&o->sideStream, hipStreamNonBlocking));
+      FB_HIP(hipEventCreateWithFlags(&o->evFork, hipEventDisableTiming));
+      FB_HIP(hipEventCreateWithFlags(&o->evJoin, hipEventDisableTiming));
+    }
+    sBlur = o->sideStream;
+    FB_HIP(hipEventRecord(o->evFork, s));
+    FB_HIP(hipStreamWaitEvent(sBlur, o->evFork, 0));
   }
+  {
+    fb::ProfScope prof_(fb::P_BLUR, sBlur);
+    k_blur<<<dim3((K.blurStrips[nl] + 3) / 4, batch), 256, 0, sBlur>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
+                                                                        o->blur.as<uint8_t>());
+  }
+  if (fork) FB_HIP(hipEventRecord(o->evJoin, sBlur));
   const bool octWide = nl * batch <= 512;  // few workgroups: 1024 threads each (two such workgroups fill a CU's wave slots)
   FB_HIP(hipFuncSetAttribute(octWide ? reinterpret_cast<const void *>(k_octree<1024>) : reinterpret_cast<const void *>(k_octree<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->octreeLds));
   {
@@ -1738,6 +1770,7 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
     k_octree<256><<<dim3(nl, batch), 256, o->octreeLds, s>>>(K, o->cellCand.as<uint32_t>(), o->cellCount.as<int>(), o->cand.as<uint32_t>(), candCount, o->nodeOf.as<uint16_t>(),
                                                          o->lvlOut.as<uint32_t>(), lvlCount, o->maxNodes);
   }
+  if (fork) FB_HIP(hipStreamWaitEvent(s, o->evJoin, 0));  // the blurred levels are complete
   {
   fb::ProfScope prof_(fb::P_DESCRIBE, s);
   k_describe<<<dim3(((K.capOut + DESC_WPB * DESC_KPW - 1) / (DESC_WPB * DESC_KPW) + 7) / 8 * 8, batch), 64 * DESC_WPB, 0, s>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
