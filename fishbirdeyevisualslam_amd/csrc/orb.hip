@@ -794,7 +794,8 @@ __global__ __launch_bounds__(NT) void k_octree(OrbK K, const uint32_t *__restric
                                                 uint32_t *__restrict__ cand, int *__restrict__ candCount, uint16_t *__restrict__ nodeOf,
                                                 uint32_t *__restrict__ lvlOut, int *__restrict__ lvlCount, int maxNodes) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  // level-major grid: the workgroups of level 0, the longest by far, are dispatched first and the short ones fill in behind
+  const int l = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
   const LevelInfo &Lv = K.L[l];
   const int M = maxNodes;
   ONode *listA = reinterpret_cast<ONode *>(smem);        // [M]
@@ -1759,15 +1760,16 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
                                                                         o->blur.as<uint8_t>());
   }
   if (fork) FB_HIP(hipEventRecord(o->evJoin, sBlur));
-  const bool octWide = nl * batch <= 512;  // few workgroups: 1024 threads each (two such workgroups fill a CU's wave slots)
+  static const int octWideMax = getenv("FB_OCT_WIDE_MAX") ? atoi(getenv("FB_OCT_WIDE_MAX")) : 512;
+  const bool octWide = nl * batch <= octWideMax;  // few workgroups: 1024 threads each (two such workgroups fill a CU's wave slots)
   FB_HIP(hipFuncSetAttribute(octWide ? reinterpret_cast<const void *>(k_octree<1024>) : reinterpret_cast<const void *>(k_octree<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->octreeLds));
   {
   fb::ProfScope prof_(fb::P_OCTREE, s);
   if (octWide)
-    k_octree<1024><<<dim3(nl, batch), 1024, o->octreeLds, s>>>(K, o->cellCand.as<uint32_t>(), o->cellCount.as<int>(), o->cand.as<uint32_t>(), candCount, o->nodeOf.as<uint16_t>(),
+    k_octree<1024><<<dim3(batch, nl), 1024, o->octreeLds, s>>>(K, o->cellCand.as<uint32_t>(), o->cellCount.as<int>(), o->cand.as<uint32_t>(), candCount, o->nodeOf.as<uint16_t>(),
                                                           o->lvlOut.as<uint32_t>(), lvlCount, o->maxNodes);
   else
-    k_octree<256><<<dim3(nl, batch), 256, o->octreeLds, s>>>(K, o->cellCand.as<uint32_t>(), o->cellCount.as<int>(), o->cand.as<uint32_t>(), candCount, o->nodeOf.as<uint16_t>(),
+    k_octree<256><<<dim3(batch, nl), 256, o->octreeLds, s>>>(K, o->cellCand.as<uint32_t>(), o->cellCount.as<int>(), o->cand.as<uint32_t>(), candCount, o->nodeOf.as<uint16_t>(),
                                                          o->lvlOut.as<uint32_t>(), lvlCount, o->maxNodes);
   }
   if (fork) FB_HIP(hipStreamWaitEvent(s, o->evJoin, 0));  // the blurred levels are complete
