@@ -1198,6 +1198,7 @@ constexpr int DESC_KPW = 2;  // consecutive key points per wave, all their patch
 // 256 tests), not by arithmetic.  Measured at B=256 (per step, both images): one key point per wave 0.97 ms; 8 per wave
 // with the NEXT patch prefetched during the tests 1.47 ms (the tests are far too short to cover a patch); 2 per wave
 // with both patches requested together 0.93 ms and the best overlap with the other streams; 4 per wave the same.
+// More resident waves do not help either (amdgpu_waves_per_eu 6: 76 VGPRs, same time; 7: spills, 1.12 ms).
 __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(OrbK K, const uint8_t *__restrict__ img0, long long imgStride,
                                                  int pitch0, const uint8_t *__restrict__ pyr,
                                                  const uint8_t *__restrict__ blur, const uint4 *__restrict__ angTab,
@@ -1731,11 +1732,9 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
       FAST_LAUNCH(FAST_MAX_TILE)
 #undef FAST_LAUNCH
   }
-  // The Gaussian blur (vector-ALU bound, no LDS) and the quadtree (one workgroup per image level, latency bound, LDS heavy)
-  // are independent and complement each other: the blur goes to a side stream that forks here, after k_fast, and joins before
-  // k_describe.  In one stream the quadtree's 0.27 ms per image set were pure waiting: nothing else on the GPU can use the
-  // time -- k_fast and k_describe of the other streams need the LDS its workgroups hold (the step without the quadtree
-  // launch measured 3.09 instead of 3.59 ms).
+  // The Gaussian blur (vector-ALU bound) and the quadtree (one workgroup per image level, latency bound: 70 % of its wave
+  // cycles wait) are independent and complement each other: the blur goes to a side stream that forks here, after k_fast, and
+  // joins before k_describe (calls of FB_ORB_SIDE_MIN = 64 images or more: the fork/join costs ~0.05 ms of latency).
   // (When every kernel is bracketed for the per-kernel table -- fb_prof_enable without fb_prof_only -- everything stays on the
   // caller's stream, so that the table shows each kernel on its own.)
   static const int sideMin = [] {
