@@ -129,3 +129,39 @@ def test_fast_phase_timers(monkeypatch):
         assert t[11] == 0                                              # reading reset them
     finally:
         orb.close()
+
+
+def test_batch_of_72_images_takes_the_side_stream_and_matches_single_image_calls():
+    # calls of 64 images or more run k_blur on a side stream of the extractor beside k_octree (fork after k_fast, join
+    # before k_describe); the result must not depend on that, nor on a second call reusing the same buffers at once
+    import torch
+    B, w, h = 72, 320, 240
+    p = O.orb_params(nfeatures=500)
+    imgs = np.stack([synth.synth_image(4000 + i, w, h) for i in range(B)])
+    orb = H.Orb(p)
+    try:
+        dev = torch.device("cuda:0")
+        d_img = torch.from_numpy(imgs.reshape(-1)).to(dev)
+        d_kps = torch.zeros(B * orb.cap * cabi.KP_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        d_desc = torch.zeros(B * orb.cap * 32, dtype=torch.uint8, device=dev)
+        d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+        st = torch.cuda.Stream()
+        for _ in range(3):  # back-to-back calls: the fork / join events are reused
+            fb.check(fb.lib().fb_orb_extract_batch_dev(orb.h, C.c_void_p(d_img.data_ptr()), B, w, h, w, C.c_size_t(w * h),
+                                                       C.c_void_p(d_kps.data_ptr()), C.c_void_p(d_desc.data_ptr()),
+                                                       C.c_void_p(d_n.data_ptr()), C.c_void_p(st.cuda_stream)), "extract batch")
+        st.synchronize()
+        n = d_n.cpu().numpy()
+        kps = d_kps.cpu().numpy().view(cabi.KP_DTYPE).reshape(B, orb.cap)
+        desc = d_desc.cpu().numpy().reshape(B, orb.cap, 32)
+        for b in range(B):
+            if b % 24 == 5:
+                k1, d1 = O.orb_extract(p, imgs[b])   # the oracle itself for three of them
+            else:
+                k1, d1 = orb.extract(imgs[b])        # single-image entry point (one stream, pinned by the tests above)
+            assert n[b] == len(k1) and n[b] > 100
+            for f in ("octave", "x", "y", "response", "size", "angle"):
+                np.testing.assert_array_equal(kps[b, : n[b]][f], k1[f], err_msg="image %d %s" % (b, f))
+            np.testing.assert_array_equal(desc[b, : n[b]], d1)
+    finally:
+        orb.close()
