@@ -1283,7 +1283,11 @@ int fb_pose_opt_batch_dev(const fb_pose_opt_args *A, void *stream) {
   // register-resident kernel whenever its in-kernel way out (level bytes of every slot in LDS) fits: by default
   // k_pose_opt_split (448 edge threads + a solver wave; 120 B of scratch per lane); FB_POSE_NT=512 / 256 / 0 selects
   // k_pose_opt_reg with 512 threads / with one wave per SIMD / the LDS-staged kernel (measurements only)
-  static const int regNT = [] { const char *e = getenv("FB_POSE_NT"); const int v = e ? atoi(e) : 448; return v == 256 || v == 512 || v == 448 ? v : 0; }();
+  // Without FB_POSE_NT, batches of 64 frames or more take the 256-thread kernel instead: alone it is 9 % slower
+  // (0.38 vs 0.35 ms), but its workgroup leaves 148 registers per SIMD lane to the extractor kernels of the other streams
+  // (the split kernel holds a CU's whole register file while it runs): +1.5 % pairs/s in the overlapped step.
+  static const int envNT = [] { const char *e = getenv("FB_POSE_NT"); const int v = e ? atoi(e) : -1; return v < 0 || v == 256 || v == 512 || v == 448 ? v : 0; }();
+  const int regNT = envNT >= 0 ? envNT : (A->batch >= 64 ? 256 : 448);
   if (regNT) {
     const size_t lds = regNT == 448 ? (size_t)NACC * (448 + 16) * sizeof(double) : (size_t)NACC * (regNT + regNT / 32) * sizeof(double);
     const size_t flagBytes = ((size_t)((A->front_stride + 15) & ~15)) + ((A->bird_stride + 15) & ~15);

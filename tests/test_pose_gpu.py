@@ -100,3 +100,10 @@ def test_pose_opt_other_kernel_variants(variant):
                         "-k", "config3 or weights_and_masks", "-p", "no:cacheprovider"],
                        env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_pose_opt_batch_of_64_takes_the_throughput_kernel():
+    """Batches of 64 frames or more run k_pose_opt_reg<256> (it shares its CUs with other streams' kernels); same bar."""
+    probs = [synth.make_pose_problem(3300 + i, n_front=260 + 7 * (i % 9), n_bird=120 + 5 * (i % 7)) for i in range(64)]
+    out_o, out_h = _run(probs, mode=cabi.FB_POSE_FRONT_BIRD)
+    _compare(out_o, out_h, cabi.FB_POSE_FRONT_BIRD)
