@@ -116,7 +116,10 @@ int fb_orb_extract(fb_orb *h, const uint8_t *image, int width, int height, int s
 /* same, `batch` equally sized images resident in HBM; image b starts at
  * d_images + b*image_stride.  Outputs: d_keypoints[batch][cap],
  * d_descriptors[batch][cap][32], d_n[batch], cap = fb_orb_capacity(); d_n[b] is
- * clamped to cap (asynchronous call: no error channel for the overflow above).  */
+ * clamped to cap (asynchronous call: no error channel for the overflow above).
+ * Stream semantics: everything is ordered after the work already in `stream` and is complete for work enqueued to
+ * `stream` afterwards.  Calls of 64 images or more run one kernel on a stream the handle owns, forked from and joined
+ * back into `stream` with events inside the call (legal under stream capture as well).  */
 int fb_orb_extract_batch_dev(fb_orb *h, const uint8_t *d_images, int batch, int width, int height,
                              int stride, size_t image_stride, fb_keypoint *d_keypoints,
                              uint8_t *d_descriptors, int32_t *d_n, void *stream);
