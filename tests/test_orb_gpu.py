@@ -165,3 +165,39 @@ def test_batch_of_72_images_takes_the_side_stream_and_matches_single_image_calls
             np.testing.assert_array_equal(desc[b, : n[b]], d1)
     finally:
         orb.close()
+
+
+def test_batch_extraction_with_the_side_stream_can_be_captured_in_a_graph():
+    # fishbird.h: the fork / join of the side stream is legal under stream capture; the replayed graph gives the same bytes
+    import torch
+    B, w, h = 64, 256, 192
+    p = O.orb_params(nfeatures=300)
+    imgs = np.stack([synth.synth_image(4200 + i, w, h) for i in range(B)])
+    orb = H.Orb(p)
+    try:
+        dev = torch.device("cuda:0")
+        d_img = torch.from_numpy(imgs.reshape(-1)).to(dev)
+        d_kps = torch.zeros(B * orb.cap * cabi.KP_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        d_desc = torch.zeros(B * orb.cap * 32, dtype=torch.uint8, device=dev)
+        d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+
+        def call(stream):
+            fb.check(fb.lib().fb_orb_extract_batch_dev(orb.h, C.c_void_p(d_img.data_ptr()), B, w, h, w, C.c_size_t(w * h),
+                                                       C.c_void_p(d_kps.data_ptr()), C.c_void_p(d_desc.data_ptr()),
+                                                       C.c_void_p(d_n.data_ptr()), C.c_void_p(stream.cuda_stream)), "extract batch")
+
+        st = torch.cuda.Stream()
+        call(st)  # direct call (also creates the side stream and its events)
+        st.synchronize()
+        ref = (d_n.clone(), d_kps.clone(), d_desc.clone())
+        assert int(ref[0].min()) > 50
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            call(torch.cuda.current_stream())
+        for t in (d_n, d_kps, d_desc):
+            t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(d_n, ref[0]) and torch.equal(d_desc, ref[2]) and torch.equal(d_kps, ref[1])
+    finally:
+        orb.close()
