@@ -107,3 +107,15 @@ def test_pose_opt_batch_of_64_takes_the_throughput_kernel():
     probs = [synth.make_pose_problem(3300 + i, n_front=260 + 7 * (i % 9), n_bird=120 + 5 * (i % 7)) for i in range(64)]
     out_o, out_h = _run(probs, mode=cabi.FB_POSE_FRONT_BIRD)
     _compare(out_o, out_h, cabi.FB_POSE_FRONT_BIRD)
+
+
+@pytest.mark.parametrize("batch", [2, 64])
+def test_pose_opt_more_edges_than_register_slots(batch):
+    """Frames with more edges than the register kernels hold (2240 + 1344 in k_pose_opt_split, 2560 + 1536 in
+    k_pose_opt_reg<256>) leave through the in-kernel generic schedule (edges re-read from HBM); e.g. the 4000-feature
+    initialisation extractor.  A batch of 64 mixes them with ordinary frames."""
+    big = [synth.make_pose_problem(3400, n_front=3100, n_bird=300), synth.make_pose_problem(3401, n_front=900, n_bird=1700)]
+    small = [synth.make_pose_problem(3410 + i, n_front=200 + 11 * (i % 5), n_bird=90 + 3 * (i % 4)) for i in range(batch - 2)]
+    probs = small[: len(small) // 2] + [big[0]] + small[len(small) // 2:] + [big[1]]
+    out_o, out_h = _run(probs, mode=cabi.FB_POSE_FRONT_BIRD)
+    _compare(out_o, out_h, cabi.FB_POSE_FRONT_BIRD)
