@@ -6,10 +6,11 @@ import numpy as np
 import hip_lib as H, oracle_lib as O
 from fishbirdeyevisualslam_amd import cabi, problems as P, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8   # problems per call: 64 or more run k_pose_opt_reg<256>, fewer k_pose_opt_split
 bad = 0; worst = 0.0
 for mode in (cabi.FB_POSE_FRONT_BIRD, cabi.FB_POSE_FRONT, cabi.FB_POSE_BIRD):
-    for s0 in range(0, n, 8):
-        probs = [synth.make_pose_problem(7000 + s0 + i, n_front=500 + 37 * ((s0 + i) % 40), n_bird=200 + 19 * ((s0 + i) % 40)) for i in range(8)]
+    for s0 in range(0, n, B):
+        probs = [synth.make_pose_problem(7000 + s0 + i, n_front=500 + 37 * ((s0 + i) % 40), n_bird=200 + 19 * ((s0 + i) % 40)) for i in range(B)]
         a, oo, k = P.pose_args(probs, mode=mode); O.call("orc_pose_opt", a)
         a2, oh, k2 = P.pose_args(probs, mode=mode); H.call("fb_pose_opt", a2)
         To, Th = oo["Tcw"].reshape(-1, 3, 4), oh["Tcw"].reshape(-1, 3, 4)
@@ -19,4 +20,4 @@ for mode in (cabi.FB_POSE_FRONT_BIRD, cabi.FB_POSE_FRONT, cabi.FB_POSE_BIRD):
         if not same or rel > 1e-4:
             bad += 1
             print("MISMATCH mode", mode, "seeds", 7000 + s0, "rel", rel, flush=True)
-print("pose sweep: %d problems x 3 modes, %d mismatching batches, worst relative pose difference %.3g" % (n, bad, worst))
+print("pose sweep: %d problems x 3 modes in calls of %d, %d mismatching batches, worst relative pose difference %.3g" % (n, B, bad, worst))
