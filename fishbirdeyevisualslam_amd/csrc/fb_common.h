@@ -29,6 +29,7 @@ int check_device();  // FB_OK or FB_ERR_NODEVICE (sets error)
     hipError_t e_ = (expr);                                                            \
     if (e_ != hipSuccess) {                                                            \
       fb::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+      (void)hipGetLastError(); /* the runtime also remembers it: a later hipGetLastError() must not report it again */ \
       return FB_ERR_HIP;                                                               \
     }                                                                                  \
   } while (0)

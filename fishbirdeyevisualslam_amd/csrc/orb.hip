@@ -764,35 +764,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TP == 44 ? F
 // (modelled as creation sequence in the oracle).  Each round: count keypoints per child
 // quadrant (LDS atomics), rebuild the list with block scans, remap the keypoints.
 // ------------------------------------------------------------------------------------------
-// The split point of a node (DivideNode, ORBextractor.cc:481-487: halfX = ceil((UR.x - UL.x) / 2)) is computed once, when the
-// node is made, and kept next to its count in level coordinates (+ BORDER): the two passes over the candidates of every round
-// then read 8 bytes per candidate and compare -- they are most of the kernel's instructions.
-struct alignas(8) ONode {
+struct ONode {
   short x0, y0, x1, y1;
-  short mxB, myB;  // x0 + halfX + BORDER, y0 + halfY + BORDER
   int cnt;
 };
 
-__device__ __forceinline__ void set_split_point(ONode &n) {
+__device__ __forceinline__ int quadrant(const ONode &n, int rx, int ry) {
   const int halfX = (int)ceilf((float)(n.x1 - n.x0) / 2), halfY = (int)ceilf((float)(n.y1 - n.y0) / 2);
-  n.mxB = (short)(n.x0 + halfX + BORDER);
-  n.myB = (short)(n.y0 + halfY + BORDER);
-}
-
-// x, y: level coordinates of the candidate as k_fast packs them (not yet minus BORDER)
-__device__ __forceinline__ int quadrant(const ONode &n, int x, int y) {
-  return (x < n.mxB ? 0 : 1) + (y < n.myB ? 0 : 2);  // n1=0 (UL), n2=1 (UR), n3=2 (BL), n4=3 (BR)
+  const int mx = n.x0 + halfX, my = n.y0 + halfY;
+  return (rx < mx ? 0 : 1) + (ry < my ? 0 : 2);  // n1=0 (UL), n2=1 (UR), n3=2 (BL), n4=3 (BR)
 }
 
 __device__ __forceinline__ ONode child_of(const ONode &n, int q, int cnt) {
-  const int mx = n.mxB - BORDER, my = n.myB - BORDER;
+  const int halfX = (int)ceilf((float)(n.x1 - n.x0) / 2), halfY = (int)ceilf((float)(n.y1 - n.y0) / 2);
+  const int mx = n.x0 + halfX, my = n.y0 + halfY;
   ONode c;
-  c.x0 = (short)((q & 1) ? mx : n.x0);
-  c.x1 = (short)((q & 1) ? n.x1 : mx);
-  c.y0 = (short)((q & 2) ? my : n.y0);
-  c.y1 = (short)((q & 2) ? n.y1 : my);
+  c.x0 = (q & 1) ? mx : n.x0;
+  c.x1 = (q & 1) ? n.x1 : mx;
+  c.y0 = (q & 2) ? my : n.y0;
+  c.y1 = (q & 2) ? n.y1 : my;
   c.cnt = cnt;
-  set_split_point(c);
   return c;
 }
 
@@ -872,7 +863,6 @@ __global__ __launch_bounds__(NT) void k_octree(OrbK K, const uint32_t *__restric
     nd.x0 = (short)(int)(Lv.hX * (float)i);
     nd.x1 = (short)(int)(Lv.hX * (float)(i + 1));
     nd.y0 = 0; nd.y1 = (short)Hh; nd.cnt = 0;
-    set_split_point(nd);
     listB[i] = nd;
   }
   __syncthreads();
@@ -908,7 +898,7 @@ __global__ __launch_bounds__(NT) void k_octree(OrbK K, const uint32_t *__restric
       int pk[4];
       uint32_t ck[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { const uint32_t kk = (uint32_t)min(k0 + u * NT, n - 1); pk[u] = nof[kk]; ck[u] = cd[kk]; }
+      for (int u = 0; u < 4; u++) { const int kk = min(k0 + u * NT, n - 1); pk[u] = nof[kk]; ck[u] = cd[kk]; }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         if (k0 + u * NT >= n) break;
@@ -916,7 +906,7 @@ __global__ __launch_bounds__(NT) void k_octree(OrbK K, const uint32_t *__restric
         const ONode nd = cur[p];
         if (nd.cnt > 1) {
           const uint32_t c = ck[u];
-          atomicAdd(&ccnt[4 * p + quadrant(nd, (int)(c & 0xFFF), (int)((c >> 12) & 0xFFF))], 1);
+          atomicAdd(&ccnt[4 * p + quadrant(nd, (int)(c & 0xFFF) - BORDER, (int)((c >> 12) & 0xFFF) - BORDER)], 1);
         }
       }
     }
@@ -1020,7 +1010,7 @@ __global__ __launch_bounds__(NT) void k_octree(OrbK K, const uint32_t *__restric
       int pk[4];
       uint32_t ck[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { const uint32_t kk = (uint32_t)min(k0 + u * NT, n - 1); pk[u] = nof[kk]; ck[u] = cd[kk]; }
+      for (int u = 0; u < 4; u++) { const int kk = min(k0 + u * NT, n - 1); pk[u] = nof[kk]; ck[u] = cd[kk]; }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int k = k0 + u * NT;
@@ -1028,7 +1018,7 @@ __global__ __launch_bounds__(NT) void k_octree(OrbK K, const uint32_t *__restric
         const int p = pk[u];
         if (split[p]) {
           const uint32_t c = ck[u];
-          nof[k] = cpos[4 * p + quadrant(cur[p], (int)(c & 0xFFF), (int)((c >> 12) & 0xFFF))];
+          nof[k] = cpos[4 * p + quadrant(cur[p], (int)(c & 0xFFF) - BORDER, (int)((c >> 12) & 0xFFF) - BORDER)];
         } else nof[k] = npos[p];
       }
     }
@@ -1058,7 +1048,7 @@ __global__ __launch_bounds__(NT) void k_octree(OrbK K, const uint32_t *__restric
     int pk[4];
     uint32_t ck[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const uint32_t kk = (uint32_t)min(k0 + u * NT, n - 1); pk[u] = nof[kk]; ck[u] = cd[kk]; }
+    for (int u = 0; u < 4; u++) { const int kk = min(k0 + u * NT, n - 1); pk[u] = nof[kk]; ck[u] = cd[kk]; }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
     const int k = k0 + u * NT;
@@ -1625,7 +1615,9 @@ int prepare(fb_orb *o, int w, int h, int batch) {
     for (int l = 0; l < p.nlevels; l++) maxCells = std::max(maxCells, (size_t)K.L[l].nCols * K.L[l].nRows);
     lds = std::max(lds, (maxCells + 1) * 4 + 16);  // the per-cell offsets of the packing prologue alias the node lists
   }
-  if (lds > 160 * 1024) { fb::set_error("nfeatures too large for the LDS quadtree (%zu B)", lds); return FB_ERR_CAPACITY; }
+  // (512 B of the 160 KB are left to the kernel's static LDS: scan scratch and a few scalars; with the dynamic part alone
+  // at the limit hipFuncSetAttribute refuses the size, a HIP error instead of this documented refusal)
+  if (lds > 160 * 1024 - 512) { fb::set_error("nfeatures too large for the LDS quadtree (%zu B)", lds); return FB_ERR_CAPACITY; }
   o->octreeLds = lds;
   FB_TRY(o->tabs.upload(tabBytes.data(), tabBytes.size()));
   for (int l = 1; l < p.nlevels; l++) {

@@ -201,3 +201,17 @@ def test_batch_extraction_with_the_side_stream_can_be_captured_in_a_graph():
         assert torch.equal(d_n, ref[0]) and torch.equal(d_desc, ref[2]) and torch.equal(d_kps, ref[1])
     finally:
         orb.close()
+
+
+@pytest.mark.parametrize("nf", [2363, 2660, 2700, 3000])
+def test_single_level_with_many_features_is_extracted_or_refused_as_capacity(nf):
+    # all features on one level: the quadtree's node lists approach the 160 KB of LDS.  Below the limit the result is the
+    # oracle's; above it the call is refused with the documented capacity message -- never with a HIP error (the fuzz probe
+    # once hit a size the host check let through and hipFuncSetAttribute refused), and the next call works
+    p = O.orb_params(nfeatures=nf, nlevels=1, scale_factor=1.759)
+    img = synth.synth_image(77, 501, 431)
+    try:
+        _check_image(p, img, stagewise=False)
+    except fb.FishbirdError as e:
+        assert "(-3)" in str(e) and "nfeatures too large for the LDS quadtree" in str(e), str(e)
+    _check_image(O.orb_params(nfeatures=300), synth.synth_image(78, 200, 160), stagewise=False)
