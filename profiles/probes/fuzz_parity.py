@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised HIP-vs-oracle parity sweep (ORB extraction on odd sizes / parameters, windowed matchers on odd counts).
-Not part of the test suite: a few hundred random cases, prints every mismatch.  usage: fuzz_parity.py [seconds]"""
+Not part of the test suite: a few hundred random cases, prints every mismatch.  usage: fuzz_parity.py [seconds [seed]]"""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
@@ -8,7 +8,7 @@ import hip_lib as H, oracle_lib as O
 from fishbirdeyevisualslam_amd import kf_problems as KP, more_problems as M, problems as P, synth
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-g = np.random.default_rng(12345)
+g = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 t_end = time.time() + budget
 n_cases = n_bad = 0
 exc_count = {}
