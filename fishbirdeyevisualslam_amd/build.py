@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libfishbird_hip.so")
-SOURCES = ["runtime.hip", "match.hip", "match_bow.hip", "frame.hip", "bow.hip", "orb.hip", "pose.hip", "ba.hip"]
+SOURCES = ["runtime.hip", "match.hip", "match_bow.hip", "frame.hip", "track.hip", "bow.hip", "orb.hip", "pose.hip", "ba.hip"]
 # Files whose results are held to a floating-point tolerance (poses: 1e-4 relative), not to bit equality with the
 # oracle: fused multiply-adds are allowed there.  An LM evaluation of k_pose_opt is ~75 % fp64 edge arithmetic that one
 # wave per SIMD issues back to back; mul + add pairs instead of fma made it a quarter longer.

@@ -232,6 +232,37 @@ class LocalBAArgs(C.Structure):
                 ("stop_flag", _vp), ("obs_outlier", _vp), ("bobs_outlier", _vp)]
 
 
+class FrameParams(C.Structure):
+    _fields_ = [("batch", _i32), ("front_width", _i32), ("front_height", _i32), ("bird_width", _i32), ("bird_height", _i32),
+                ("orb", OrbParams), ("K", _f32 * 4), ("D", _f32 * 4), ("Tbc", _f32 * 12), ("Tcb", _f32 * 12),
+                ("pixel2meter", C.c_double), ("meter2pixel", C.c_double), ("rear_axle_to_center", C.c_double),
+                ("map_cap", _i32), ("local_mp_cap", _i32), ("local_mpb_cap", _i32)]
+
+
+class MapPoints(C.Structure):
+    _fields_ = [("stride", _i32), ("n", _vp), ("bad", _vp), ("obs_pos", _vp), ("xw", _vp), ("normal", _vp),
+                ("max_dist", _vp), ("min_dist", _vp), ("desc", _vp)]
+
+
+class MapPointsBird(C.Structure):
+    _fields_ = [("stride", _i32), ("n", _vp), ("xw", _vp), ("desc", _vp)]
+
+
+class TrackArgs(C.Structure):
+    _fields_ = [("map", MapPoints), ("mpb", MapPointsBird), ("d_delta", _vp), ("d_local_mp", _vp), ("d_n_local_mp", _vp),
+                ("d_local_mpb", _vp), ("d_n_local_mpb", _vp), ("wB", _f32), ("wF", _f32)]
+
+
+class FrameView(C.Structure):
+    _fields_ = [("batch", _i32), ("kp_stride", _i32), ("n", _vp), ("kps", _vp), ("kps_un", _vp), ("desc", _vp),
+                ("map_point", _vp), ("outlier", _vp), ("n_bird", _vp), ("kps_bird", _vp), ("desc_bird", _vp),
+                ("bird_cam_xyz", _vp), ("map_point_bird", _vp), ("bird_outlier", _vp), ("Tcw", _vp), ("counts", _vp)]
+
+
+FB_CNT = dict(BIRD_KF_MATCHES=0, PROJ_MATCHES=1, POSE1_INLIERS=2, MATCHES=3, MATCHES_MAP=4, BIRDVIEW_MATCHES=5, BIRD_INLIERS=6,
+              BIRD_NEW=7, TO_MATCH=8, LOCAL_MATCHES=9, POSE2_INLIERS=10, MATCHES_INLIERS=11)
+FB_CNT_COUNT = 16
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), _i32, _i32)
 
 
@@ -270,5 +301,10 @@ EXPORTS = [
     "fb_bird_filter_matches_dev", "fb_bird_filter_matches", "fb_bow_transform_dev", "fb_bow_transform",
     "fb_in_frustum_dev", "fb_in_frustum", "fb_undistort_keypoints_dev", "fb_undistort_keypoints", "fb_image_bounds",
     "fb_pose_opt_batch_dev", "fb_pose_opt", "fb_pose_gather_front_dev", "fb_pose_gather_bird_dev",
+    "fb_frame_create", "fb_frame_destroy", "fb_frame_extract_dev", "fb_frame_extract", "fb_frame_set_pose_dev",
+    "fb_frame_predict_pose_dev", "fb_frame_clear_map_points_dev", "fb_frame_set_map_points_dev",
+    "fb_frame_bird_mappoint_match_dev", "fb_frame_search_by_projection_dev", "fb_frame_pose_optimization_dev",
+    "fb_frame_discard_outliers_dev", "fb_frame_match_bird_points_dev", "fb_frame_search_local_points_dev",
+    "fb_frame_finish_dev", "fb_frame_track_dev", "fb_frame_view_dev", "fb_frame_download", "fb_frame_counts",
     "fb_local_ba", "fb_local_ba_sharded", "fb_local_ba_sharded_rccl", "fb_rccl_get_unique_id", "fb_rccl_comm_init", "fb_rccl_comm_destroy", "fb_global_ba",
 ]

@@ -23,28 +23,12 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_in_frustum(fb_frustum_args A)
   A.in_view[e] = 0;
   if (A.mp_valid && !A.mp_valid[e]) return;
   const float *T = A.Tcw + (size_t)b * 12, *Ow = A.Ow + (size_t)b * 3;
-  const float P0 = A.mp_xw[e * 3], P1 = A.mp_xw[e * 3 + 1], P2 = A.mp_xw[e * 3 + 2];
-  const float PcX = ((T[0] * P0 + T[1] * P1) + T[2] * P2) + T[3];
-  const float PcY = ((T[4] * P0 + T[5] * P1) + T[6] * P2) + T[7];
-  const float PcZ = ((T[8] * P0 + T[9] * P1) + T[10] * P2) + T[11];
-  if (PcZ < 0.0f) return;
-  const float invz = 1.0f / PcZ;
-  const float u = A.cam.fx * PcX * invz + A.cam.cx;
-  const float v = A.cam.fy * PcY * invz + A.cam.cy;
-  if (u < A.cam.min_x || u > A.cam.max_x) return;
-  if (v < A.cam.min_y || v > A.cam.max_y) return;
-  const float maxD = A.mp_max_dist[e];
-  const float maxDistance = 1.2f * maxD, minDistance = 0.8f * A.mp_min_dist[e];
-  const float PO0 = P0 - Ow[0], PO1 = P1 - Ow[1], PO2 = P2 - Ow[2];
-  const float dist = fb::norm3(PO0, PO1, PO2);
-  if (dist < minDistance || dist > maxDistance) return;
-  double dot = 0.0;  // cv::Mat::dot accumulates CV_32F products in double
-  dot += (double)PO0 * (double)A.mp_normal[e * 3];
-  dot += (double)PO1 * (double)A.mp_normal[e * 3 + 1];
-  dot += (double)PO2 * (double)A.mp_normal[e * 3 + 2];
-  const float viewCos = (float)(dot / (double)dist);
-  if (viewCos < A.viewing_cos_limit) return;
-  const int lvl = fb::predict_scale(maxD, dist, A.log_scale_factor, A.n_levels);
+  fb::FrustumOut o;
+  if (!fb::in_frustum(T, Ow, A.cam, A.mp_xw[e * 3], A.mp_xw[e * 3 + 1], A.mp_xw[e * 3 + 2], A.mp_normal[e * 3], A.mp_normal[e * 3 + 1],
+                      A.mp_normal[e * 3 + 2], A.mp_max_dist[e], A.mp_min_dist[e], A.viewing_cos_limit, A.log_scale_factor, A.n_levels, o))
+    return;
+  const float u = o.u, v = o.v, invz = o.invz, viewCos = o.view_cos;
+  const int lvl = o.level;
   A.in_view[e] = 1;
   A.proj[e * 2] = u;
   A.proj[e * 2 + 1] = v;
@@ -63,11 +47,7 @@ __global__ __launch_bounds__(256) void k_bird_filter(fb_bird_filter_args A) {
   const int nm = A.n_matches[b];
   __shared__ float s_Twc1[12], s_T2[12];
   if (tid == 0) {
-    const float *T1 = A.Tcw1 + (size_t)b * 12;
-    for (int r = 0; r < 3; r++) {
-      for (int c = 0; c < 3; c++) s_Twc1[r * 4 + c] = T1[c * 4 + r];
-      s_Twc1[r * 4 + 3] = -((T1[0 * 4 + r] * T1[3] + T1[1 * 4 + r] * T1[7]) + T1[2 * 4 + r] * T1[11]);  // Converter::invT
-    }
+    fb::inv_T(A.Tcw1 + (size_t)b * 12, s_Twc1);
     for (int i = 0; i < 12; i++) s_T2[i] = A.Tcw2[(size_t)b * 12 + i];
   }
   for (int i = tid; i < A.kp2_stride; i += nt) s_first[i] = 0x7fffffff;
@@ -77,16 +57,7 @@ __global__ __launch_bounds__(256) void k_bird_filter(fb_bird_filter_args A) {
     bool pass = false;
     float ptw[3] = {0.f, 0.f, 0.f};
     if (!A.occupied2[o2 + ti]) {
-      const float *p1 = A.cam_xyz1 + (o1 + qi) * 3;
-      float pc2[3];
-#pragma unroll
-      for (int r = 0; r < 3; r++) ptw[r] = ((s_Twc1[r * 4] * p1[0] + s_Twc1[r * 4 + 1] * p1[1]) + s_Twc1[r * 4 + 2] * p1[2]) + s_Twc1[r * 4 + 3];
-#pragma unroll
-      for (int r = 0; r < 3; r++) pc2[r] = ((s_T2[r * 4] * ptw[0] + s_T2[r * 4 + 1] * ptw[1]) + s_T2[r * 4 + 2] * ptw[2]) + s_T2[r * 4 + 3];
-      const float *p2 = A.cam_xyz2 + (o2 + ti) * 3;
-      const float d0 = pc2[0] - p2[0], d1 = pc2[1] - p2[1], d2 = pc2[2] - p2[2];
-      const double disC = sqrt((double)d0 * d0 + (double)d1 * d1 + (double)d2 * d2);
-      pass = disC < (double)A.window_size;
+      pass = fb::bird_filter_test(s_Twc1, s_T2, A.cam_xyz1 + (o1 + qi) * 3, A.cam_xyz2 + (o2 + ti) * 3, A.window_size, ptw);
     }
     if (pass) {
       atomicMin(&s_first[ti], i);
@@ -147,7 +118,7 @@ __global__ __launch_bounds__(GUIDE_THREADS) void k_bird_guidance(fb_bird_guidanc
   extern __shared__ uint8_t s_keep[];  // [kp_stride]
   __shared__ int s_w[GUIDE_THREADS / 64];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int n = A.n_in[b];
+  const int n = min(max(A.n_in[b], 0), A.kp_stride);  // the LDS flag array and the output rows hold kp_stride entries
   const size_t ko = (size_t)b * A.kp_stride;
   const uint8_t *icp = A.contour + (size_t)b * A.rows * A.pitch;
   const uint8_t *mask = A.mask ? A.mask + (size_t)b * A.rows * A.pitch : nullptr;

@@ -717,6 +717,172 @@ int fb_pose_gather_bird_dev(int batch, int kp_stride, int mp_stride, const int32
 int fb_pose_opt(const fb_pose_opt_args *args); /* host pointers */
 
 /* ======================================================================== */
+/* Device-resident Frame and the per-frame tracking chain                    */
+/* (include/Frame.h, src/Frame.cc:262-379; src/Tracking.cc:1312-1441,690-746) */
+/* ======================================================================== */
+/* An fb_frame is the reference's Frame object for `batch` independent sequences, with every per-key-point member living
+ * in HBM: mvKeys / mvKeysUn / mDescriptors / mGrid / mvpMapPoints / mvbOutlier, their bird counterparts (mvKeysBird,
+ * mDescriptorsBird, mvKeysBirdCamXYZ, mGridBirdview, mvpMapPointsBird, mvBirdOutlier) and mTcw / mOw.  The entry points
+ * below take frames where the reference's ORBmatcher / Optimizer methods take Frame& / Frame*, so that consecutive calls
+ * (extract -> match -> optimise -> match -> optimise, and frame k -> frame k+1) hand their results over on the device.
+ * mvpMapPoints[i] / mvpMapPointsBird[i] are kept as int32 indices into the caller's map tables (-1 = NULL).
+ *
+ * All *_dev entry points only enqueue on `stream`; the return values of the reference functions (match / inlier counts)
+ * land in the frame's counter block, which fb_frame_counts reads back (one synchronisation per frame instead of one per
+ * call).  The Tracking state machine stays with the host: it reads the counters and decides on retries (Tracking.cc:1345),
+ * LOST handling and key-frame insertion.  One call at a time per frame handle.                                          */
+typedef struct fb_frame fb_frame;
+
+typedef struct fb_frame_params {
+  int32_t batch;                    /* sequences side by side; 1 = the reference's single Frame                        */
+  int32_t front_width, front_height, bird_width, bird_height;
+  fb_orb_params orb;                /* ORBextractor.* of the settings file: capacity and level tables (Frame.cc:299-306)  */
+  float K[4];                       /* Camera.fx, fy, cx, cy (Tracking.cc:61-75)                                        */
+  float D[4];                       /* Camera.k1, k2, p1, p2, fed to the fisheye model as k1..k4 (Frame.cc:657);
+                                       D[0] == 0: mvKeysUn = mvKeys (Frame.cc:640-644)                                  */
+  float Tbc[12], Tcb[12];           /* Frame::Tbc / Tcb rows 0..2 (CalculateExtrinsics, Frame.cc:1015-1037)             */
+  double pixel2meter, meter2pixel, rear_axle_to_center; /* Frame.cc:39-42                                               */
+  int32_t map_cap;                  /* largest fb_map_points.stride a call may pass (per-point "seen" flags)            */
+  int32_t local_mp_cap;             /* longest mvpLocalMapPoints list a call may pass (>= map stride for NULL lists)    */
+  int32_t local_mpb_cap;            /* longest vlocalMPB list (>= bird map stride for NULL lists)                       */
+} fb_frame_params;
+
+/* The caller's MapPoint table on the device (MapPoint getters; the Map itself stays with the host, which refreshes the
+ * entries LocalMapping changed).  An index into it is what a frame stores in mvpMapPoints.  [batch][stride] arrays.     */
+typedef struct fb_map_points {
+  int32_t stride;                   /* <= fb_frame_params.map_cap                                                       */
+  const int32_t *n;                 /* [batch] entries in use                                                           */
+  const uint8_t *bad;               /* isBad()                                                                          */
+  const uint8_t *obs_pos;           /* Observations() > 0                                                               */
+  const float *xw;                  /* [..][3] GetWorldPos()                                                            */
+  const float *normal;              /* [..][3] GetNormal()                                                              */
+  const float *max_dist, *min_dist; /* mfMaxDistance, mfMinDistance (the 1.2 / 0.8 factors are applied by the kernels)  */
+  const uint8_t *desc;              /* [..][32] GetDescriptor()                                                         */
+} fb_map_points;
+
+/* MapPointBird table.  FilterBirdOutlierInFront creates points (Tracking.cc:1896-1901): they are appended at n[b].     */
+typedef struct fb_map_points_bird {
+  int32_t stride;
+  int32_t *n;                       /* [batch] entries in use (in/out)                                                  */
+  float *xw;                        /* [..][3] GetWorldPos()                                                            */
+  uint8_t *desc;                    /* [..][32] mDescriptor                                                             */
+} fb_map_points_bird;
+
+/* slots of a frame's counter block */
+enum {
+  FB_CNT_BIRD_KF_MATCHES = 0, /* mnBirdKFMatches = BirdMapPointMatch(...)            Tracking.cc:2006                   */
+  FB_CNT_PROJ_MATCHES,        /* nmatches = SearchByProjection(cur, last)            Tracking.cc:1339                   */
+  FB_CNT_POSE1_INLIERS,       /* PoseOptimizationWithBird                            Tracking.cc:1353                   */
+  FB_CNT_MATCHES,             /* nmatches after the outlier discard                  Tracking.cc:1358-1376              */
+  FB_CNT_MATCHES_MAP,         /* nmatchesMap                                         Tracking.cc:1373                   */
+  FB_CNT_BIRDVIEW_MATCHES,    /* nmatchesBird = BirdviewMatch(...)                   Tracking.cc:2728                   */
+  FB_CNT_BIRD_INLIERS,        /* inlier of FilterBirdOutlierInFront                  Tracking.cc:1888                   */
+  FB_CNT_BIRD_NEW,            /* mnBirdLastFMatches = buildNew                       Tracking.cc:1913                   */
+  FB_CNT_TO_MATCH,            /* nToMatch of SearchLocalPoints                       Tracking.cc:1973-1982              */
+  FB_CNT_LOCAL_MATCHES,       /* SearchByProjection(cur, mvpLocalMapPoints, th)      Tracking.cc:1995                   */
+  FB_CNT_POSE2_INLIERS,       /* PoseOptimizationWithBird                            Tracking.cc:1400                   */
+  FB_CNT_MATCHES_INLIERS,     /* mnMatchesInliers                                    Tracking.cc:1411-1424              */
+  FB_CNT_COUNT = 16
+};
+
+int fb_frame_create(const fb_frame_params *params, fb_frame **out);
+void fb_frame_destroy(fb_frame *f);
+
+/* Frame::Frame(imGray, BirdGray, ..., birdviewmask, ..., birdviewContourICP, ...) (Frame.cc:262-379) on images in HBM:
+ * ExtractORB (front) -> UndistortKeyPoints -> bird extraction (ORBextractor, the E9 substitution) with the detect mask
+ * -> GuidenceKeyBirdPts on d_contour -> mvKeysBirdCamXYZ -> mvpMapPoints = NULL, mvbOutlier = false, mvpMapPointsBird =
+ * NULL, mvBirdOutlier = TRUE (:355-356) -> AssignFeaturesToGrid.  Image b starts b * image_stride bytes after the base;
+ * d_contour / d_mask have the bird image's geometry (rows of bird_stride bytes) and may be NULL (no filter / no mask).
+ * The bird chain runs on a stream the handle owns, forked from and joined back into `stream` inside the call.           */
+int fb_frame_extract_dev(fb_frame *f, fb_orb *front_extractor, fb_orb *bird_extractor, const uint8_t *d_front,
+                         int front_stride, size_t front_image_stride, const uint8_t *d_bird, int bird_stride,
+                         size_t bird_image_stride, const uint8_t *d_contour, const uint8_t *d_mask, void *stream);
+/* The same from HOST images (the reference's call): the images are copied through page-locked staging buffers the handle
+ * owns, asynchronously on `stream`; the call returns when the copies out of the caller's buffers are done, not when the
+ * kernels are (fb_frame_counts / fb_frame_download synchronise).  Images are tightly packed batch after batch.           */
+int fb_frame_extract(fb_frame *f, fb_orb *front_extractor, fb_orb *bird_extractor, const uint8_t *front, int front_stride,
+                     const uint8_t *bird, int bird_stride, const uint8_t *contour, const uint8_t *mask, void *stream);
+
+/* Frame::SetPose(Tcw) + UpdatePoseMatrices (Frame.cc:421-433): d_Tcw [batch][12] device.                                */
+int fb_frame_set_pose_dev(fb_frame *f, const float *d_Tcw, void *stream);
+/* mCurrentFrame.SetPose(detlaT * mLastFrame.mTcw) (Tracking.cc:1314-1320): d_delta [batch][12] = rows 0..2 of detlaT.   */
+int fb_frame_predict_pose_dev(fb_frame *cur, const fb_frame *last, const float *d_delta, void *stream);
+/* fill(mvpMapPoints, NULL) (Tracking.cc:1330,1344)                                                                       */
+int fb_frame_clear_map_points_dev(fb_frame *f, void *stream);
+/* A frame that enters the chain without having been tracked (the first one after initialisation): sets mvpMapPoints /
+ * mvpMapPointsBird from host-built index arrays [batch][fb_orb_capacity] (device), mvbOutlier = false.                  */
+int fb_frame_set_map_points_dev(fb_frame *f, const int32_t *d_map_point, const int32_t *d_map_point_bird, void *stream);
+
+/* BirdMapPointMatch(CurF, vlocalMPB, windowSize, filterSize) (ORBmatcher.cc:1763-1902, Tracking.cc:1999-2012; M9).
+ * d_local [batch][params.local_mpb_cap] lists vlocalMPB as indices into `mpb`, d_n_local [batch] their counts; NULL
+ * lists = the whole table in index order.  Tracking.cc:2004: the call is skipped (count 0) unless the list has > 10
+ * entries.                                                                                                              */
+int fb_frame_bird_mappoint_match_dev(fb_frame *cur, const fb_map_points_bird *mpb, const int32_t *d_local,
+                                     const int32_t *d_n_local, int window_size, float filter_size,
+                                     const fb_matcher_params *matcher, void *stream);
+/* SearchByProjection(CurrentFrame, LastFrame, th, bMono = true) (ORBmatcher.cc:1329-1471; M3)                           */
+int fb_frame_search_by_projection_dev(fb_frame *cur, const fb_frame *last, const fb_map_points *map, float th,
+                                      const fb_matcher_params *matcher, void *stream);
+/* PoseOptimization / PoseOptimizationWithBird / BirdOptimization(pFrame) (Optimizer.cc:246-835), mode FB_POSE_*.
+ * which = 0 writes FB_CNT_POSE1_INLIERS, 1 writes FB_CNT_POSE2_INLIERS.                                                 */
+int fb_frame_pose_optimization_dev(fb_frame *f, const fb_map_points *map, const fb_map_points_bird *mpb, int mode,
+                                   float wB, float wF, int which, void *stream);
+/* "Discard outliers" of TrackWithMotionModel (Tracking.cc:1358-1376)                                                     */
+int fb_frame_discard_outliers_dev(fb_frame *f, const fb_map_points *map, void *stream);
+/* GetPerFrameMatchedBirdPoints (Tracking.cc:2724-2733): BirdviewMatch(cur, ref keys / descriptors, ..., 0, window)
+ * (M8) followed by the whole of FilterBirdOutlierInFront(ref, cur, matches, filter_size) (:1825-1914), bookkeeping
+ * included: cur.mvBirdOutlier[train] = false, cur.mvpMapPointsBird[train] = ref's point or a NEW MapPointBird (appended
+ * to `mpb` with position ptwC and cur's descriptor) that ref.mvpMapPointsBird[query] receives as well.                  */
+int fb_frame_match_bird_points_dev(fb_frame *cur, fb_frame *ref, fb_map_points_bird *mpb, int window_size,
+                                   float filter_size, const fb_matcher_params *matcher, void *stream);
+/* SearchLocalPoints (Tracking.cc:1947-1997): points the frame already holds are marked seen, isInFrustum(pMP, 0.5) on the
+ * others of mvpLocalMapPoints (d_local: indices into `map`, [batch][params.local_mp_cap]; NULL = the whole table), then
+ * SearchByProjection(cur, mvpLocalMapPoints, th) (ORBmatcher.cc:46-130; M2) if anything is to be matched.               */
+int fb_frame_search_local_points_dev(fb_frame *f, const fb_map_points *map, const int32_t *d_local,
+                                     const int32_t *d_n_local, float th, const fb_matcher_params *matcher, void *stream);
+/* End of Tracking::Track for a tracked frame (Tracking.cc:1411-1424 mnMatchesInliers; :690-701 clean VO matches;
+ * :721-725 mvpMapPoints[i] = NULL for outliers) -- after it the frame is what mLastFrame = Frame(mCurrentFrame) copies. */
+int fb_frame_finish_dev(fb_frame *f, const fb_map_points *map, void *stream);
+
+/* The OK-state path of Tracking::Track in one call: TrackWithMotionModel (Tracking.cc:1312-1385) + TrackLocalMap
+ * (:1387-1441) + the end-of-Track clean-up, i.e. predict_pose, M9, M3 (th = 15), PoseOptimizationWithBird, discard,
+ * M8 + filter (window 10, 0.05 m), SearchLocalPoints (th = 1, nnratio 0.8), PoseOptimizationWithBird, finish --
+ * optimistically: the host checks the counters afterwards (nmatches < 20 -> its own retry with 2 * th, :1342-1349).     */
+typedef struct fb_track_args {
+  fb_map_points map;
+  fb_map_points_bird mpb;
+  const float *d_delta;             /* [batch][12] detlaT                                                               */
+  const int32_t *d_local_mp, *d_n_local_mp;   /* mvpLocalMapPoints (NULL = whole table)                                 */
+  const int32_t *d_local_mpb, *d_n_local_mpb; /* vlocalMPB (NULL = whole table)                                         */
+  float wB, wF;                     /* Optimizer.h:52 defaults 1, 1                                                     */
+} fb_track_args;
+int fb_frame_track_dev(fb_frame *cur, fb_frame *last, const fb_track_args *args, void *stream);
+
+/* Pointers to a frame's arrays: device pointers from fb_frame_view_dev (valid for the handle's lifetime, for harnesses
+ * that keep working on the device), or host buffers the caller hands to fb_frame_download (NULL members are skipped).
+ * kp_stride = fb_orb_capacity(params.orb).                                                                             */
+typedef struct fb_frame_view {
+  int32_t batch, kp_stride;
+  int32_t *n;                       /* [batch] N                                                                        */
+  fb_keypoint *kps, *kps_un;        /* mvKeys, mvKeysUn                                                                 */
+  uint8_t *desc;                    /* mDescriptors                                                                     */
+  int32_t *map_point;               /* mvpMapPoints as table index, -1 = NULL                                           */
+  uint8_t *outlier;                 /* mvbOutlier                                                                       */
+  int32_t *n_bird;                  /* [batch] Nbird                                                                    */
+  fb_keypoint *kps_bird;            /* mvKeysBird                                                                       */
+  uint8_t *desc_bird;               /* mDescriptorsBird                                                                 */
+  float *bird_cam_xyz;              /* mvKeysBirdCamXYZ                                                                 */
+  int32_t *map_point_bird;          /* mvpMapPointsBird                                                                 */
+  uint8_t *bird_outlier;            /* mvBirdOutlier                                                                    */
+  float *Tcw;                       /* [batch][12]                                                                      */
+  int32_t *counts;                  /* [FB_CNT_COUNT][batch] (slot-major: every kernel writes one contiguous row)      */
+} fb_frame_view;
+int fb_frame_view_dev(fb_frame *f, fb_frame_view *out);
+int fb_frame_download(fb_frame *f, const fb_frame_view *host, void *stream); /* synchronises `stream`                  */
+int fb_frame_counts(fb_frame *f, int32_t *host_counts /* [FB_CNT_COUNT][batch] */, float *host_Tcw /* [batch][12] or NULL */,
+                    void *stream);                                              /* synchronises `stream`                 */
+
+/* ======================================================================== */
 /* Optimizer::LocalBundleAdjustment / LocalBundleAdjustmentWithOdom          */
 /* (src/Optimizer.cc:838-1165, 2137-2670)                                    */
 /* ======================================================================== */

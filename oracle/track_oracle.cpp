@@ -1,0 +1,475 @@
+/*
+ * track_oracle.cpp -- CPU restatement of the per-frame tracking chain (TEST INFRASTRUCTURE ONLY; see orb_oracle.cpp
+ * header for who may call it).  Parity unpinned: the reference holds no fixture for this path, and the OpenCV pieces
+ * inside the steps are restated.
+ *
+ * A host-side Frame (orc_frame) with the members the chain touches, and the sequence the reference runs per tracked
+ * frame, serially and in the reference's loop order:
+ *   Frame::Frame(...)                  /root/reference/src/Frame.cc:262-379
+ *   Tracking::TrackWithMotionModel     /root/reference/src/Tracking.cc:1312-1385
+ *   Tracking::TrackLocalMap            :1387-1441 with GetPerFrameMatchedBirdPoints :2724-2733,
+ *                                      FilterBirdOutlierInFront :1825-1914, SearchLocalPoints :1947-1997,
+ *                                      GetLocalMapForBird :1999-2012
+ *   end of Tracking::Track             :690-701 (clean VO matches), :721-725 (drop outliers)
+ * mvpMapPoints / mvpMapPointsBird are indices into the caller's map tables (-1 = NULL), like the product's fb_frame.
+ * The matchers / extractor / optimiser called in between are the other files of this oracle.
+ */
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../include/fishbird.h"
+
+extern "C" {
+int orc_orb_tables(const fb_orb_params *p, fb_orb_tables *out);
+int orc_orb_extract(const fb_orb_params *p, const uint8_t *img, int w, int h, int stride, fb_keypoint *kps, uint8_t *desc, int32_t *n);
+int orc_undistort_keypoints(const fb_keypoint *kps, int n, const float *K4, const float *D4, fb_keypoint *out);
+int orc_image_bounds(int cols, int rows, const float *K4, const float *D4, float *bounds);
+int orc_bird_guidance(const fb_bird_guidance_args *A);
+int orc_bird_keys_to_cam(const fb_keypoint *kps, const int32_t *n, int batch, int kp_stride, int bird_cols, int bird_rows,
+                         double pixel2meter, double rear_axle_to_center, const float *Tcb12, float *cam_xyz);
+int orc_grid_build(const fb_keypoint *kps, const int32_t *n, int batch, int kp_stride, const fb_grid_geom *g, int32_t *cs, int32_t *ci);
+int orc_match_bird_mappoints(const fb_bird_mp_args *A);
+int orc_match_projection_frame(const fb_proj_frame_args *A);
+int orc_match_projection_points(const fb_proj_points_args *A);
+int orc_match_birdview(const fb_birdview_args *A);
+int orc_in_frustum(const fb_frustum_args *A);
+int orc_pose_opt(const fb_pose_opt_args *A);
+}
+
+struct orc_frame {
+  fb_frame_params P;
+  int cap, B;
+  fb_orb_tables tab;
+  fb_grid_geom gF, gB;
+  fb_camera cam;
+  float logScale;
+  std::vector<int32_t> n, nb, mp, mpb, cs, ci, bcs, bci, counts;
+  std::vector<fb_keypoint> kps, kps_un, bkps;
+  std::vector<uint8_t> desc, bdesc, outlier, boutlier;
+  std::vector<float> bcam, Tcw;
+  double stage_s[8];  // seconds inside each stage of the last orc_frame_extract / orc_frame_track call
+};
+
+namespace {
+
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int *cnt(orc_frame *f, int slot) { return f->counts.data() + (size_t)slot * f->B; }
+
+// Edge construction of PoseOptimizationWithBird (Optimizer.cc:525-602) from the frame's members, then the optimiser
+void pose_optimization(orc_frame *f, const fb_map_points *map, const fb_map_points_bird *mpb, int mode, float wB, float wF, int slot) {
+  const size_t B = f->B, cap = f->cap;
+  std::vector<float> fxw(B * cap * 3), fobs(B * cap * 2), finf(B * cap), bxw(B * cap * 3), bxc(B * cap * 3), binf(B * cap);
+  std::vector<uint8_t> fv(B * cap, 0), bv(B * cap, 0);
+  for (size_t b = 0; b < B; b++) {
+    for (int i = 0; i < f->n[b]; i++) {
+      const size_t o = b * cap + i;
+      const int id = f->mp[o];
+      if (id < 0) continue;
+      const fb_keypoint &kpUn = f->kps_un[o];
+      fv[o] = 1;
+      for (int k = 0; k < 3; k++) fxw[o * 3 + k] = map->xw[(b * map->stride + id) * 3 + k];
+      fobs[o * 2] = kpUn.x; fobs[o * 2 + 1] = kpUn.y;
+      finf[o] = f->tab.inv_level_sigma2[kpUn.octave];
+    }
+    for (int i = 0; i < f->nb[b]; i++) {
+      const size_t o = b * cap + i;
+      const int id = f->mpb[o];
+      if (id < 0) continue;
+      bv[o] = 1;
+      for (int k = 0; k < 3; k++) { bxw[o * 3 + k] = mpb->xw[(b * mpb->stride + id) * 3 + k]; bxc[o * 3 + k] = f->bcam[o * 3 + k]; }
+      binf[o] = f->tab.inv_level_sigma2[f->bkps[o].octave];
+    }
+  }
+  fb_pose_opt_args A;
+  std::memset(&A, 0, sizeof(A));
+  A.batch = f->B; A.mode = mode; A.front_stride = f->cap; A.bird_stride = f->cap;
+  A.fx = f->P.K[0]; A.fy = f->P.K[1]; A.cx = f->P.K[2]; A.cy = f->P.K[3]; A.wF = wF; A.wB = wB;
+  A.n_front = f->n.data(); A.front_xw = fxw.data(); A.front_obs = fobs.data(); A.front_inv_sigma2 = finf.data(); A.front_valid = fv.data();
+  A.n_bird = f->nb.data(); A.bird_xw = bxw.data(); A.bird_xc = bxc.data(); A.bird_inv_sigma2 = binf.data(); A.bird_valid = bv.data();
+  A.bird_outlier = f->boutlier.data(); A.Tcw = f->Tcw.data(); A.front_outlier = f->outlier.data(); A.ninliers = cnt(f, slot);
+  orc_pose_opt(&A);
+}
+
+}  // namespace
+
+extern "C" {
+
+int orc_frame_create(const fb_frame_params *p, orc_frame **out) {
+  orc_frame *f = new orc_frame();
+  f->P = *p;
+  f->B = p->batch;
+  f->cap = p->orb.nfeatures + 8 * p->orb.nlevels;
+  orc_orb_tables(&p->orb, &f->tab);
+  f->logScale = (float)std::log((double)p->orb.scale_factor);  // Frame.cc:301
+  float bounds[4];
+  orc_image_bounds(p->front_width, p->front_height, p->K, p->D, bounds);  // Frame.cc:271-277
+  f->gF.min_x = bounds[0]; f->gF.min_y = bounds[2];
+  f->gF.inv_w = 64.0f / (bounds[1] - bounds[0]);
+  f->gF.inv_h = 48.0f / (bounds[3] - bounds[2]);
+  f->gF.cols = 64; f->gF.rows = 48;
+  f->gB.min_x = 0.f; f->gB.min_y = 0.f;
+  f->gB.inv_w = 32.0f / (float)p->bird_width;  // Frame.cc:282-283
+  f->gB.inv_h = 32.0f / (float)p->bird_height;
+  f->gB.cols = 32; f->gB.rows = 32;
+  f->cam.fx = p->K[0]; f->cam.fy = p->K[1]; f->cam.cx = p->K[2]; f->cam.cy = p->K[3];
+  f->cam.min_x = bounds[0]; f->cam.max_x = bounds[1]; f->cam.min_y = bounds[2]; f->cam.max_y = bounds[3];
+  const size_t B = f->B, cap = f->cap;
+  f->n.assign(B, 0); f->nb.assign(B, 0);
+  f->mp.assign(B * cap, -1); f->mpb.assign(B * cap, -1);
+  f->cs.assign(B * (64 * 48 + 1), 0); f->ci.assign(B * cap, 0); f->bcs.assign(B * (32 * 32 + 1), 0); f->bci.assign(B * cap, 0);
+  f->counts.assign(B * FB_CNT_COUNT, 0);
+  f->kps.assign(B * cap, fb_keypoint{}); f->kps_un.assign(B * cap, fb_keypoint{}); f->bkps.assign(B * cap, fb_keypoint{});
+  f->desc.assign(B * cap * 32, 0); f->bdesc.assign(B * cap * 32, 0); f->outlier.assign(B * cap, 0); f->boutlier.assign(B * cap, 1);
+  f->bcam.assign(B * cap * 3, 0.f); f->Tcw.assign(B * 12, 0.f);
+  std::memset(f->stage_s, 0, sizeof(f->stage_s));
+  *out = f;
+  return FB_OK;
+}
+
+void orc_frame_destroy(orc_frame *f) { delete f; }
+
+// Frame::Frame (Frame.cc:262-379), host images packed batch after batch
+int orc_frame_extract(orc_frame *f, const uint8_t *front, int front_stride, const uint8_t *bird, int bird_stride,
+                      const uint8_t *contour, const uint8_t *mask) {
+  const size_t B = f->B, cap = f->cap;
+  const size_t fbytes = (size_t)front_stride * f->P.front_height, bbytes = (size_t)bird_stride * f->P.bird_height;
+  double t0 = now();
+  for (size_t b = 0; b < B; b++)  // ExtractORB(0, imGray), :310
+    orc_orb_extract(&f->P.orb, front + b * fbytes, f->P.front_width, f->P.front_height, front_stride, f->kps.data() + b * cap,
+                    f->desc.data() + b * cap * 32, &f->n[b]);
+  double t1 = now();
+  f->stage_s[0] = t1 - t0;
+  for (size_t b = 0; b < B; b++)  // UndistortKeyPoints, :320
+    orc_undistort_keypoints(f->kps.data() + b * cap, f->n[b], f->P.K, f->P.D, f->kps_un.data() + b * cap);
+  std::fill(f->mp.begin(), f->mp.end(), -1);           // :327
+  std::fill(f->outlier.begin(), f->outlier.end(), 0);   // :328
+  t0 = now();
+  std::vector<fb_keypoint> pre(B * cap);
+  std::vector<uint8_t> pred(B * cap * 32);
+  std::vector<int32_t> npre(B, 0);
+  for (size_t b = 0; b < B; b++)  // the E9 substitution: ORBextractor on the bird image (:337-339, :355)
+    orc_orb_extract(&f->P.orb, bird + b * bbytes, f->P.bird_width, f->P.bird_height, bird_stride, pre.data() + b * cap,
+                    pred.data() + b * cap * 32, &npre[b]);
+  t1 = now();
+  f->stage_s[1] = t1 - t0;
+  if (contour) {  // GuidenceKeyBirdPts(preKeysBird), :342 (+ the detect mask, :339)
+    fb_bird_guidance_args G;
+    std::memset(&G, 0, sizeof(G));
+    G.batch = f->B; G.kp_stride = f->cap; G.cols = f->P.bird_width; G.rows = f->P.bird_height; G.pitch = bird_stride;
+    G.contour = contour; G.mask = mask; G.n_in = npre.data(); G.kps_in = pre.data(); G.desc_in = pred.data();
+    G.n_out = f->nb.data(); G.kps_out = f->bkps.data(); G.desc_out = f->bdesc.data();
+    orc_bird_guidance(&G);
+  } else {
+    f->nb = npre;
+    f->bkps = pre;
+    f->bdesc = pred;
+  }
+  std::fill(f->mpb.begin(), f->mpb.end(), -1);            // :355
+  std::fill(f->boutlier.begin(), f->boutlier.end(), 1);    // :356  mvBirdOutlier = vector<bool>(Nbird, true)
+  orc_bird_keys_to_cam(f->bkps.data(), f->nb.data(), f->B, f->cap, f->P.bird_width, f->P.bird_height, f->P.pixel2meter,
+                       f->P.rear_axle_to_center, f->P.Tcb, f->bcam.data());  // :365-373
+  orc_grid_build(f->kps_un.data(), f->n.data(), f->B, f->cap, &f->gF, f->cs.data(), f->ci.data());  // AssignFeaturesToGrid, :376
+  orc_grid_build(f->bkps.data(), f->nb.data(), f->B, f->cap, &f->gB, f->bcs.data(), f->bci.data());
+  std::fill(f->counts.begin(), f->counts.end(), 0);
+  return FB_OK;
+}
+
+int orc_frame_set_pose(orc_frame *f, const float *Tcw) {
+  std::memcpy(f->Tcw.data(), Tcw, (size_t)f->B * 48);
+  return FB_OK;
+}
+
+int orc_frame_set_map_points(orc_frame *f, const int32_t *mp, const int32_t *mpb) {
+  const size_t B = f->B, cap = f->cap;
+  for (size_t b = 0; b < B; b++)
+    for (size_t i = 0; i < cap; i++) {
+      if (mp) { f->mp[b * cap + i] = (int)i < f->n[b] ? mp[b * cap + i] : -1; f->outlier[b * cap + i] = 0; }
+      if (mpb) f->mpb[b * cap + i] = (int)i < f->nb[b] ? mpb[b * cap + i] : -1;
+    }
+  return FB_OK;
+}
+
+// Tracking::Track for a frame in state OK: TrackWithMotionModel + TrackLocalMap + the clean-up (host pointers in T)
+int orc_frame_track(orc_frame *cur, orc_frame *last, const fb_track_args *T) {
+  const size_t B = cur->B, cap = cur->cap;
+  const fb_map_points *map = &T->map;
+  fb_map_points_bird mpbv = T->mpb;
+  fb_map_points_bird *mpb = &mpbv;
+  std::memset(cur->stage_s, 0, sizeof(cur->stage_s));
+  double t0 = now();
+  // ---- mCurrentFrame.SetPose(detlaT * mLastFrame.mTcw), Tracking.cc:1320 (4x4 * 4x4 CV_32F, small-matrix gemm path)
+  for (size_t b = 0; b < B; b++) {
+    const float *D = T->d_delta + b * 12, *L = last->Tcw.data() + b * 12;
+    float *C = cur->Tcw.data() + b * 12;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 4; c++) {
+        float s = (D[r * 4 + 0] * L[0 * 4 + c] + D[r * 4 + 1] * L[1 * 4 + c]) + D[r * 4 + 2] * L[2 * 4 + c];
+        s = s + D[r * 4 + 3] * (c == 3 ? 1.0f : 0.0f);
+        C[r * 4 + c] = s;
+      }
+  }
+  // ---- GetLocalMapForBird, :1322-1323 -> :1999-2012
+  {
+    const int lcap = T->d_local_mpb ? cur->P.local_mpb_cap : mpb->stride;
+    std::vector<uint8_t> valid(B * lcap, 0), rdesc(B * (size_t)lcap * 32, 0);
+    std::vector<float> rxw(B * (size_t)lcap * 3, 0.f);
+    std::vector<int32_t> nref(B, 0), match(B * cap, -1);
+    for (size_t b = 0; b < B; b++) {
+      const int nl = T->d_local_mpb ? T->d_n_local_mpb[b] : mpb->n[b];
+      nref[b] = nl > 10 ? nl : 0;  // if (vlocalMPB.size() > 10)
+      for (int j = 0; j < nl; j++) {
+        const int id = T->d_local_mpb ? T->d_local_mpb[b * lcap + j] : j;
+        if (id < 0 || id >= mpb->n[b]) continue;
+        valid[b * lcap + j] = 1;
+        std::memcpy(&rxw[(b * lcap + j) * 3], mpb->xw + (b * mpb->stride + id) * 3, 12);
+        std::memcpy(&rdesc[(b * lcap + j) * 32], mpb->desc + (b * mpb->stride + id) * 32, 32);
+      }
+    }
+    fb_bird_mp_args A;
+    std::memset(&A, 0, sizeof(A));
+    A.batch = cur->B; A.cur_stride = cur->cap; A.ref_stride = lcap;
+    A.n_cur = cur->nb.data(); A.cur_kps = cur->bkps.data(); A.cur_desc = cur->bdesc.data(); A.cur_cam_xyz = cur->bcam.data();
+    A.cur_cell_start = cur->bcs.data(); A.cur_cell_items = cur->bci.data(); A.cur_Tcw = cur->Tcw.data();
+    A.n_ref = nref.data(); A.ref_valid = valid.data(); A.ref_xw = rxw.data(); A.ref_desc = rdesc.data();
+    std::memcpy(A.Tbc, cur->P.Tbc, sizeof(A.Tbc));
+    A.bird_cols = cur->P.bird_width; A.bird_rows = cur->P.bird_height; A.meter2pixel = cur->P.meter2pixel;
+    A.rear_axle_to_center = cur->P.rear_axle_to_center; A.grid = cur->gB; A.window_size = 10; A.filter_size = 0.05f;
+    A.matcher.nnratio = 0.9f; A.matcher.check_orientation = 1;
+    A.match_cur_to_ref = match.data(); A.ninliers = cnt(cur, FB_CNT_BIRD_KF_MATCHES);
+    orc_match_bird_mappoints(&A);
+    for (size_t b = 0; b < B; b++)  // CurF.mvpMapPointsBird[match] = pMPBird, ORBmatcher.cc:1891
+      for (int i = 0; i < cur->nb[b]; i++) {
+        const int m = match[b * cap + i];
+        if (m >= 0) cur->mpb[b * cap + i] = T->d_local_mpb ? T->d_local_mpb[b * lcap + m] : m;
+      }
+  }
+  double t1 = now();
+  cur->stage_s[2] = t1 - t0;
+  t0 = t1;
+  // ---- fill(mvpMapPoints, NULL); SearchByProjection(cur, last, 15, mono), :1330-1339
+  {
+    std::fill(cur->mp.begin(), cur->mp.end(), -1);
+    std::vector<uint8_t> valid(B * cap, 0), obs(B * cap, 0), ldesc(B * cap * 32, 0);
+    std::vector<float> lxw(B * cap * 3, 0.f), lang(B * cap, 0.f);
+    std::vector<int32_t> loct(B * cap, 0), match(B * cap, -1);
+    for (size_t b = 0; b < B; b++)
+      for (int i = 0; i < last->n[b]; i++) {
+        const size_t o = b * cap + i;
+        const int id = last->mp[o];
+        if (id < 0 || last->outlier[o]) continue;  // pMP && !LastFrame.mvbOutlier[i], ORBmatcher.cc:1357-1359
+        valid[o] = 1;
+        obs[o] = map->obs_pos[b * map->stride + id];
+        std::memcpy(&lxw[o * 3], map->xw + (b * map->stride + id) * 3, 12);
+        std::memcpy(&ldesc[o * 32], map->desc + (b * map->stride + id) * 32, 32);
+        loct[o] = last->kps[o].octave;
+        lang[o] = last->kps_un[o].angle;
+      }
+    fb_proj_frame_args A;
+    std::memset(&A, 0, sizeof(A));
+    A.batch = cur->B; A.cur_stride = cur->cap; A.last_stride = cur->cap;
+    A.n_cur = cur->n.data(); A.cur_kps = cur->kps_un.data(); A.cur_desc = cur->desc.data();
+    A.cur_cell_start = cur->cs.data(); A.cur_cell_items = cur->ci.data(); A.cur_blocked = nullptr; A.cur_Tcw = cur->Tcw.data();
+    A.n_last = last->n.data(); A.last_valid = valid.data(); A.last_obs_pos = obs.data(); A.last_xw = lxw.data();
+    A.last_desc = ldesc.data(); A.last_octave = loct.data(); A.last_angle = lang.data();
+    A.cam = cur->cam; A.grid = cur->gF;
+    for (int i = 0; i < FB_MAX_LEVELS; i++) A.scale_factors[i] = cur->tab.scale_factor[i];
+    A.th = 15.0f; A.matcher.nnratio = 0.9f; A.matcher.check_orientation = 1;
+    A.match_cur_to_last = match.data(); A.nmatches = cnt(cur, FB_CNT_PROJ_MATCHES);
+    orc_match_projection_frame(&A);
+    for (size_t b = 0; b < B; b++)  // CurrentFrame.mvpMapPoints[bestIdx2] = pMP, ORBmatcher.cc:1430
+      for (int i = 0; i < cur->n[b]; i++) {
+        const int m = match[b * cap + i];
+        cur->mp[b * cap + i] = m >= 0 ? last->mp[b * cap + m] : -1;
+      }
+  }
+  t1 = now();
+  cur->stage_s[3] = t1 - t0;
+  t0 = t1;
+  // ---- Optimizer::PoseOptimizationWithBird(&mCurrentFrame), :1353
+  pose_optimization(cur, map, mpb, FB_POSE_FRONT_BIRD, T->wB, T->wF, FB_CNT_POSE1_INLIERS);
+  t1 = now();
+  cur->stage_s[4] = t1 - t0;
+  t0 = t1;
+  // ---- Discard outliers, :1358-1376
+  for (size_t b = 0; b < B; b++) {
+    int nmatches = cnt(cur, FB_CNT_PROJ_MATCHES)[b], nmatchesMap = 0;
+    for (int i = 0; i < cur->n[b]; i++) {
+      const size_t o = b * cap + i;
+      if (cur->mp[o] < 0) continue;
+      if (cur->outlier[o]) { cur->mp[o] = -1; cur->outlier[o] = 0; nmatches--; }
+      else if (map->obs_pos[b * map->stride + cur->mp[o]]) nmatchesMap++;
+    }
+    cnt(cur, FB_CNT_MATCHES)[b] = nmatches;
+    cnt(cur, FB_CNT_MATCHES_MAP)[b] = nmatchesMap;
+  }
+  // ---- TrackLocalMap: GetPerFrameMatchedBirdPoints, :1392 -> :2724-2733
+  {
+    std::vector<int32_t> m12(B * cap, -1), mdist(B * cap, 0), ndm(B, 0);
+    fb_birdview_args A;
+    std::memset(&A, 0, sizeof(A));
+    A.batch = cur->B; A.cur_stride = cur->cap; A.ref_stride = cur->cap;
+    A.n_cur = cur->nb.data(); A.cur_kps = cur->bkps.data(); A.cur_desc = cur->bdesc.data();
+    A.cur_cell_start = cur->bcs.data(); A.cur_cell_items = cur->bci.data();
+    A.n_ref = last->nb.data(); A.ref_kps = last->bkps.data(); A.ref_desc = last->bdesc.data();
+    A.grid = cur->gB; A.window_size = 10; A.matcher.nnratio = 0.9f; A.matcher.check_orientation = 1;
+    A.match_ref_to_cur = m12.data(); A.match_dist = mdist.data(); A.nmatches = cnt(cur, FB_CNT_BIRDVIEW_MATCHES); A.n_dmatches = ndm.data();
+    orc_match_birdview(&A);
+    // FilterBirdOutlierInFront(tmpRefFrame, &mCurrentFrame, vDMatches12, 0.05), :1825-1914
+    for (size_t b = 0; b < B; b++) {
+      const float *T1 = last->Tcw.data() + b * 12, *T2 = cur->Tcw.data() + b * 12;
+      float Twc1[12];  // Converter::invT(Tcw1), Converter.cc:176-187
+      for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) Twc1[r * 4 + c] = T1[c * 4 + r];
+        Twc1[r * 4 + 3] = -((T1[0 * 4 + r] * T1[3] + T1[1 * 4 + r] * T1[7]) + T1[2 * 4 + r] * T1[11]);
+      }
+      int inlier = 0, buildNew = 0;
+      std::vector<uint8_t> taken(cap, 0);  // a slot a passing match took stays taken even when the bird table is full
+      for (int i1 = 0; i1 < last->nb[b]; i1++) {        // vDMatches12: DMatch(i1, vnMatches12[i1]) iff vnMatches12[i1] > 0
+        const int t = m12[b * cap + i1];
+        if (!(t > 0)) continue;
+        if (cur->mpb[b * cap + t] >= 0 || taken[t]) continue;  // tmpMP, :1861-1863
+        const float *p1 = last->bcam.data() + (b * cap + i1) * 3, *p2 = cur->bcam.data() + (b * cap + t) * 3;
+        float ptw[3], pc2[3];
+        for (int r = 0; r < 3; r++) ptw[r] = ((Twc1[r * 4] * p1[0] + Twc1[r * 4 + 1] * p1[1]) + Twc1[r * 4 + 2] * p1[2]) + Twc1[r * 4 + 3];
+        for (int r = 0; r < 3; r++) pc2[r] = ((T2[r * 4] * ptw[0] + T2[r * 4 + 1] * ptw[1]) + T2[r * 4 + 2] * ptw[2]) + T2[r * 4 + 3];
+        const float d[3] = {pc2[0] - p2[0], pc2[1] - p2[1], pc2[2] - p2[2]};
+        const double disC = std::sqrt((double)d[0] * d[0] + (double)d[1] * d[1] + (double)d[2] * d[2]);  // cv::norm, :1874
+        if (disC < 0.05f) {
+          cur->boutlier[b * cap + t] = 0;                 // :1887
+          taken[t] = 1;
+          inlier++;
+          const int refId = last->mpb[b * cap + i1];
+          if (refId >= 0) {
+            cur->mpb[b * cap + t] = refId;                // :1893
+          } else {
+            const int id = mpb->n[b];
+            if (id < mpb->stride) {                       // new MapPointBird(ptwC, MatchedFrame2, mpMap, trainIdx), :1897
+              std::memcpy(mpb->xw + (b * mpb->stride + id) * 3, ptw, 12);
+              std::memcpy(mpb->desc + (b * mpb->stride + id) * 32, cur->bdesc.data() + (b * cap + t) * 32, 32);
+              mpb->n[b] = id + 1;
+              cur->mpb[b * cap + t] = id;
+              last->mpb[b * cap + i1] = id;
+            }
+            buildNew++;
+          }
+        }
+      }
+      cnt(cur, FB_CNT_BIRD_INLIERS)[b] = inlier;
+      cnt(cur, FB_CNT_BIRD_NEW)[b] = buildNew;
+    }
+  }
+  t1 = now();
+  cur->stage_s[5] = t1 - t0;
+  t0 = t1;
+  // ---- SearchLocalPoints, :1396 -> :1947-1997
+  {
+    const int lcap = T->d_local_mp ? cur->P.local_mp_cap : map->stride;
+    std::vector<uint8_t> seen(B * (size_t)map->stride, 0), blocked(B * cap, 0), lvalid(B * (size_t)lcap, 0), inview(B * (size_t)lcap, 0),
+        lobs(B * (size_t)lcap, 0), ldesc(B * (size_t)lcap * 32, 0);
+    std::vector<float> lxw(B * (size_t)lcap * 3, 0.f), lnrm(B * (size_t)lcap * 3, 0.f), lmax(B * (size_t)lcap, 0.f), lmin(B * (size_t)lcap, 0.f),
+        proj(B * (size_t)lcap * 2, 0.f), vcos(B * (size_t)lcap, 0.f), Ow(B * 3, 0.f);
+    std::vector<int32_t> level(B * (size_t)lcap, 0), nl(B, 0), match(B * cap, -1);
+    for (size_t b = 0; b < B; b++) {
+      for (int i = 0; i < cur->n[b]; i++) {  // :1950-1966
+        const size_t o = b * cap + i;
+        const int id = cur->mp[o];
+        if (id < 0) continue;
+        if (map->bad[b * map->stride + id]) cur->mp[o] = -1;
+        else { seen[b * map->stride + id] = 1; blocked[o] = map->obs_pos[b * map->stride + id]; }
+      }
+      nl[b] = T->d_local_mp ? T->d_n_local_mp[b] : map->n[b];
+      for (int j = 0; j < nl[b]; j++) {      // :1971-1984
+        const int id = T->d_local_mp ? T->d_local_mp[b * lcap + j] : j;
+        if (id < 0 || id >= map->n[b]) continue;
+        const size_t m = b * map->stride + id, o = b * lcap + j;
+        if (seen[m] || map->bad[m]) continue;
+        lvalid[o] = 1;
+        std::memcpy(&lxw[o * 3], map->xw + m * 3, 12);
+        std::memcpy(&lnrm[o * 3], map->normal + m * 3, 12);
+        lmax[o] = map->max_dist[m]; lmin[o] = map->min_dist[m];
+        lobs[o] = map->obs_pos[m];
+        std::memcpy(&ldesc[o * 32], map->desc + m * 32, 32);
+      }
+      const float *Tc = cur->Tcw.data() + b * 12;  // mOw = -mRcw.t() * mtcw (Frame.cc:432): general gemm path, double accumulation
+      for (int r = 0; r < 3; r++) {
+        double s = 0.0;
+        for (int k = 0; k < 3; k++) s += (double)Tc[k * 4 + r] * (double)Tc[k * 4 + 3];
+        Ow[b * 3 + r] = (float)(-s);
+      }
+    }
+    fb_frustum_args F;
+    std::memset(&F, 0, sizeof(F));
+    F.batch = cur->B; F.mp_stride = lcap; F.Tcw = cur->Tcw.data(); F.Ow = Ow.data(); F.n_mp = nl.data(); F.mp_valid = lvalid.data();
+    F.mp_xw = lxw.data(); F.mp_normal = lnrm.data(); F.mp_max_dist = lmax.data(); F.mp_min_dist = lmin.data(); F.cam = cur->cam;
+    F.mbf = 0.f; F.viewing_cos_limit = 0.5f; F.log_scale_factor = cur->logScale; F.n_levels = cur->P.orb.nlevels;
+    F.in_view = inview.data(); F.proj = proj.data(); F.proj_xr = nullptr; F.level = level.data(); F.view_cos = vcos.data();
+    orc_in_frustum(&F);
+    for (size_t b = 0; b < B; b++) {
+      int nToMatch = 0;
+      for (int j = 0; j < nl[b]; j++) nToMatch += inview[b * lcap + j];
+      cnt(cur, FB_CNT_TO_MATCH)[b] = nToMatch;
+    }
+    fb_proj_points_args A;
+    std::memset(&A, 0, sizeof(A));
+    A.batch = cur->B; A.cur_stride = cur->cap; A.mp_stride = lcap;
+    A.n_cur = cur->n.data(); A.cur_kps = cur->kps_un.data(); A.cur_desc = cur->desc.data();
+    A.cur_cell_start = cur->cs.data(); A.cur_cell_items = cur->ci.data(); A.cur_blocked = blocked.data();
+    A.n_mp = nl.data(); A.mp_track = inview.data(); A.mp_obs_pos = lobs.data(); A.mp_proj = proj.data(); A.mp_level = level.data();
+    A.mp_view_cos = vcos.data(); A.mp_desc = ldesc.data(); A.grid = cur->gF;
+    for (int i = 0; i < FB_MAX_LEVELS; i++) A.scale_factors[i] = cur->tab.scale_factor[i];
+    A.th = 1.0f; A.matcher.nnratio = 0.8f; A.matcher.check_orientation = 1;
+    A.match_cur_to_mp = match.data(); A.nmatches = cnt(cur, FB_CNT_LOCAL_MATCHES);
+    orc_match_projection_points(&A);  // (with nothing in view it matches nothing: the if (nToMatch > 0) of :1986)
+    for (size_t b = 0; b < B; b++)    // F.mvpMapPoints[bestIdx] = pMP, ORBmatcher.cc:124
+      for (int i = 0; i < cur->n[b]; i++) {
+        const int m = match[b * cap + i];
+        if (m >= 0) cur->mp[b * cap + i] = T->d_local_mp ? T->d_local_mp[b * lcap + m] : m;
+      }
+  }
+  t1 = now();
+  cur->stage_s[6] = t1 - t0;
+  t0 = t1;
+  // ---- Optimizer::PoseOptimizationWithBird(&mCurrentFrame), :1400
+  pose_optimization(cur, map, mpb, FB_POSE_FRONT_BIRD, T->wB, T->wF, FB_CNT_POSE2_INLIERS);
+  t1 = now();
+  cur->stage_s[7] = t1 - t0;
+  // ---- mnMatchesInliers (:1411-1424), clean VO matches (:690-701), drop outliers (:721-725)
+  for (size_t b = 0; b < B; b++) {
+    int inl = 0;
+    for (int i = 0; i < cur->n[b]; i++) {
+      const size_t o = b * cap + i;
+      if (cur->mp[o] < 0) continue;
+      if (!cur->outlier[o] && map->obs_pos[b * map->stride + cur->mp[o]]) inl++;
+    }
+    for (int i = 0; i < cur->n[b]; i++) {
+      const size_t o = b * cap + i;
+      if (cur->mp[o] >= 0 && !map->obs_pos[b * map->stride + cur->mp[o]]) { cur->outlier[o] = 0; cur->mp[o] = -1; }
+    }
+    for (int i = 0; i < cur->n[b]; i++) {
+      const size_t o = b * cap + i;
+      if (cur->mp[o] >= 0 && cur->outlier[o]) cur->mp[o] = -1;
+    }
+    cnt(cur, FB_CNT_MATCHES_INLIERS)[b] = inl;
+  }
+  return FB_OK;
+}
+
+int orc_frame_view(orc_frame *f, fb_frame_view *v) {
+  v->batch = f->B; v->kp_stride = f->cap;
+  v->n = f->n.data(); v->kps = f->kps.data(); v->kps_un = f->kps_un.data(); v->desc = f->desc.data();
+  v->map_point = f->mp.data(); v->outlier = f->outlier.data();
+  v->n_bird = f->nb.data(); v->kps_bird = f->bkps.data(); v->desc_bird = f->bdesc.data(); v->bird_cam_xyz = f->bcam.data();
+  v->map_point_bird = f->mpb.data(); v->bird_outlier = f->boutlier.data(); v->Tcw = f->Tcw.data(); v->counts = f->counts.data();
+  return FB_OK;
+}
+
+int orc_frame_stage_seconds(orc_frame *f, double *out8) {
+  std::memcpy(out8, f->stage_s, sizeof(f->stage_s));
+  return FB_OK;
+}
+
+}  // extern "C"

@@ -44,6 +44,9 @@ def test_ctypes_mirrors_match_the_header_layout():
              "fb_fuse_args": C.sizeof(cabi.FuseArgs), "fb_proj_sim3_args": C.sizeof(cabi.ProjSim3Args),
              "fb_sim3_args": C.sizeof(cabi.Sim3Args), "fb_init_match_args": C.sizeof(cabi.InitMatchArgs),
              "fb_frustum_args": C.sizeof(cabi.FrustumArgs), "fb_bird_filter_args": C.sizeof(cabi.BirdFilterArgs),
+             "fb_frame_params": C.sizeof(cabi.FrameParams), "fb_map_points": C.sizeof(cabi.MapPoints),
+             "fb_map_points_bird": C.sizeof(cabi.MapPointsBird), "fb_track_args": C.sizeof(cabi.TrackArgs),
+             "fb_frame_view": C.sizeof(cabi.FrameView),
              "fb_vocabulary": C.sizeof(cabi.Vocabulary), "fb_bow_transform_args": C.sizeof(cabi.BowTransformArgs)}
     src = '#include <stdio.h>\n#include "fishbird.h"\nint main(void){\n' + "".join(
         'printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in names) + "return 0;}\n"
