@@ -294,6 +294,160 @@ def single_sequence_leg(Pipeline, rank, local_rank, batches=(1, 8), steps=200, w
     return out
 
 
+def _triangle_path(nframes, steps):
+    """0,1,..,K-1,K-2,..,0,1,.. : the vehicle drives the rendered stretch forth and back, every step a real motion."""
+    period = list(range(nframes)) + list(range(nframes - 2, 0, -1))
+    return [period[i % len(period)] for i in range(steps + 1)]
+
+
+def track_chain_leg(rank, local_rank, batches=(1, 8, 256), steps=(200, 100, 20), warm=(20, 20, 4), parity_pairs=2, parity_frames=5,
+                    nframes=11):
+    """The sequence-faithful per-frame chain (fb_frame_*, csrc/track.hip): Frame construction (extract x2, fisheye
+    undistortion with fisheye.yaml's coefficients, bird guidance on a contour image + detect mask, camera XYZ, grids), then
+    TrackWithMotionModel + TrackLocalMap (Tracking.cc:1312-1441): pose prediction from the PREVIOUS frame's optimised pose,
+    M9, M3, PoseOptimizationWithBird, outlier discard, M8 + FilterBirdOutlierInFront, SearchLocalPoints (isInFrustum + M2),
+    second PoseOptimizationWithBird, clean-up.  Frame k+1 is enqueued after frame k on one stream and reads its results.
+      dependent: the host reads the counter block after every frame (fb_frame_counts = one synchronisation per frame), as a
+                 Tracking state machine that decides on retries / LOST per frame must
+      free_running: no per-frame read-back (counters checked afterwards)"""
+    import torch
+    from fishbirdeyevisualslam_amd import sequence as SQ, track as TR, cabi
+    dev = "cuda:%d" % local_rank
+    ground = SQ.make_ground(9000 + rank)
+    out = {"workload": "synthetic drive over a textured ground plane (fishbirdeyevisualslam_amd/sequence.py): 1280x720 fisheye front "
+                       "(fisheye.yaml k1..k4) + 512x512 bird + contour + mask per frame, %d rendered frames driven forth and back, map = "
+                       "key points of the two end frames" % nframes,
+           "order": "Frame.cc:262-379, Tracking.cc:1312-1385, 1387-1441, 690-725"}
+    for B, nsteps, nwarm in zip(batches, steps, warm):
+        seq = SQ.Sequence(B, nframes, seed=9000 + rank * 1000 + B, device=dev, ground=ground)
+        imgs = [seq.render(k) for k in range(nframes)]
+        mask = torch.from_numpy(seq.mask).to(dev)
+        cap0 = 2064
+        tc = TR.TrackChain(B, FRONT_WH, BIRD_WH, K=seq.Kc, D=seq.D, map_cap=2 * cap0, bird_cap=8 * cap0, device=dev)
+        tc.extract(*imgs[nframes - 1], mask)
+        v_end = tc.view("cur")
+        tc.extract(*imgs[0], mask)
+        v0 = tc.view("cur")
+        M, MB, mp0, mpb0, Tcw0 = seq.build_map(v0, tc.tables, map_cap=tc.map_cap, bird_cap=tc.bird_cap, extra_views=[(nframes - 1, v_end)])
+        tc.set_map(M, MB)
+        tc.init_first(mp0, mpb0, Tcw0)
+        path = _triangle_path(nframes, nwarm + 2 * nsteps)
+        dl = {}
+        for a_, b_ in set(zip(path[:-1], path[1:])):
+            dl[(a_, b_)] = torch.from_numpy(seq.delta_between(a_, b_)).to(dev)
+        res = {}
+        pos = 0
+
+        def run(n, sync_each):
+            nonlocal pos
+            last_counts = None
+            for _ in range(n):
+                a_, b_ = path[pos], path[pos + 1]
+                pos += 1
+                tc.delta.copy_(dl[(a_, b_)], non_blocking=True)
+                tc.track(*imgs[b_], mask)
+                if sync_each:
+                    last_counts = tc.counts()
+            torch.cuda.synchronize()
+            return last_counts
+        run(nwarm, True)
+        for name, sync_each in (("dependent", True), ("free_running", False)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(nsteps, sync_each)
+            dt = time.perf_counter() - t0
+            res[name] = {"ms_per_step": dt / nsteps * 1e3, "ms_per_frame_pair": dt / nsteps / B * 1e3, "frames_per_s": B * nsteps / dt, "steps": nsteps}
+        c, T = tc.counts()
+        res["counters_mean_last_frame"] = {k: float(c[i].mean()) for k, i in cabi.FB_CNT.items()}
+        tp = np.stack([np.asarray(seq.Tcw_true(path[pos], b))[:3, :4].reshape(12) for b in range(B)])
+        res["max_abs_pose_error_vs_truth"] = float(np.abs(T - tp).max())
+        res["bird_table_points"] = float(tc.mpb["n"].float().mean().item())
+        out["b%d" % B] = res
+        tc.close()
+        del imgs, seq, tc
+        torch.cuda.empty_cache()
+    # parity of the chain inside the bench: a few sequences, consecutive dependent frames, GPU vs oracle chain
+    try:
+        from oracle import pyoracle as O
+        seq = SQ.Sequence(parity_pairs, parity_frames + 1, seed=9700 + rank, device=dev, ground=ground)
+        tc = TR.TrackChain(parity_pairs, FRONT_WH, BIRD_WH, K=seq.Kc, D=seq.D, device=dev)
+        oc = O.OracleChain(tc.params, tc.map_cap, tc.bird_cap)
+        mask = torch.from_numpy(seq.mask).to(dev)
+        h = lambda t: t.cpu().numpy()
+        f, b, c = seq.render(0)
+        tc.extract(f, b, c, mask)
+        oc.extract(h(f), h(b), h(c), seq.mask)
+        v0 = tc.view("cur")
+        M, MB, mp0, mpb0, Tcw0 = seq.build_map(v0, tc.tables, map_cap=tc.map_cap, bird_cap=tc.bird_cap)
+        for ch in (tc, oc):
+            ch.set_map(M, MB)
+            ch.init_first(mp0, mpb0, Tcw0)
+        bad, worst, cpu_ms, stages = [], 0.0, [], []
+        for k in range(1, parity_frames + 1):
+            f, b, c = seq.render(k)
+            d = seq.delta(k)
+            tc.set_delta(d)
+            tc.track(f, b, c, mask)
+            t0 = time.perf_counter()
+            oc.track(h(f), h(b), h(c), seq.mask, d)
+            cpu_ms.append((time.perf_counter() - t0) * 1e3 / parity_pairs)
+            stages.append(oc.stage_seconds())
+            g, o = tc.view(), oc.view()
+            for bb in range(parity_pairs):
+                n, nb = int(o["n"][bb]), int(o["n_bird"][bb])
+                for key, m in (("kps", n), ("desc", n), ("map_point", n), ("outlier", n), ("kps_bird", nb), ("desc_bird", nb), ("map_point_bird", nb), ("bird_outlier", nb)):
+                    if not np.array_equal(g[key][bb, :m], o[key][bb, :m]):
+                        bad.append("frame %d sequence %d: %s" % (k, bb, key))
+                rel = float(np.abs(g["Tcw"][bb] - o["Tcw"][bb]).max() / max(1.0, np.abs(o["Tcw"][bb]).max()))
+                worst = max(worst, rel)
+                if rel > REL_TOL:
+                    bad.append("frame %d sequence %d: pose %.3g" % (k, bb, rel))
+            if not np.array_equal(g["counts"][:12], o["counts"][:12]):
+                bad.append("frame %d: counters" % k)
+        out["parity_check"] = {"sequences": parity_pairs, "consecutive_frames": parity_frames, "mismatches": len(bad), "details": bad[:8],
+                               "worst_relative_pose_difference": worst,
+                               "checked": "every frame: key points, descriptors, mvpMapPoints / mvpMapPointsBird indices, outlier masks, all counters "
+                                          "bit-exact; pose <= 1e-4 relative; frame k's pose and associations are the inputs of frame k+1"}
+        st = np.array(stages)
+        out["cpu_oracle_chain"] = {"ms_per_frame_pair_1_core": float(statistics.median(cpu_ms)),
+                                   "includes": "Frame construction (extract x2 ...) + the whole chain, oracle/track_oracle.cpp, 1 thread",
+                                   "stage_ms_median": {"extract_front": float(np.median(st[:, 0])) * 1e3 / parity_pairs, "extract_bird": float(np.median(st[:, 1])) * 1e3 / parity_pairs,
+                                                       "m9": float(np.median(st[:, 2])) * 1e3 / parity_pairs, "m3": float(np.median(st[:, 3])) * 1e3 / parity_pairs,
+                                                       "pose1": float(np.median(st[:, 4])) * 1e3 / parity_pairs, "m8_filter": float(np.median(st[:, 5])) * 1e3 / parity_pairs,
+                                                       "local_points_m2": float(np.median(st[:, 6])) * 1e3 / parity_pairs, "pose2": float(np.median(st[:, 7])) * 1e3 / parity_pairs}}
+        tc.close()
+        oc.close()
+    except Exception as e:  # noqa: BLE001
+        out["parity_check"] = {"error": str(e)[:300]}
+    return out
+
+
+def host_abi_leg(rank):
+    """What one frame costs through the HOST-POINTER C-ABI the INTEGRATION.md shims call (fb_orb_extract x2, host grids,
+    fb_match_projection_frame, fb_match_bird_mappoints, fb_pose_opt, synchronous, one 1280x720 + 512x512 pair per call) and
+    through the device-resident frame handle (fb_frame_extract from host images + fb_frame_track_dev + one fb_frame_counts):
+    tests/cpp/host_abi_bench.cpp, a plain g++ program, run as a child process."""
+    import subprocess
+    import tempfile
+    import fishbirdeyevisualslam_amd as fb
+    from fishbirdeyevisualslam_amd import synth
+    d = tempfile.mkdtemp()
+    exe = os.path.join(d, "host_abi_bench")
+    libdir = os.path.dirname(fb.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "host_abi_bench.cpp"), "-o", exe,
+                           "-L", libdir, "-lfishbird_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    synth.synth_image(1000 + rank * 10000, *FRONT_WH).tofile(os.path.join(d, "front.raw"))
+    synth.synth_image(1500 + rank * 10000, *BIRD_WH).tofile(os.path.join(d, "bird.raw"))
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    txt = subprocess.check_output([exe, os.path.join(d, "front.raw"), os.path.join(d, "bird.raw"), "40"], env=env, timeout=300).decode()
+    r = json.loads(txt.strip().splitlines()[-1])
+    r["note"] = ("host_pointer = every call uploads its inputs, runs, synchronises and downloads (the drop-in of INTEGRATION.md 1-3); "
+                 "frame_handle = images copied through pinned staging, everything else device resident, one synchronisation per frame; "
+                 "the frame-handle chain also runs M8 + filter, SearchLocalPoints / M2 and the second pose optimisation")
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -303,6 +457,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=55, help="frame pairs timed on the host for cpu_baseline and checked against the GPU batch (0 = skip)")
     ap.add_argument("--no-ba", action="store_true", help="skip the secondary local-BA measurement")
     ap.add_argument("--no-single", action="store_true", help="skip the B=1 / B=8 single-sequence sub-results")
+    ap.add_argument("--no-chain", action="store_true", help="skip the tracking-chain and host-ABI sub-results")
     ap.add_argument("--serial", action="store_true", help="single-stream steps (kernels do not overlap; for profiling)")
     a = ap.parse_args()
 
@@ -517,9 +672,28 @@ def main():
                 rc = 3
         if not a.no_single and world_size == 1:
             try:
-                out["single_sequence"] = single_sequence_leg(FramePipeline, rank, local_rank)
+                out["single_sequence"] = {"independent_frames": single_sequence_leg(FramePipeline, rank, local_rank),
+                                          "note": "independent_frames = the configs[2] step at B = 1 / 8 with NO data dependency between "
+                                                  "consecutive steps (throughput of unrelated frame pairs); dependent = the tracking chain below, "
+                                                  "frame k+1 predicted from frame k's optimised pose: THAT is a single sequence"}
             except Exception as e:
                 out["single_sequence"] = {"error": str(e)[:200]}
+        if not a.no_chain and world_size == 1:
+            try:
+                tcl = track_chain_leg(rank, local_rank)
+                out["track_chain"] = tcl
+                if isinstance(out.get("single_sequence"), dict):
+                    out["single_sequence"]["dependent"] = {k: tcl[k]["dependent"] for k in ("b1", "b8") if k in tcl}
+                if tcl.get("parity_check", {}).get("mismatches"):
+                    rc = 3
+            except Exception as e:
+                out["track_chain"] = {"error": str(e)[:300]}
+            try:
+                out["host_abi"] = host_abi_leg(rank)
+                if out.get("cpu_baseline"):
+                    out["host_abi"]["cpu_oracle_stage_ms_median"] = out["cpu_baseline"]["one_core"]["stage_ms_median"]
+            except Exception as e:
+                out["host_abi"] = {"error": str(e)[:300]}
         print(json.dumps(out), flush=True)
         if rc:
             print("bench.py: GPU results differ from the oracle: %s" % out["parity_check"]["details"], file=sys.stderr, flush=True)

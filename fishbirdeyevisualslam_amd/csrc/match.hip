@@ -237,10 +237,13 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
             const int dist = fb::hamming256(d, T.desc + i2 * 2);
             if (fill && dist <= TH_HIGH) {  // stable insertion into the sorted top-K (equal keys keep walk order)
               nElig++;
+              // (once an entry has been displaced everything behind it moves down one place: comparing the displaced
+              // entry again would let it jump over an equal-distance neighbour and break the walk order among ties)
               uint32_t e = ((uint32_t)dist << 16) | (uint32_t)i2;
+              bool shift = false;
 #pragma unroll
               for (int k = 0; k < CACHE_K; k++) {
-                if ((e >> 16) < (top[k] >> 16)) { const uint32_t t = top[k]; top[k] = e; e = t; }
+                if (shift || (e >> 16) < (top[k] >> 16)) { const uint32_t t = top[k]; top[k] = e; e = t; shift = true; }
               }
             }
             if (own < q) return;        // taken by an earlier query

@@ -158,7 +158,7 @@ class FramePipeline:
     def gather_bird(self, s, S):
         L, B, cap, nl = self.L, self.B, self.cap, self.params.nlevels
         S["e_nb"].copy_(self.b_n)
-        S["e_bout"].zero_()         # mvBirdOutlier of a fresh Frame
+        S["e_bout"].fill_(1)        # mvBirdOutlier = vector<bool>(Nbird, true) of a fresh Frame (Frame.cc:356)
         check(L.fb_pose_gather_bird_dev(B, cap, self.nr, _vp(self.b_n), _vp(self.b_kps), _vp(self.b_cam), _vp(self.m_bird), _vp(self.ref["xw"]),
                                         self._inv_sigma2, nl, _vp(S["e_bxw"]), _vp(S["e_bxc"]), _vp(S["e_binf"]), _vp(S["e_bvalid"]), s), "gather bird")
 
@@ -202,8 +202,12 @@ class FramePipeline:
 
     def step_serial(self):
         """The same pass on torch's current stream only (used by tests and for single-stream timing)."""
-        s = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        cur = torch.cuda.current_stream(self.dev)
+        s = C.c_void_p(cur.cuda_stream)
         S = self._sets[self._k & 1]
+        if S["pending"]:  # a pose kernel of an overlapped step() may still read this set's edge arrays on the pose stream
+            cur.wait_event(S["evP"])
+            S["pending"] = False
         self.extract(s)
         self.grids(s)
         self.match_front(s)

@@ -123,7 +123,11 @@ class Sequence:
 
     def delta(self, k):
         """[B][12] float32: detlaT between frame k-1 and k from the odometer readings."""
-        return np.stack([odom_delta(self.odom[k - 1, b], self.odom[k, b], self.Tbc, self.Tcb) for b in range(self.B)])
+        return self.delta_between(k - 1, k)
+
+    def delta_between(self, k_from, k_to):
+        """detlaT that takes frame k_from's pose to frame k_to's (any two frames: the bench drives back and forth)."""
+        return np.stack([odom_delta(self.odom[k_from, b], self.odom[k_to, b], self.Tbc, self.Tcb) for b in range(self.B)])
 
     def _ray_table(self):
         fx, fy, cx, cy = self.Kc
@@ -172,10 +176,12 @@ class Sequence:
         return torch.stack(fr).contiguous(), torch.stack(bd).contiguous(), torch.stack(ct).contiguous()
 
     # ---- the map the tracker starts from (built from frame 0's extraction) -----------------------------------------------
-    def build_map(self, view0, tables, seed=9100, map_cap=None, bird_cap=None, hold_frac=0.7, bird_hold_frac=0.6):
+    def build_map(self, view0, tables, seed=9100, map_cap=None, bird_cap=None, hold_frac=0.7, bird_hold_frac=0.6, extra_views=()):
         """From frame 0's key points (a downloaded frame view: numpy arrays) make, per sequence,
         the MapPoint table (every front key point's ground point), the MapPointBird table (every bird key point) and
-        frame 0's initial mvpMapPoints / mvpMapPointsBird (a subset: the rest is for SearchLocalPoints / M9 to find)."""
+        frame 0's initial mvpMapPoints / mvpMapPointsBird (a subset: the rest is for SearchLocalPoints / M9 to find).
+        extra_views = [(k, view of frame k), ...]: further "key frames" whose key points are added to the tables
+        (the map a LocalMapping thread would have built along the drive)."""
         B = self.B
         cap = view0["kps"].shape[1]
         map_cap = map_cap or cap
@@ -190,42 +196,48 @@ class Sequence:
         mp0 = np.full((B, cap), -1, np.int32)
         mpb0 = np.full((B, cap), -1, np.int32)
         Tcw0 = np.zeros((B, 12), np.float32)
+        views = [(0, view0)] + list(extra_views)
+        bird_budget = bird_cap // 2 // len(views)   # the other half of the bird table is for points the chain creates
         for b in range(B):
             g = synth.rng(seed + b)
-            Tcw = self.Tcw_true(0, b)
-            Twc = np.linalg.inv(Tcw)
-            Tcw0[b] = synth.to12(Tcw)
-            n = int(view0["n"][b])
-            ku = view0["kps_un"][b, :n]
-            ray = np.stack([(ku["x"].astype(np.float64) - cx) / fx, (ku["y"].astype(np.float64) - cy) / fy, np.ones(n)], 1)
-            d = ray @ Twc[:3, :3].T
-            O = Twc[:3, 3]
-            good = d[:, 2] < -1e-6
-            t = np.where(good, -O[2] / np.where(good, d[:, 2], -1.0), 10.0)
-            good &= t * np.linalg.norm(ray, axis=1) < 60.0
-            X = O + t[:, None] * d + g.normal(0, 0.001, (n, 3))
-            ids = np.nonzero(good)[0][:map_cap]
-            m = len(ids)
-            M["n"][b] = m
-            M["xw"][b, :m] = X[ids]
-            dist = np.linalg.norm(X[ids] - O, axis=1)
-            M["normal"][b, :m] = ((X[ids] - O) / dist[:, None]).astype(np.float32)
-            lvl = ku["octave"][ids]
-            M["max_dist"][b, :m] = dist * sf[lvl]
-            M["min_dist"][b, :m] = dist * sf[lvl] / sf[7]
-            M["desc"][b, :m] = synth.flip_bits(g, view0["desc"][b, ids], p=0.03)
-            M["obs_pos"][b, :m] = (g.random(m) >= 0.03).astype(np.uint8)
-            M["bad"][b, :m] = (g.random(m) < 0.01).astype(np.uint8)
-            hold = g.random(m) < hold_frac
-            mp0[b, ids[hold]] = np.nonzero(hold)[0].astype(np.int32)
-            # bird: camera XYZ of the key point -> world
-            nb = int(view0["n_bird"][b])
-            pc = view0["bird_cam_xyz"][b, :nb].astype(np.float64)
-            Xb = pc @ Twc[:3, :3].T + O + g.normal(0, 0.002, (nb, 3))
-            mb = min(nb, bird_cap // 2)
-            MB["n"][b] = mb
-            MB["xw"][b, :mb] = Xb[:mb]
-            MB["desc"][b, :mb] = synth.flip_bits(g, view0["desc_bird"][b, :mb], p=0.03)
-            holdb = g.random(mb) < bird_hold_frac
-            mpb0[b, :mb][holdb] = np.nonzero(holdb)[0].astype(np.int32)
+            Tcw0[b] = synth.to12(self.Tcw_true(0, b))
+            for vi, (kf, view) in enumerate(views):
+                Twc = np.linalg.inv(self.Tcw_true(kf, b))
+                n = int(view["n"][b])
+                ku = view["kps_un"][b, :n]
+                ray = np.stack([(ku["x"].astype(np.float64) - cx) / fx, (ku["y"].astype(np.float64) - cy) / fy, np.ones(n)], 1)
+                d = ray @ Twc[:3, :3].T
+                O = Twc[:3, 3]
+                good = d[:, 2] < -1e-6
+                t = np.where(good, -O[2] / np.where(good, d[:, 2], -1.0), 10.0)
+                good &= t * np.linalg.norm(ray, axis=1) < 60.0
+                X = O + t[:, None] * d + g.normal(0, 0.001, (n, 3))
+                m0 = int(M["n"][b])
+                ids = np.nonzero(good)[0][: max(0, map_cap - m0)]
+                m = len(ids)
+                sl = slice(m0, m0 + m)
+                M["n"][b] = m0 + m
+                M["xw"][b, sl] = X[ids]
+                dist = np.linalg.norm(X[ids] - O, axis=1)
+                M["normal"][b, sl] = ((X[ids] - O) / dist[:, None]).astype(np.float32)
+                lvl = ku["octave"][ids]
+                M["max_dist"][b, sl] = dist * sf[lvl]
+                M["min_dist"][b, sl] = dist * sf[lvl] / sf[7]
+                M["desc"][b, sl] = synth.flip_bits(g, view["desc"][b, ids], p=0.03)
+                M["obs_pos"][b, sl] = (g.random(m) >= 0.03).astype(np.uint8)
+                M["bad"][b, sl] = (g.random(m) < 0.01).astype(np.uint8)
+                # bird: camera XYZ of the key point -> world
+                nb = int(view["n_bird"][b])
+                pc = view["bird_cam_xyz"][b, :nb].astype(np.float64)
+                Xb = pc @ Twc[:3, :3].T + O + g.normal(0, 0.002, (nb, 3))
+                b0 = int(MB["n"][b])
+                mb = min(nb, bird_budget)
+                MB["n"][b] = b0 + mb
+                MB["xw"][b, b0:b0 + mb] = Xb[:mb]
+                MB["desc"][b, b0:b0 + mb] = synth.flip_bits(g, view["desc_bird"][b, :mb], p=0.03)
+                if vi == 0:
+                    hold = g.random(m) < hold_frac
+                    mp0[b, ids[hold]] = np.nonzero(hold)[0].astype(np.int32)
+                    holdb = g.random(mb) < bird_hold_frac
+                    mpb0[b, :mb][holdb] = np.nonzero(holdb)[0].astype(np.int32)
         return M, MB, mp0, mpb0, Tcw0

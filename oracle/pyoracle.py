@@ -148,6 +148,7 @@ def frame_pipeline(params, front, bird, world, fx=500.0, fy=500.0, timings=None)
               front_inv_sigma2=inv[fk["octave"]], bird_xw=bx_w, bird_xc=bcam, bird_inv_sigma2=inv[bk["octave"]],
               Tcw0=world["Tcw0"])
     ap, outp, keepp = P.pose_args([pp], mode=cabi.FB_POSE_FRONT_BIRD, front_valid=[fv], bird_valid=[bv])
+    outp["bird_outlier"][...] = 1  # mvBirdOutlier = vector<bool>(Nbird, true) of a fresh Frame (Frame.cc:356)
     t0 = time.perf_counter()
     call("orc_pose_opt", ap)
     tm["pose_opt"] = time.perf_counter() - t0

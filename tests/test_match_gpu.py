@@ -75,6 +75,32 @@ def test_search_by_projection_frame_contention():
           ["match_cur_to_last", "nmatches"])
 
 
+@pytest.mark.parametrize("pool,th", [(12, 60.0), (40, 30.0), (3, 90.0)])
+def test_search_by_projection_frame_equal_distances(pool, th):
+    """Descriptors drawn from a small pool: a query sees many candidates at EXACTLY the same Hamming distance, and the
+    first one in grid-walk order must win (ORBmatcher.cc:1411-1421: strict <), also for the candidates a query falls back
+    to after its best one was taken by an earlier query.  (Real images produce such ties; random descriptors never do:
+    this is the case a drive of the tracking chain found in round 3 -- the cached candidate list had lost the walk
+    order among equal distances.)"""
+    probs = []
+    for i in range(3):
+        p = synth.make_proj_frame_problem(2600 + 7 * i + pool, 1500, 1500, dup_frac=0.4)
+        g = synth.rng(2700 + i + pool)
+        base = synth.random_descriptors(g, pool)
+        p["cur_desc"] = base[g.integers(0, pool, len(p["cur_desc"]))].copy()
+        q = base[g.integers(0, pool, len(p["last_desc"]))].copy()
+        flip = g.random(len(q)) < 0.5
+        q[flip, 0] ^= 1                       # half of the queries one bit away: ties at distance 0 and at distance 1
+        p["last_desc"] = q
+        probs.append(p)
+    geom = P.grid_geom(synth.front_grid_geom(1280, 720))
+    cs, ci = P.build_grid_host([p["cur_kps"] for p in probs], geom, O.grid_build, 1500)
+    for ori in (1, 0):
+        out = _both(lambda: P.proj_frame_args(probs, cs, ci, th=th, check_ori=ori), "orc_match_projection_frame",
+                    "fb_match_projection_frame", ["match_cur_to_last", "nmatches"])
+        assert out["nmatches"].min() > 30
+
+
 @pytest.mark.parametrize("seed,ncur,nref", [(2100, 1000, 1000), (2101, 2064, 700), (2102, 64, 300)])
 def test_bird_mappoint_match(seed, ncur, nref):
     probs = [synth.make_bird_mp_problem(seed + 10 * i, ncur, nref) for i in range(3)]

@@ -1,0 +1,75 @@
+"""CPU tests of the oracle's tracking chain (oracle/track_oracle.cpp) and of the synthetic drive that feeds it:
+the chain must actually track (the frame-to-frame data dependency is real), and its bookkeeping follows the
+reference's rules (Tracking.cc:1358-1376, 1825-1914, 690-725)."""
+import numpy as np
+
+from fishbirdeyevisualslam_amd import cabi, sequence as S, synth, track as T
+from oracle import pyoracle as O
+
+_GROUND = {}
+
+
+def _ground(seed):
+    if seed not in _GROUND:
+        _GROUND[seed] = S.make_ground(seed)
+    return _GROUND[seed]
+
+
+def _chain(B=1, K=4, seed=9500, wh=(640, 480), bwh=(384, 384), fx=250.0):
+    seq = S.Sequence(B, K, seed=seed, front_wh=wh, bird_wh=bwh, fx=fx, fy=fx, ground=_ground(9500))
+    cap = synth.ORB_DEFAULT["nfeatures"] + 8 * synth.ORB_DEFAULT["nlevels"]
+    p = T.frame_params(B, wh, bwh, seq.Kc, seq.D, cap, cap, 2 * cap)
+    oc = O.OracleChain(p, cap, 2 * cap)
+    imgs = [tuple(t.numpy() for t in seq.render(k)) for k in range(K)]
+    oc.extract(imgs[0][0], imgs[0][1], imgs[0][2], seq.mask)
+    v0 = oc.view("cur")
+    M, MB, mp0, mpb0, Tcw0 = seq.build_map(v0, O.orb_tables(p.orb), map_cap=cap, bird_cap=2 * cap)
+    oc.set_map(M, MB)
+    oc.init_first(mp0, mpb0, Tcw0)
+    return seq, oc, imgs, (M, MB, mp0, mpb0), v0
+
+
+def test_oracle_chain_tracks_a_drive():
+    seq, oc, imgs, (M, MB, mp0, mpb0), v0 = _chain()
+    n_bird0 = int(MB["n"][0])
+    prev = None
+    for k in range(1, seq.K):
+        oc.track(imgs[k][0], imgs[k][1], imgs[k][2], seq.mask, seq.delta(k))
+        v = oc.view()
+        c = {name: int(v["counts"][i, 0]) for name, i in cabi.FB_CNT.items()}
+        # the chain tracks: enough matches survive and the optimised pose stays at the true one
+        assert c["PROJ_MATCHES"] >= 20 and c["MATCHES_MAP"] >= 10 and c["MATCHES_INLIERS"] >= 30, c
+        assert c["MATCHES"] <= c["PROJ_MATCHES"] and c["MATCHES_MAP"] <= c["MATCHES"], c
+        assert c["BIRD_NEW"] <= c["BIRD_INLIERS"] <= c["BIRDVIEW_MATCHES"], c
+        Tt = np.asarray(seq.Tcw_true(k, 0))[:3, :4].reshape(12)
+        assert np.abs(v["Tcw"][0] - Tt).max() < 0.03, (k, np.abs(v["Tcw"][0] - Tt).max())
+        n = int(v["n"][0])
+        mp, out = v["map_point"][0, :n], v["outlier"][0, :n]
+        # after the clean-up no slot holds an outlier or a point without observations (Tracking.cc:690-701, 721-725)
+        held = mp[mp >= 0]
+        assert not out[mp >= 0].any()
+        assert M["obs_pos"][0][held].all() and not M["bad"][0][held].any()
+        # new MapPointBirds were appended with the current frame's descriptor and both frames point at them
+        nb = int(v["n_bird"][0])
+        mpb = v["map_point_bird"][0, :nb]
+        assert not v["bird_outlier"][0, :nb][(mpb >= 0) & (mpb >= n_bird0)].any()
+        prev = v
+    tab = oc.bird_table_host()
+    assert int(tab["n"][0]) > n_bird0
+    oc.close()
+
+
+def test_pose_feeds_the_next_frame():
+    """Frame k+1's prediction is detlaT * (frame k's OPTIMISED pose): a chain started from a wrong pose of frame 0 ends elsewhere."""
+    seq, oc, imgs, (M, MB, mp0, mpb0), v0 = _chain(K=3)
+    seq2, oc2, imgs2, _, _ = _chain(K=3)
+    bad = synth.to12(synth.perturb_pose(synth.rng(1), seq.Tcw_true(0, 0), 0.0, 0.4))[None]
+    oc2.k -= 1
+    oc2.init_first(mp0, mpb0, bad)
+    for k in (1, 2):
+        oc.track(imgs[k][0], imgs[k][1], imgs[k][2], seq.mask, seq.delta(k))
+        oc2.track(imgs[k][0], imgs[k][1], imgs[k][2], seq.mask, seq.delta(k))
+    a, b = oc.view(), oc2.view()
+    assert int(b["counts"][cabi.FB_CNT["PROJ_MATCHES"], 0]) < int(a["counts"][cabi.FB_CNT["PROJ_MATCHES"], 0])
+    oc.close()
+    oc2.close()
