@@ -373,6 +373,11 @@ struct BAProblem : LMProblem {
 // schedule: its1 < 0 selects LocalBundleAdjustment[WithOdom] (optimize(5) robust, gate, optimize(10)); otherwise
 // BundleAdjustmentWithOdom (Optimizer.cc:1786-2135): ONE optimize(its1), robust iff `robust`, delta sqrt(5.99), no gate
 static int ba_common(const fb_local_ba_args *A, int its1, int robust);
+static double g_ba_min_margin = 1e300;
+static long g_ba_decisions = 0;
+// margin behind "identical outlier flags" for an implementation that rounds differently (tests/test_parity_sweeps_gpu.py)
+extern "C" void orc_ba_margin_reset() { g_ba_min_margin = 1e300; g_ba_decisions = 0; }
+extern "C" int orc_ba_margin_get(double *min_margin, long *decisions) { *min_margin = g_ba_min_margin; *decisions = g_ba_decisions; return FB_OK; }
 extern "C" int orc_local_ba(const fb_local_ba_args *A) { return ba_common(A, -1, 1); }
 extern "C" int orc_global_ba(const fb_local_ba_args *A, int n_iterations, int robust) { return ba_common(A, n_iterations, robust); }
 
@@ -416,6 +421,12 @@ static int ba_common(const fb_local_ba_args *A, int its1, int robust1) {
     e.robust = false;
     P.edges.push_back(e);
   }
+  auto gate = [](double chi2) {  // every chi2 > 5.991 decision (Optimizer.cc:2534-2565 gate, :2579-2610 collection) notes its margin
+    const double m = std::fabs(chi2 - 5.991) / 5.991;
+    if (m < g_ba_min_margin) g_ba_min_margin = m;
+    g_ba_decisions++;
+    return chi2 > 5.991;
+  };
   if (A->stop_flag && *A->stop_flag) return FB_OK;  // Optimizer.cc:2498-2500
   if (global && !robust1)
     for (auto &e : P.edges) e.robust = false;
@@ -425,13 +436,13 @@ static int ba_common(const fb_local_ba_args *A, int its1, int robust1) {
   if (more) {
     for (int i = 0; i < A->n_obs; i++) {
       BEdge &e = P.edges[i];
-      if (BAProblem::chi2(e) > 5.991 || !P.depthPositive(e)) e.level = 1;
+      if (gate(BAProblem::chi2(e)) || !P.depthPositive(e)) e.level = 1;
       e.robust = false;
     }
     for (int i = 0; i < nb; i++) {
       BEdge &e = P.edges[A->n_obs + i];
       P.computeError(e);
-      if (BAProblem::chi2(e) > 5.991) e.level = 1;
+      if (gate(BAProblem::chi2(e))) e.level = 1;
       e.robust = false;
     }
     P.initialize(0);
@@ -440,9 +451,9 @@ static int ba_common(const fb_local_ba_args *A, int its1, int robust1) {
   if (!global) {
     for (int i = 0; i < A->n_obs; i++) {
       const BEdge &e = P.edges[i];
-      A->obs_outlier[i] = (BAProblem::chi2(e) > 5.991 || !P.depthPositive(e)) ? 1 : 0;
+      A->obs_outlier[i] = (gate(BAProblem::chi2(e)) || !P.depthPositive(e)) ? 1 : 0;
     }
-    for (int i = 0; i < nb; i++) A->bobs_outlier[i] = BAProblem::chi2(P.edges[A->n_obs + i]) > 5.991 ? 1 : 0;
+    for (int i = 0; i < nb; i++) A->bobs_outlier[i] = gate(BAProblem::chi2(P.edges[A->n_obs + i])) ? 1 : 0;
   }
   for (int k = 0; k < A->n_kf; k++)
     if (!A->kf_fixed[k]) se3_to_float12(P.pose[k], A->kf_Tcw + 12 * k);  // local keyframes only; fixed ones unchanged

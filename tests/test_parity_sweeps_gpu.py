@@ -44,6 +44,36 @@ def test_pose_mask_sweep_240_problems(capsys):
     assert decisions.value > 1000000
 
 
+def test_local_ba_gate_sweep_60_problems(capsys):
+    """60 LocalBundleAdjustmentWithOdom problems (6-20 key frames): outlier flags identical, poses / landmarks within 1e-4;
+    PRINTS the smallest |chi2 - 5.991| / 5.991 over every decision of the chi2 gate between the two optimisations and of the
+    final outlier collection (Optimizer.cc:2534-2565, 2579-2610), front and bird edges: the margin behind 'identical flags'."""
+    from fishbirdeyevisualslam_amd import ba_problem
+    O.lib().orc_ba_margin_reset()
+    worst_pose = worst_pt = 0.0
+    n = 60
+    for i in range(n):
+        nkf = 6 + (i * 7) % 15
+        p = synth.make_ba_problem(8000 + i, n_kf=nkf, n_mp=300 + 53 * (i % 11), n_mpb=80 + 17 * (i % 7), outlier_frac=0.03 + 0.01 * (i % 4))
+        a, oo, k = ba_problem.local_ba_args(p, with_odom=1)
+        O.call("orc_local_ba", a)
+        a2, oh, k2 = ba_problem.local_ba_args(p, with_odom=1)
+        H.call("fb_local_ba", a2)
+        rel = lambda x, y: float(np.abs(x - y).max() / max(1.0, np.abs(y).max()))
+        worst_pose = max(worst_pose, rel(oh["kf_Tcw"], oo["kf_Tcw"]))
+        worst_pt = max(worst_pt, rel(oh["mp_xw"], oo["mp_xw"]), rel(oh["mpb_xw"], oo["mpb_xw"]))
+        assert worst_pose <= 1e-4 and worst_pt <= 1e-4, (i, worst_pose, worst_pt)
+        np.testing.assert_array_equal(oh["obs_outlier"], oo["obs_outlier"], err_msg="problem %d front flags" % i)
+        nb = len(p["bobs_kf"])
+        np.testing.assert_array_equal(oh["bobs_outlier"][:nb], oo["bobs_outlier"][:nb], err_msg="problem %d bird flags" % i)
+    margin, decisions = C.c_double(0), C.c_long(0)
+    O.lib().orc_ba_margin_get(C.byref(margin), C.byref(decisions))
+    with capsys.disabled():
+        print("\n[local BA sweep] %d problems (6-20 key frames), %d chi2-gate decisions: outlier flags identical; worst relative difference "
+              "poses %.3g, landmarks %.3g; smallest |chi2 - 5.991| / 5.991 = %.3g" % (n, decisions.value, worst_pose, worst_pt, margin.value))
+    assert decisions.value > 100000
+
+
 def _both(build, on, hn, keys):
     a, oo, k = build()
     O.call(on, a)

@@ -155,7 +155,11 @@ def test_chain_host_images():
         rc = tc.L.fb_frame_extract(tc.cur, tc.orb_f, tc.orb_b, vp(fh), 640, vp(bh), 384, vp(ch), vp(seq.mask), tc._stream())
         assert rc == 0, tc.L.fb_last_error()
     v_host = tc.view("cur")
-    for k in v_dev:
-        if k != "counts":
-            assert np.array_equal(v_dev[k], v_host[k]), k
+    assert np.array_equal(v_dev["n"], v_host["n"]) and np.array_equal(v_dev["n_bird"], v_host["n_bird"])
+    for b in range(2):
+        n, nb = int(v_dev["n"][b]), int(v_dev["n_bird"][b])
+        for k in ("kps", "kps_un", "desc", "map_point", "outlier"):
+            assert np.array_equal(v_dev[k][b, :n], v_host[k][b, :n]), k
+        for k in ("kps_bird", "desc_bird", "bird_cam_xyz", "map_point_bird", "bird_outlier"):
+            assert np.array_equal(v_dev[k][b, :nb], v_host[k][b, :nb]), k
     tc.close()
