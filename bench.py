@@ -331,32 +331,46 @@ def track_chain_leg(rank, local_rank, batches=(1, 8, 256), steps=(200, 100, 20),
         M, MB, mp0, mpb0, Tcw0 = seq.build_map(v0, tc.tables, map_cap=tc.map_cap, bird_cap=tc.bird_cap, extra_views=[(nframes - 1, v_end)])
         tc.set_map(M, MB)
         tc.init_first(mp0, mpb0, Tcw0)
-        path = _triangle_path(nframes, nwarm + 2 * nsteps)
+        path = _triangle_path(nframes, 2 * nwarm + 4 * nsteps + 8)
         dl = {}
         for a_, b_ in set(zip(path[:-1], path[1:])):
             dl[(a_, b_)] = torch.from_numpy(seq.delta_between(a_, b_)).to(dev)
         res = {}
         pos = 0
 
-        def run(n, sync_each):
+        def run(n, sync_each, pipelined):
             nonlocal pos
-            last_counts = None
             for _ in range(n):
                 a_, b_ = path[pos], path[pos + 1]
+                if pipelined:   # frame pos+2 is constructed on the extraction stream while frame pos+1 is tracked
+                    tc.prefetch(*imgs[path[pos + 2]], mask)
+                    tc.track_prefetched(dl[(a_, b_)], sync=sync_each)
+                else:
+                    tc.delta.copy_(dl[(a_, b_)], non_blocking=True)
+                    tc.track(*imgs[b_], mask)
+                    if sync_each:
+                        tc.counts()
                 pos += 1
-                tc.delta.copy_(dl[(a_, b_)], non_blocking=True)
-                tc.track(*imgs[b_], mask)
-                if sync_each:
-                    last_counts = tc.counts()
             torch.cuda.synchronize()
-            return last_counts
-        run(nwarm, True)
+        run(nwarm, True, False)
         for name, sync_each in (("dependent", True), ("free_running", False)):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            run(nsteps, sync_each)
+            run(nsteps, sync_each, False)
             dt = time.perf_counter() - t0
             res[name] = {"ms_per_step": dt / nsteps * 1e3, "ms_per_frame_pair": dt / nsteps / B * 1e3, "frames_per_s": B * nsteps / dt, "steps": nsteps}
+        # pipelined: the NEXT frame's construction (it needs only the images) overlaps the tracking of the current frame;
+        # the frame k -> frame k+1 dependency of pose / associations is untouched
+        tc.prefetch(*imgs[path[pos + 1]], mask)
+        run(min(nwarm, 8), True, True)
+        for name, sync_each in (("dependent_pipelined", True), ("free_running_pipelined", False)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(nsteps, sync_each, True)
+            dt = time.perf_counter() - t0
+            res[name] = {"ms_per_step": dt / nsteps * 1e3, "ms_per_frame_pair": dt / nsteps / B * 1e3, "frames_per_s": B * nsteps / dt, "steps": nsteps}
+        tc.track_prefetched(dl[(path[pos], path[pos + 1])], sync=True)   # drain the frame already constructed
+        pos += 1
         c, T = tc.counts()
         res["counters_mean_last_frame"] = {k: float(c[i].mean()) for k, i in cabi.FB_CNT.items()}
         tp = np.stack([np.asarray(seq.Tcw_true(path[pos], b))[:3, :4].reshape(12) for b in range(B)])
@@ -683,7 +697,8 @@ def main():
                 tcl = track_chain_leg(rank, local_rank)
                 out["track_chain"] = tcl
                 if isinstance(out.get("single_sequence"), dict):
-                    out["single_sequence"]["dependent"] = {k: tcl[k]["dependent"] for k in ("b1", "b8") if k in tcl}
+                    out["single_sequence"]["dependent"] = {k: {"serial": tcl[k]["dependent"], "pipelined_frame_construction": tcl[k]["dependent_pipelined"]}
+                                                           for k in ("b1", "b8") if k in tcl}
                 if tcl.get("parity_check", {}).get("mismatches"):
                     rc = 3
             except Exception as e:

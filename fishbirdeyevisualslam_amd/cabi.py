@@ -99,7 +99,7 @@ class ProjPointsArgs(C.Structure):
                 ("n_mp", _vp), ("mp_track", _vp), ("mp_obs_pos", _vp), ("mp_proj", _vp), ("mp_level", _vp),
                 ("mp_view_cos", _vp), ("mp_desc", _vp),
                 ("grid", GridGeom), ("scale_factors", _f32 * FB_MAX_LEVELS), ("th", _f32),
-                ("matcher", MatcherParams), ("match_cur_to_mp", _vp), ("nmatches", _vp)]
+                ("matcher", MatcherParams), ("match_cur_to_mp", _vp), ("nmatches", _vp), ("workspace", _vp), ("workspace_bytes", C.c_size_t)]
 
 
 class BirdviewArgs(C.Structure):
@@ -283,14 +283,14 @@ def fill(struct, **kw):
 
 # every symbol include/fishbird.h declares (checked by tests/test_cabi_exports.py)
 EXPORTS = [
-    "fb_abi_version", "fb_last_error", "fb_device_count", "fb_set_device",
+    "fb_abi_version", "fb_last_error", "fb_device_count", "fb_set_device", "fb_shutdown",
     "fb_prof_enable", "fb_prof_only", "fb_prof_reset", "fb_prof_report",
     "fb_orb_create", "fb_orb_destroy", "fb_orb_get_tables", "fb_orb_capacity", "fb_orb_extract", "fb_orb_extract_batch_dev",
     "fb_orb_get_level", "fb_orb_get_blurred_level", "fb_orb_debug_candidates", "fb_orb_debug_timers", "fb_grid_build_batch_dev", "fb_bird_keys_to_cam_dev", "fb_bird_guidance", "fb_bird_guidance_dev",
     "fb_descriptor_distance_dev", "fb_descriptor_distance",
     "fb_match_projection_frame_dev", "fb_match_projection_frame",
     "fb_match_bird_mappoints_dev", "fb_match_bird_mappoints",
-    "fb_match_projection_points_dev", "fb_match_projection_points",
+    "fb_match_projection_points_dev", "fb_match_projection_points", "fb_match_projection_points_workspace",
     "fb_match_birdview_dev", "fb_match_birdview",
     "fb_match_bow_dev", "fb_match_bow", "fb_match_triangulation_dev", "fb_match_triangulation",
     "fb_match_projection_keyframe_dev", "fb_match_projection_keyframe", "fb_match_bow_kf_dev", "fb_match_bow_kf",

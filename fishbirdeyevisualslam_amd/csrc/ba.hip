@@ -23,6 +23,8 @@
 // The accept/reject logic of Levenberg-Marquardt runs on the host between trials (a few scalars
 // are read back per trial); the abort flag (pbStopFlag) is polled there, between iterations.
 #include "fb_common.h"
+
+#include <thread>
 #include "fb_se3.h"
 
 #include <algorithm>
@@ -1606,6 +1608,29 @@ extern "C" int fb_local_ba_sharded_rccl(const fb_local_ba_args *A, int rank, int
 // Landmark-partitioned BA: rank r owns the landmarks l with l % world == r and all their edges, the
 // odometry edges live on rank 0, the keyframe state is replicated.  Per LM trial two small all-reduces: the
 // Schur-reduced system (after k_ba_schur) and [Hpp, bp, chi2, scale] (after the linearisation at the trial state).
+// per host thread and device: the side stream for the abort request, the pinned mirror of the control block and the event
+// the host waits on (concurrent callers must not share them; a stream belongs to its device).  fb_shutdown releases the
+// calling thread's set.
+struct PerDev { hipStream_t sAux = nullptr; BACtl *hCtl = nullptr; hipEvent_t evDone = nullptr; };
+static thread_local PerDev g_perDev[64];
+
+extern "C" int fb_shutdown(void) {
+  int cur = 0;
+  const bool have = hipGetDevice(&cur) == hipSuccess;
+  for (int d = 0; d < 64; d++) {
+    PerDev &pd = g_perDev[d];
+    if (!pd.sAux && !pd.hCtl && !pd.evDone) continue;
+    if (hipSetDevice(d) != hipSuccess) continue;
+    if (pd.evDone) (void)hipEventDestroy(pd.evDone);
+    if (pd.hCtl) (void)hipHostFree(pd.hCtl);
+    if (pd.sAux) (void)hipStreamDestroy(pd.sAux);
+    pd = PerDev();
+  }
+  if (have) (void)hipSetDevice(cur);
+  fb::pool_release();
+  return FB_OK;
+}
+
 static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, const BASchedule &sc) {
   FB_TRY(fb::check_device());
   const int world = X.world;
@@ -1616,15 +1641,17 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   };
   const bool sharded = X.active();
   auto reduce = [&](double *buf, int n, int op) -> int { return sharded ? X.reduce_host(buf, n, op) : FB_OK; };
-  FB_ARG(A && A->n_kf > 0 && A->n_mp >= 0 && A->n_mpb >= 0 && A->n_obs >= 0 && A->kf_Tcw && A->kf_fixed);
+  // (sharded: a rank must not return alone on ITS argument error -- the others would wait for it in the first exchange;
+  // the agreement block below reports it on every rank together)
+  if (!sharded) FB_ARG(A && A->n_kf > 0 && A->n_mp >= 0 && A->n_mpb >= 0 && A->n_obs >= 0 && A->kf_Tcw && A->kf_fixed);
   // Optimizer.cc:902-906 / 2498-2500.  Sharded: a rank must not leave on its OWN view of the flag (the others would wait for
   // it in the first exchange): every stop decision below goes through a reduction
   if (!sharded && A->stop_flag && *A->stop_flag) return FB_OK;
+  const bool argsOk = A && A->n_kf > 0 && A->n_mp >= 0 && A->n_mpb >= 0 && A->n_obs >= 0 && A->kf_Tcw && A->kf_fixed;
   if (sharded) {
     // Agreement on the arguments before the first exchange: a rank that rejected its input alone would leave the others
     // waiting in a collective.  (The same checks run again below, where they can no longer fail.)
-    int bad = 0;
-    if (!(A && A->n_kf > 0 && A->n_mp >= 0 && A->n_mpb >= 0 && A->n_obs >= 0 && A->kf_Tcw && A->kf_fixed)) bad = 1;
+    int bad = argsOk ? 0 : 1;
     if (!bad) {
       const bool od = A->with_odom != 0;
       int free = 0;
@@ -1913,12 +1940,10 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
     // per host thread and device (concurrent callers must not share the pinned mirror; a stream belongs to its device):
     // side stream for the abort request (does not synchronise with the null stream), pinned mirror of the control block,
     // the event the host polls
-    struct PerDev { hipStream_t sAux = nullptr; BACtl *hCtl = nullptr; hipEvent_t evDone = nullptr; };
-    static thread_local PerDev perDev[64];
     int devId = 0;
     FB_HIP(hipGetDevice(&devId));
     if (devId < 0 || devId >= 64) { fb::set_error("fb_local_ba: device id %d", devId); return FB_ERR_NODEVICE; }
-    PerDev &pd = perDev[devId];
+    PerDev &pd = g_perDev[devId];
     if (!pd.sAux) FB_HIP(hipStreamCreateWithFlags(&pd.sAux, hipStreamNonBlocking));
     if (!pd.hCtl) FB_HIP(hipHostMalloc(reinterpret_cast<void **>(&pd.hCtl), sizeof(BACtl), hipHostMallocDefault));
     if (!pd.evDone) FB_HIP(hipEventCreateWithFlags(&pd.evDone, hipEventDisableTiming));
@@ -2019,13 +2044,21 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
       if (hipMemcpyAsync(hCtl, ctl, sizeof(BACtl), hipMemcpyDeviceToHost, s0) != hipSuccess || hipEventRecord(evDone, s0) != hipSuccess) {
         fb::set_error("fb_local_ba: control block read-back failed"); rcLoop = FB_ERR_HIP; break;
       }
-      for (;;) {  // wait; meanwhile forward pbStopFlag (the control kernel sees it at the end of the slot that is running)
-        const hipError_t q = hipEventQuery(evDone);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) { fb::set_error("fb_local_ba: %s", hipGetErrorString(q)); rcLoop = FB_ERR_HIP; break; }
-        if (!abortSent && A->stop_flag && *A->stop_flag) {
-          (void)hipMemcpyAsync(d_abort.p, &one, sizeof(int), hipMemcpyHostToDevice, sAux);
-          abortSent = true;
+      if (!A->stop_flag) {  // nothing to forward: block in the driver instead of holding a host core
+        const hipError_t q = hipEventSynchronize(evDone);
+        if (q != hipSuccess) { fb::set_error("fb_local_ba: %s", hipGetErrorString(q)); rcLoop = FB_ERR_HIP; }
+      } else {
+        for (;;) {  // wait; meanwhile forward pbStopFlag (the control kernel sees it at the end of the slot that is running)
+          const hipError_t q = hipEventQuery(evDone);
+          if (q == hipSuccess) break;
+          if (q != hipErrorNotReady) { fb::set_error("fb_local_ba: %s", hipGetErrorString(q)); rcLoop = FB_ERR_HIP; break; }
+          if (!abortSent && *A->stop_flag) {
+            (void)hipMemcpyAsync(d_abort.p, &one, sizeof(int), hipMemcpyHostToDevice, sAux);
+            abortSent = true;
+          }
+          // a BA lasts milliseconds and the flag only has to reach the device before the running slot (~0.1 ms) ends:
+          // poll every 20 us instead of spinning on the LocalMapping thread's core
+          std::this_thread::sleep_for(std::chrono::microseconds(20));
         }
       }
       if (rcLoop != FB_OK || hCtl->phase == 2) break;

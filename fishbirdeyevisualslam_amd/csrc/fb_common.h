@@ -73,6 +73,7 @@ struct ProfScope {  // (the record list is mutex-protected and a scope closes it
 // buffers per call, so freed blocks are kept in a per-device pool of power-of-two size classes (runtime.hip).
 void *pool_take(size_t bytes, size_t *granted);  // nullptr on failure (error set)
 void pool_give(void *p, size_t granted);
+void pool_release();  // frees every idle block (fb_shutdown)
 
 struct DevBuf {
   void *p = nullptr;

@@ -172,6 +172,66 @@ __global__ __launch_bounds__(GUIDE_THREADS) void k_bird_guidance(fb_bird_guidanc
   if (tid == 0) A.n_out[b] = total;
 }
 
+// The same in two launches, taken when the caller passes a `keep` array (it doubles as the flag store): the verdicts by
+// 8 key points per 256-thread workgroup -- thousands of independent row walks in flight instead of 32 at a time inside
+// one workgroup, whose serialised byte loads made the one-kernel version 0.29 ms per frame at batch 1 (rocprof, round 3)
+// -- and the stable compaction by one workgroup per image.
+__global__ __launch_bounds__(256) void k_bird_flags(fb_bird_guidance_args A) {
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int n = min(max(A.n_in[b], 0), A.kp_stride);
+  const int i = blockIdx.x * 8 + (tid >> 5), sub = tid & 31;
+  if (blockIdx.x * 8 >= n) return;
+  const size_t ko = (size_t)b * A.kp_stride;
+  const uint8_t *icp = A.contour + (size_t)b * A.rows * A.pitch;
+  const uint8_t *mask = A.mask ? A.mask + (size_t)b * A.rows * A.pitch : nullptr;
+  bool hit = false, ok = true;
+  if (i < n) {
+    const fb_keypoint kpt = A.kps_in[ko + i];
+    const int r = 10;
+    const float pt1x = (kpt.x - r) > 0 ? (kpt.x - r) : 0;
+    const float pt1y = (kpt.y - r) > 0 ? (kpt.y - r) : 0;
+    const float pt2x = (kpt.x + r) < A.cols ? (kpt.x + r) : A.cols;
+    const float pt2y = (kpt.y + r) < A.rows ? (kpt.y + r) : A.rows;
+    const size_t row = (size_t)pt1x + sub;       // size_t row = pt1x; row < pt2x; row++
+    if ((float)row < pt2x && row < (size_t)A.rows) {
+      const uint8_t *src = icp + row * (size_t)A.pitch;
+      for (size_t col = (size_t)pt1y; (float)col < pt2y && col < (size_t)A.cols; col++)
+        if (src[col] >= 10) { hit = true; break; }
+    }
+    if (mask) {
+      const int my = (int)(kpt.y + 0.5f), mx = (int)(kpt.x + 0.5f);
+      ok = my >= 0 && my < A.rows && mx >= 0 && mx < A.cols && mask[(size_t)my * A.pitch + mx] != 0;
+    }
+  }
+  const unsigned long long bal = __ballot(hit);
+  const unsigned int mine = (unsigned int)(bal >> (tid & 32));
+  if (sub == 0 && i < n) A.keep[ko + i] = (ok && mine != 0u) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(GUIDE_THREADS) void k_bird_compact(fb_bird_guidance_args A) {
+  __shared__ int s_w[GUIDE_THREADS / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = min(max(A.n_in[b], 0), A.kp_stride);
+  const size_t ko = (size_t)b * A.kp_stride;
+  const int per = (n + GUIDE_THREADS - 1) / GUIDE_THREADS;
+  const int i0 = min(n, tid * per), i1 = min(n, i0 + per);
+  int cnt = 0;
+  for (int i = i0; i < i1; i++) cnt += A.keep[ko + i];
+  int total;
+  int o = block_excl_scan1024(cnt, s_w, &total);
+  for (int i = i0; i < i1; i++) {
+    if (!A.keep[ko + i]) continue;
+    A.kps_out[ko + o] = A.kps_in[ko + i];
+    if (A.desc_in) {
+      const uint4 *src = reinterpret_cast<const uint4 *>(A.desc_in + (ko + i) * 32);
+      uint4 *dst = reinterpret_cast<uint4 *>(A.desc_out + (ko + o) * 32);
+      dst[0] = src[0]; dst[1] = src[1];
+    }
+    o++;
+  }
+  if (tid == 0) A.n_out[b] = total;
+}
+
 // genEdgesPC: raster-order compaction of the contour pixels into the "sign" ([10,150)) and "free" (>= 150) point lists.
 // A thread owns a contiguous run of the raster, two block scans give its output offsets.
 __global__ __launch_bounds__(GUIDE_THREADS) void k_bird_edges(fb_bird_guidance_args A) {
@@ -224,7 +284,12 @@ int fb_bird_guidance_dev(const fb_bird_guidance_args *A, void *stream) {
   if (lds > 150 * 1024) { fb::set_error("fb_bird_guidance: kp_stride %d beyond the LDS flag array", A->kp_stride); return FB_ERR_CAPACITY; }
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bird_guidance), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   fb::ProfScope prof_(fb::P_BIRDCAM, fb::as_stream(stream));
-  k_bird_guidance<<<A->batch, GUIDE_THREADS, lds, fb::as_stream(stream)>>>(*A);
+  if (A->keep && A->kp_stride > 0 && A->batch <= 65535) {
+    k_bird_flags<<<dim3((A->kp_stride + 7) / 8, A->batch), 256, 0, fb::as_stream(stream)>>>(*A);
+    k_bird_compact<<<A->batch, GUIDE_THREADS, 0, fb::as_stream(stream)>>>(*A);
+  } else {
+    k_bird_guidance<<<A->batch, GUIDE_THREADS, lds, fb::as_stream(stream)>>>(*A);
+  }
   FB_HIP(hipGetLastError());
   if (A->edge_cap > 0) {
     k_bird_edges<<<A->batch, GUIDE_THREADS, 0, fb::as_stream(stream)>>>(*A);

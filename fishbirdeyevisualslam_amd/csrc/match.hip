@@ -449,6 +449,9 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_kf(fb_proj_kf_args A, in
 // ---------------------------------------------------------------------------------------
 // M2  SearchByProjection(Frame&, const vector<MapPoint*>&, th)
 // ---------------------------------------------------------------------------------------
+#ifdef FB_MATCH_STAMPS
+__device__ int g_m2_rounds[4];  // probe build only: rounds / queries in view / launches of k_proj_points (block 0)
+#endif
 __global__ __launch_bounds__(MATCH_THREADS) void k_proj_points(fb_proj_points_args A, int descInLds) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -493,6 +496,153 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_points(fb_proj_points_ar
             bestLevel2 = T.oct[idx]; bestDist2 = dist;
           }
         });
+        if (bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && bestDist > A.matcher.nnratio * bestDist2)) best = bestIdx;
+      }
+      assignB[q] = best;
+      if (best != assignA[q]) s_changed = 1;
+      if (best != NONE && A.mp_obs_pos[mo + q]) atomicMin(&ownerB[best], q);
+    }
+    __syncthreads();
+    const int changed = s_changed;
+    int *t = ownerA; ownerA = ownerB; ownerB = t;
+    t = assignA; assignA = assignB; assignB = t;
+    __syncthreads();
+#ifdef FB_MATCH_STAMPS
+    if (b == 0 && tid == 0) atomicAdd(&g_m2_rounds[0], 1);
+#endif
+    if (!changed) break;
+  }
+#ifdef FB_MATCH_STAMPS
+  if (b == 0 && tid == 0) { atomicAdd(&g_m2_rounds[2], 1); int c = 0; for (int q = 0; q < nmp; q++) c += A.mp_track[mo + q]; atomicAdd(&g_m2_rounds[1], c); }
+#endif
+  int *matchL = ownerB;
+  for (int i = tid; i < ncur; i += nt) matchL[i] = -1;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  for (int q = tid; q < nmp; q += nt) {
+    const int c = assignA[q];
+    if (c == NONE) continue;
+    atomicMax(&matchL[c], q);
+    atomicAdd(&s_n, 1);
+  }
+  __syncthreads();
+  for (int i = tid; i < ncur; i += nt) A.match_cur_to_mp[co + i] = matchL[i];
+  if (tid == 0) A.nmatches[b] = s_n;
+}
+
+// ---------------------------------------------------------------------------------------
+// M2 in two phases (taken when the caller provides a workspace): the expensive, owner-independent part of a query -- the
+// grid walk and the Hamming distances of its candidates -- is done ONCE, by many workgroups per problem; the serial
+// "already taken" rule is then resolved by one workgroup per problem on the cached candidate lists.  In the one-kernel
+// version every round repeated every walk inside a single workgroup: 0.68 ms per frame for a 4000-point local map at
+// batch 1 (rocprof, round 3), most of a tracked frame.
+//   candidate record: dist << 20 | octave << 16 | key point index, in grid-walk order (the order decides ties);
+//   M2_K records per query + a count; a query with more candidates keeps count = M2_OVER and is walked again each round.
+// ---------------------------------------------------------------------------------------
+constexpr int M2_K = 8, M2_OVER = 255, M2_CAND_THREADS = 256;
+
+struct GridLds { const float2 *xy; const uint8_t *oct; const uint16_t *cs; const uint16_t *items; };
+__device__ __forceinline__ TargetLds stage_grid_only(uint8_t *smem, const Carve &cv, int n, int ncell, const fb_keypoint *kps,
+                                                     const uint8_t *desc, const int32_t *cs, const int32_t *items) {
+  return stage_target(smem, cv, n, ncell, kps, desc, cs, items, false);
+}
+
+__device__ __forceinline__ float m2_radius(const fb_proj_points_args &A, size_t e, bool bFactor, int lvl) {
+  float r = A.mp_view_cos[e] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos
+  if (bFactor) r *= A.th;
+  return r * A.scale_factors[lvl];
+}
+
+__global__ __launch_bounds__(M2_CAND_THREADS) void k_m2_candidates(fb_proj_points_args A, uint32_t *cand, uint8_t *ncand) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int ncell = A.grid.cols * A.grid.rows;
+  const size_t co = (size_t)b * A.cur_stride, mo = (size_t)b * A.mp_stride;
+  const int ncur = A.n_cur[b], nmp = A.n_mp[b];
+  if ((int)(blockIdx.x * M2_CAND_THREADS) >= nmp) return;
+  const Carve cv(A.cur_stride, ncell, false);
+  const TargetLds T = stage_grid_only(smem, cv, ncur, ncell, A.cur_kps + co, A.cur_desc + co * 32,
+                                      A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co);
+  __syncthreads();
+  const int q = blockIdx.x * M2_CAND_THREADS + tid;
+  if (q >= nmp) return;
+  int n = 0;
+  if (A.mp_track[mo + q]) {
+    const int lvl = A.mp_level[mo + q];
+    uint32_t d[8];
+    const uint4 *dq = reinterpret_cast<const uint4 *>(A.mp_desc + (mo + q) * 32);
+    const uint4 d0 = dq[0], d1 = dq[1];
+    d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+    uint32_t *out = cand + (mo + q) * M2_K;
+    for_area<false>(A.grid, T, A.mp_proj[(mo + q) * 2], A.mp_proj[(mo + q) * 2 + 1], m2_radius(A, mo + q, A.th != 1.0f, lvl), lvl - 1, lvl,
+                    [&](int idx) {
+      if (n < M2_K) {
+        const int dist = fb::hamming256(d, T.desc + idx * 2);
+        out[n] = ((uint32_t)dist << 20) | ((uint32_t)T.oct[idx] << 16) | (uint32_t)idx;
+      }
+      n++;
+    });
+    if (n > M2_K) n = M2_OVER;
+  }
+  ncand[mo + q] = (uint8_t)n;
+}
+
+__global__ __launch_bounds__(MATCH_THREADS) void k_m2_resolve(fb_proj_points_args A, const uint32_t *cand, const uint8_t *ncand) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int ncell = A.grid.cols * A.grid.rows;
+  const size_t co = (size_t)b * A.cur_stride, mo = (size_t)b * A.mp_stride;
+  const int ncur = A.n_cur[b], nmp = A.n_mp[b];
+  const Carve cv(A.cur_stride, ncell, false);
+  const TargetLds T = stage_grid_only(smem, cv, ncur, ncell, A.cur_kps + co, A.cur_desc + co * 32,
+                                      A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co);
+  int *ownerA = reinterpret_cast<int *>(smem + cv.end);
+  int *ownerB = ownerA + A.cur_stride;
+  int *assignA = ownerB + A.cur_stride;
+  int *assignB = assignA + A.mp_stride;
+  __shared__ int s_changed, s_n;
+  const uint8_t *blocked0 = A.cur_blocked ? A.cur_blocked + co : nullptr;
+  for (int i = tid; i < ncur; i += nt) ownerA[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
+  for (int q = tid; q < nmp; q += nt) assignA[q] = NONE;
+  const bool bFactor = A.th != 1.0f;
+  __syncthreads();
+  for (int round = 0; round <= nmp + 1; round++) {
+    for (int i = tid; i < ncur; i += nt) ownerB[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    for (int q = tid; q < nmp; q += nt) {
+      int best = NONE;
+      const int nc = ncand[mo + q];
+      if (nc > 0) {
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        auto take = [&](int idx, int dist, int lev) {
+          if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = lev; bestIdx = idx; }
+          else if (dist < bestDist2) { bestLevel2 = lev; bestDist2 = dist; }
+        };
+        if (nc != M2_OVER) {
+          const uint4 *cq = reinterpret_cast<const uint4 *>(cand + (mo + q) * M2_K);
+          const uint4 c0 = cq[0];
+          uint32_t c[M2_K] = {c0.x, c0.y, c0.z, c0.w, 0, 0, 0, 0};
+          if (nc > 4) { const uint4 c1 = cq[1]; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w; }
+#pragma unroll
+          for (int k = 0; k < M2_K; k++) {
+            if (k >= nc) break;
+            const int idx = (int)(c[k] & 0xFFFFu);
+            if (ownerA[idx] < q) continue;
+            take(idx, (int)(c[k] >> 20), (int)((c[k] >> 16) & 0xF));
+          }
+        } else {  // more candidates than the cache holds: the full walk, descriptors from HBM / L2
+          const int lvl = A.mp_level[mo + q];
+          uint32_t d[8];
+          const uint4 *dq = reinterpret_cast<const uint4 *>(A.mp_desc + (mo + q) * 32);
+          const uint4 d0 = dq[0], d1 = dq[1];
+          d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+          for_area<false>(A.grid, T, A.mp_proj[(mo + q) * 2], A.mp_proj[(mo + q) * 2 + 1], m2_radius(A, mo + q, bFactor, lvl), lvl - 1, lvl,
+                          [&](int idx) {
+            if (ownerA[idx] < q) return;
+            take(idx, fb::hamming256(d, T.desc + idx * 2), (int)T.oct[idx]);
+          });
+        }
         if (bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && bestDist > A.matcher.nnratio * bestDist2)) best = bestIdx;
       }
       assignB[q] = best;
@@ -880,11 +1030,37 @@ int fb_match_projection_keyframe_dev(const fb_proj_kf_args *A, void *stream) {
   return FB_OK;
 }
 
+#ifdef FB_MATCH_STAMPS
+int fb_match_debug_m2(int *dst4) {  // probe build only
+  int z[4] = {0, 0, 0, 0};
+  FB_HIP(hipMemcpyFromSymbol(dst4, HIP_SYMBOL(g_m2_rounds), sizeof(z)));
+  FB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_m2_rounds), z, sizeof(z)));
+  return FB_OK;
+}
+#endif
+
 int fb_match_projection_points_dev(const fb_proj_points_args *A, void *stream) {
   FB_TRY(fb::check_device());
   FB_ARG(A && A->batch >= 0 && A->cur_stride > 0 && A->mp_stride >= 0 && A->cur_stride < 65536);
   if (A->batch == 0) return FB_OK;
   const int ncell = A->grid.cols * A->grid.rows;
+  const size_t wsNeed = fb_match_projection_points_workspace(A->batch, A->mp_stride);
+  if (A->workspace && A->workspace_bytes >= wsNeed && A->mp_stride > 0 && A->batch <= 65535 && ((uintptr_t)A->workspace % 16) == 0) {
+    // two phases: candidate lists by many workgroups, then the serial rule on the lists (see k_m2_candidates)
+    uint32_t *cand = reinterpret_cast<uint32_t *>(A->workspace);
+    uint8_t *ncand = reinterpret_cast<uint8_t *>(cand + (size_t)A->batch * A->mp_stride * M2_K);
+    const size_t ldsA = Carve(A->cur_stride, ncell, false).end;
+    const size_t ldsB = ldsA + ((size_t)2 * A->cur_stride + (size_t)2 * A->mp_stride) * 4;
+    if (ldsB <= LDS_BUDGET) {
+      FB_TRY(set_max_lds(k_m2_candidates, ldsA));
+      FB_TRY(set_max_lds(k_m2_resolve, ldsB));
+      fb::ProfScope prof_(fb::P_PROJ_POINTS, fb::as_stream(stream));
+      k_m2_candidates<<<dim3((A->mp_stride + M2_CAND_THREADS - 1) / M2_CAND_THREADS, A->batch), M2_CAND_THREADS, ldsA, fb::as_stream(stream)>>>(*A, cand, ncand);
+      k_m2_resolve<<<A->batch, MATCH_THREADS, ldsB, fb::as_stream(stream)>>>(*A, cand, ncand);
+      FB_HIP(hipGetLastError());
+      return FB_OK;
+    }
+  }
   LdsPlan lp;
   FB_TRY(plan_lds(A->cur_stride, ncell, 2 * A->cur_stride + 2 * A->mp_stride, "fb_match_projection_points", &lp));
   const size_t lds = lp.bytes;
@@ -893,6 +1069,11 @@ int fb_match_projection_points_dev(const fb_proj_points_args *A, void *stream) {
   k_proj_points<<<A->batch, MATCH_THREADS, lds, fb::as_stream(stream)>>>(*A, lp.descInLds);
   FB_HIP(hipGetLastError());
   return FB_OK;
+}
+
+size_t fb_match_projection_points_workspace(int batch, int mp_stride) {
+  if (batch <= 0 || mp_stride <= 0) return 0;
+  return (size_t)batch * mp_stride * (M2_K * 4 + 1) + 16;
 }
 
 int fb_match_bird_mappoints_dev(const fb_bird_mp_args *A, void *stream) {
@@ -986,6 +1167,14 @@ int fb_match_projection_points(const fb_proj_points_args *H) {
   FB_TRY(o1.alloc(B * 4));
   D.match_cur_to_mp = o0.as<int32_t>();
   D.nmatches = o1.as<int32_t>();
+  fb::DevBuf ws;  // the two-phase matcher (this call is synchronous, so a pooled block is safe as its workspace)
+  static const bool onePhase = getenv("FB_M2_ONE_KERNEL") != nullptr;  // measurements / tests of the one-kernel version
+  D.workspace = nullptr; D.workspace_bytes = 0;
+  if (!onePhase && B * ms > 0) {
+    D.workspace_bytes = fb_match_projection_points_workspace((int)B, (int)ms);
+    FB_TRY(ws.alloc(D.workspace_bytes));
+    D.workspace = ws.p;
+  }
   FB_TRY(fb_match_projection_points_dev(&D, nullptr));
   FB_HIP(hipDeviceSynchronize());
   FB_TRY(o0.download(H->match_cur_to_mp, B * cs * 4));

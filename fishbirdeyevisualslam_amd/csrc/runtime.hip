@@ -71,6 +71,19 @@ void pool_give(void *p, size_t granted) {
   g_pooled_bytes += granted;
 }
 
+void pool_release() {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  int cur = 0;
+  const bool have = hipGetDevice(&cur) == hipSuccess;
+  for (auto &kv : g_free) {
+    if (kv.second.empty() || hipSetDevice(kv.first.first) != hipSuccess) continue;
+    for (void *p : kv.second) (void)hipFree(p);
+    kv.second.clear();
+  }
+  g_pooled_bytes = 0;
+  if (have) (void)hipSetDevice(cur);
+}
+
 bool g_prof_on = false;
 int g_prof_only = -1;
 namespace {

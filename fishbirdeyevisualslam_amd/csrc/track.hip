@@ -408,7 +408,7 @@ struct fb_frame {
   fb::DevBuf m9_valid, m9_xw, m9_desc, m9_n, m_bird, ones;
   fb::DevBuf e_fxw, e_fobs, e_finf, e_fvalid, e_bxw, e_bxc, e_binf, e_bvalid;
   fb::DevBuf m8_m12, m8_dist, m8_n, m8_nd;
-  fb::DevBuf l_seen, l_blocked, l_inview, l_obs, l_proj, l_level, l_cos, l_desc, l_n, m_local;
+  fb::DevBuf l_seen, l_blocked, l_inview, l_obs, l_proj, l_level, l_cos, l_desc, l_n, m_local, m2_ws;
   // images from host callers
   fb::DevBuf img_f, img_b, img_c, img_m;
   uint8_t *pin = nullptr;
@@ -535,6 +535,7 @@ int fb_frame_create(const fb_frame_params *p, fb_frame **out) {
   AL(m8_m12, B * cap * 4); AL(m8_dist, B * cap * 4); AL(m8_n, B * 4); AL(m8_nd, B * 4);
   AL(l_seen, B * (size_t)p->map_cap); AL(l_blocked, B * cap); AL(l_inview, B * lm); AL(l_obs, B * lm); AL(l_proj, B * lm * 8);
   AL(l_level, B * lm * 4); AL(l_cos, B * lm * 4); AL(l_desc, B * lm * 32); AL(l_n, B * 4); AL(m_local, B * cap * 4);
+  AL(m2_ws, fb_match_projection_points_workspace((int)B, (int)lm));
 #undef AL
   if (rc != FB_OK) { delete f; return rc; }
   hipError_t e = hipMemset(f->ones.p, 1, B * lb);
@@ -587,6 +588,7 @@ int fb_frame_extract_dev(fb_frame *f, fb_orb *of, fb_orb *ob, const uint8_t *d_f
       G.batch = B; G.kp_stride = cap; G.cols = f->P.bird_width; G.rows = f->P.bird_height; G.pitch = bird_stride;
       G.contour = d_contour; G.mask = d_mask; G.n_in = n0; G.kps_in = k0; G.desc_in = d0;
       G.n_out = f->nb.as<int32_t>(); G.kps_out = f->bkps.as<fb_keypoint>(); G.desc_out = f->bdesc.as<uint8_t>();
+      G.keep = f->l_blocked.as<uint8_t>();  // [batch][cap] scratch, free at this point of the frame: the verdicts are computed by many workgroups
       FB_TRY(fb_bird_guidance_dev(&G, sb));
     }
     FB_TRY(fb_bird_keys_to_cam_dev(f->bkps.as<fb_keypoint>(), f->nb.as<int32_t>(), B, cap, f->P.bird_width, f->P.bird_height,
@@ -752,6 +754,7 @@ int local_impl(fb_frame *f, const fb_map_points *map, const int32_t *d_local, co
   for (int i = 0; i < FB_MAX_LEVELS; i++) A.scale_factors[i] = f->tab.scale_factor[i];
   A.th = th; A.matcher = *matcher;
   A.match_cur_to_mp = f->m_local.as<int32_t>(); A.nmatches = f->cnt(FB_CNT_LOCAL_MATCHES);
+  A.workspace = f->m2_ws.p; A.workspace_bytes = f->m2_ws.bytes;
   return fb_match_projection_points_dev(&A, s);
 }
 

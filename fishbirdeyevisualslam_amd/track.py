@@ -58,10 +58,14 @@ class TrackChain:
         check(self.L.fb_orb_create(C.byref(orbp), C.byref(self.orb_b)), "fb_orb_create")
         self.tables = cabi.OrbTables()
         check(self.L.fb_orb_get_tables(self.orb_f, C.byref(self.tables)), "fb_orb_get_tables")
-        self.frames = [C.c_void_p(), C.c_void_p()]
+        # three handles: frame j lives in frames[j % 3]; with the pipelined driver frame k+1 is being constructed on the
+        # extraction stream while frame k is tracked against frame k-1
+        self.frames = [C.c_void_p(), C.c_void_p(), C.c_void_p()]
         for f in self.frames:
             check(self.L.fb_frame_create(C.byref(self.params), C.byref(f)), "fb_frame_create")
-        self.k = 0          # frames[k & 1] is the current frame, the other one the last
+        self.k = 0          # frames[k % 3] is the current frame, frames[(k - 1) % 3] the last
+        self._kext = 0      # next frame index the pipelined driver constructs
+        self._pipe = None
         self.use_lists = use_lists
         z = lambda *s, dt=torch.uint8: torch.zeros(*s, dtype=dt, device=self.dev)
         B, mc, bc = batch, self.map_cap, self.bird_cap
@@ -103,11 +107,56 @@ class TrackChain:
 
     @property
     def cur(self):
-        return self.frames[self.k & 1]
+        return self.frames[self.k % 3]
 
     @property
     def last(self):
-        return self.frames[(self.k & 1) ^ 1]
+        return self.frames[(self.k - 1) % 3]
+
+    # ---- pipelined driver: Frame construction of frame k+1 (extraction stream) beside the tracking of frame k ----
+    _streams = {}
+
+    def _pipe_init(self):
+        if self._pipe is None:
+            key = str(self.dev)
+            if key not in TrackChain._streams:  # shared per device: HIP folds streams onto few hardware queues
+                TrackChain._streams[key] = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
+            sE, sT = TrackChain._streams[key]
+            self._pipe = dict(sE=sE, sT=sT, evE=[torch.cuda.Event() for _ in range(3)], evT=[torch.cuda.Event() for _ in range(3)],
+                              tracked=[False] * 3)
+            self._kext = self.k
+        return self._pipe
+
+    def prefetch(self, front, bird, contour=None, mask=None):
+        """Frame::Frame of the next frame on the extraction stream (the images do not depend on the tracking results)."""
+        P = self._pipe_init()
+        j = self._kext
+        h = j % 3
+        sE = P["sE"]
+        sE.wait_stream(torch.cuda.current_stream(self.dev))
+        if P["tracked"][(j + 1) % 3]:  # handle h was `last` for the frame in handle (j + 1) % 3 == (j - 2) % 3
+            sE.wait_event(P["evT"][(j + 1) % 3])
+        with torch.cuda.stream(sE):
+            self.extract(front, bird, contour, mask, frame=self.frames[h])
+            P["evE"][h].record(sE)
+        self._kext = j + 1
+
+    def track_prefetched(self, delta_dev=None, sync=False):
+        """Track frame k (constructed by prefetch) against frame k-1 on the tracking stream."""
+        P = self._pipe_init()
+        h = self.k % 3
+        sT = P["sT"]
+        sT.wait_event(P["evE"][h])
+        with torch.cuda.stream(sT):
+            if delta_dev is not None:
+                self.delta.copy_(delta_dev, non_blocking=True)
+            check(self.L.fb_frame_track_dev(self.cur, self.last, C.byref(self.targs), C.c_void_p(sT.cuda_stream)), "fb_frame_track_dev")
+            P["evT"][h].record(sT)
+            P["tracked"][h] = True
+            self.k += 1
+            if sync:
+                return self.counts()
+        return None
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -158,15 +207,19 @@ class TrackChain:
         self.k += 1
 
     # ---- results ----
+    def _which(self, which):
+        return {"last": self.last, "cur": self.cur, "prev": self.frames[(self.k - 2) % 3]}[which]
+
     def view(self, which="last"):
-        f = self.last if which == "last" else self.cur
+        """last = the frame tracked most recently, prev = the one before it (the reference frame of that step), cur = the next handle."""
+        f = self._which(which)
         if "bufs" not in self._hv:
             self._hv["bufs"], self._hv["v"] = alloc_view(self.B, self.cap)
         check(self.L.fb_frame_download(f, C.byref(self._hv["v"]), self._stream()), "fb_frame_download")
         return {k: v.copy() for k, v in self._hv["bufs"].items()}
 
     def counts(self, which="last"):
-        f = self.last if which == "last" else self.cur
+        f = self._which(which)
         c = np.zeros((cabi.FB_CNT_COUNT, self.B), np.int32)
         t = np.zeros((self.B, 12), np.float32)
         check(self.L.fb_frame_counts(f, C.c_void_p(c.ctypes.data), C.c_void_p(t.ctypes.data), self._stream()), "fb_frame_counts")

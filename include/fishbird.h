@@ -50,6 +50,10 @@ int fb_abi_version(void);
 const char *fb_last_error(void);
 int fb_device_count(void);
 int fb_set_device(int device);
+/* Releases what the library keeps between calls: the idle blocks of the device scratch pool (all devices) and the calling
+ * thread's bundle-adjustment stream / event / pinned control block.  Handles (fb_orb, fb_frame, communicators) stay valid;
+ * the next call simply allocates again.  Call it from every thread that ran a bundle adjustment before the thread ends. */
+int fb_shutdown(void);
 
 /* ---- per-kernel timing (HIP events on the launch stream) ------------------- */
 /* When enabled every kernel launch of this library is bracketed by two hipEvents
@@ -308,7 +312,14 @@ typedef struct fb_proj_points_args {
   fb_matcher_params matcher;
   int32_t *match_cur_to_mp;      /* [batch][cur_stride] index into mp or -1     */
   int32_t *nmatches;
+  /* optional device scratch of fb_match_projection_points_workspace(batch, mp_stride) bytes, 16-byte aligned, private to
+   * this call until it has run: with it the grid walks and Hamming distances are computed once by many workgroups per
+   * problem and only the serial "already taken" rule runs in one workgroup (same results; several times faster for the
+   * few-thousand-point local maps of TrackLocalMap, above all at small batch).  NULL = the one-kernel version.        */
+  void *workspace;
+  size_t workspace_bytes;
 } fb_proj_points_args;
+size_t fb_match_projection_points_workspace(int batch, int mp_stride);
 int fb_match_projection_points_dev(const fb_proj_points_args *args, void *stream);
 int fb_match_projection_points(const fb_proj_points_args *args);
 

@@ -57,7 +57,7 @@ def _lists(M, MB, seed):
     return (lm, nlm), (lb, nlb)
 
 
-def _run(B, K, front_wh, bird_wh, fx, use_lists, seed, granular=False, contour=True):
+def _run(B, K, front_wh, bird_wh, fx, use_lists, seed, granular=False, contour=True, pipelined=False):
     from oracle import pyoracle as O
     seq = S.Sequence(B, K, seed=seed, front_wh=front_wh, bird_wh=bird_wh, fx=fx, fy=fx, device="cuda:0")
     tc = T.TrackChain(B, front_wh, bird_wh, K=seq.Kc, D=seq.D, use_lists=use_lists)
@@ -80,18 +80,27 @@ def _run(B, K, front_wh, bird_wh, fx, use_lists, seed, granular=False, contour=T
     tc.init_first(mp0, mpb0, Tcw0)
     oc.init_first(mp0, mpb0, Tcw0)
     worst, stats = 0.0, []
+    frames = [seq.render(k) for k in range(K)] if pipelined else None
+    if pipelined:
+        tc.prefetch(*frames[1], mask_d)
     for k in range(1, K):
-        f, b, c = seq.render(k)
+        f, b, c = frames[k] if pipelined else seq.render(k)
         if not contour:
             c = None
         d = seq.delta(k)
-        tc.set_delta(d)
-        (tc.track_granular if granular else tc.track)(f, b, c, mask_d)
+        if pipelined:  # frame k+1 is constructed on the extraction stream while frame k is tracked
+            if k + 1 < K:
+                tc.prefetch(*frames[k + 1], mask_d)
+            tc.track_prefetched(torch.from_numpy(d).cuda())
+            torch.cuda.synchronize()
+        else:
+            tc.set_delta(d)
+            (tc.track_granular if granular else tc.track)(f, b, c, mask_d)
         oc.track(h(f), h(b), h(c), mask_h, d)
         g, o = tc.view(), oc.view()
         worst = max(worst, _cmp_view(g, o, "frame %d" % k))
         # the frame that was `last` during this step received the new MapPointBirds too (Tracking.cc:1899)
-        gl, ol = tc.view("cur"), oc.view("cur")
+        gl, ol = tc.view("prev"), oc.view("cur")
         for bb in range(B):
             nb = int(ol["n_bird"][bb])
             assert np.array_equal(gl["map_point_bird"][bb, :nb], ol["map_point_bird"][bb, :nb]), ("ref frame bird points", k, bb)
@@ -130,6 +139,13 @@ def test_chain_granular_entry_points():
     """The one-call-per-reference-function entry points (each commit its own launch) give what the fused call gives."""
     worst, stats = _run(2, 5, (640, 480), (384, 384), 250.0, use_lists=True, seed=9200, granular=True)
     worst2, stats2 = _run(2, 5, (640, 480), (384, 384), 250.0, use_lists=True, seed=9200, granular=False)
+    assert stats == stats2
+
+
+def test_chain_pipelined_driver():
+    """Frame construction of frame k+1 on a second stream beside the tracking of frame k (three frame handles): same results."""
+    worst, stats = _run(2, 7, (640, 480), (384, 384), 250.0, use_lists=False, seed=9600, pipelined=True)
+    worst2, stats2 = _run(2, 7, (640, 480), (384, 384), 250.0, use_lists=False, seed=9600, pipelined=False)
     assert stats == stats2
 
 
