@@ -1475,6 +1475,8 @@ struct RcclApi {
   int (*CommDestroy)(void *) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
+  int (*CommCount)(void *, int *) = nullptr;
+  int (*CommUserRank)(void *, int *) = nullptr;
 };
 RcclApi *rccl_api() {
   // loaded once (a function-local static is initialised thread-safely)
@@ -1490,6 +1492,8 @@ RcclApi *rccl_api() {
       a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
       a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(a.lib, "ncclAllReduce"));
       a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
+      a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(a.lib, "ncclCommCount"));
+      a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(a.lib, "ncclCommUserRank"));
       if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce) a.lib = nullptr;
     }
     return a;
@@ -1554,6 +1558,15 @@ extern "C" int fb_rccl_get_unique_id(fb_rccl_unique_id *id) {
   if (!r) { fb::set_error("fb_rccl_get_unique_id: no RCCL in this process (librccl.so.1 not found)"); return FB_ERR_NODEVICE; }
   const int rc = r->GetUniqueId(id);
   if (rc != 0) { fb::set_error("ncclGetUniqueId failed (%d)", rc); return FB_ERR_HIP; }
+  return FB_OK;
+}
+extern "C" int fb_rccl_comm_info(void *comm, int *count, int *rank) {
+  FB_ARG(comm && count && rank);
+  RcclApi *r = rccl_api();
+  if (!r || !r->CommCount || !r->CommUserRank) { fb::set_error("fb_rccl_comm_info: ncclCommCount / ncclCommUserRank not available"); return FB_ERR_NODEVICE; }
+  int rc = r->CommCount(comm, count);
+  if (rc == 0) rc = r->CommUserRank(comm, rank);
+  if (rc != 0) { fb::set_error("fb_rccl_comm_info: RCCL error %d", rc); return FB_ERR_HIP; }
   return FB_OK;
 }
 extern "C" int fb_rccl_comm_init(const fb_rccl_unique_id *id, int rank, int world, void **comm) {

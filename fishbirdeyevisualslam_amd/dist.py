@@ -101,6 +101,13 @@ class RcclComm:
             uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
         check(lib.fb_rccl_comm_init(C.byref(uid), rank, world, C.byref(self.comm)), "fb_rccl_comm_init")
 
+    def info(self):
+        """(ranks in the communicator, this rank) as RCCL reports them (ncclCommCount / ncclCommUserRank)."""
+        from . import check
+        n, r = C.c_int(0), C.c_int(0)
+        check(self.lib.fb_rccl_comm_info(self.comm, C.byref(n), C.byref(r)), "fb_rccl_comm_info")
+        return n.value, r.value
+
     def close(self):
         if self.comm:
             self.lib.fb_rccl_comm_destroy(self.comm)

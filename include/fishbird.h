@@ -960,6 +960,9 @@ typedef struct fb_rccl_unique_id { char internal[128]; } fb_rccl_unique_id;
 int fb_rccl_get_unique_id(fb_rccl_unique_id *id);
 int fb_rccl_comm_init(const fb_rccl_unique_id *id, int rank, int world, void **comm);
 int fb_rccl_comm_destroy(void *comm);
+/* ncclCommCount / ncclCommUserRank of a communicator: what RCCL itself says about the ranks it connects (bench.py prints it
+ * as local_ba.rccl_ranks_seen, so that a multi-GPU run shows that the collective really spans the ranks). */
+int fb_rccl_comm_info(void *comm, int *count, int *rank);
 int fb_local_ba_sharded_rccl(const fb_local_ba_args *args, int rank, int world, void *comm);
 
 #ifdef __cplusplus

@@ -2,8 +2,10 @@
 
 CPU: the distributed helpers bench.py and the sharded BA rely on (max over ranks, sequence sharding, the
 all-reduce callback driven through its C function pointer).
-GPU: the landmark-sharded local BA (fb_local_ba_sharded), two ranks sharing the one GPU of the box, against
-the unsharded result."""
+GPU: the landmark-sharded local BA (fb_local_ba_sharded), two ranks sharing the one GPU of the box, against the ORACLE
+(8 key frames, and 20 key frames x 8000 + 2000 points = BASELINE configs[4]'s BA; stop flag raised on one rank only);
+the RCCL transport on a 1-rank communicator, and -- only on a box with >= 2 GPUs -- on a real 2-rank communicator
+(fresh child processes, one GPU each).  Multi-rank RCCL has never executed where these tests have run so far."""
 import os
 import socket
 import subprocess
@@ -62,6 +64,19 @@ def test_sharded_local_ba_world2_vs_oracle(mode):
 def test_sharded_local_ba_stop_flag_on_one_rank():
     outs = _run_world2("ba_stop", timeout=120)
     assert all("identical_across_ranks=True" in o for o in outs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["ba_rccl", "ba_rccl_stop"])
+def test_sharded_local_ba_rccl_two_ranks(mode):
+    """The multi-rank RCCL transport itself: two fresh processes, one GPU each, a 2-rank communicator made by fb_rccl_*,
+    ncclAllReduce between the kernels on the BA stream (out-of-place exchange 2, final pack / unpack, abort flag), against
+    the oracle.  Skipped on a one-GPU box: until a box with two GPUs has run it, multi-rank RCCL is UNVERIFIED."""
+    import fishbirdeyevisualslam_amd as fb
+    if fb.lib().fb_device_count() < 2:   # counting devices does not initialise the GPU in this process
+        pytest.skip("needs >= 2 GPUs (multi-rank RCCL stays unverified on this box)")
+    outs = _run_world2(mode)
+    assert all("rccl_ranks_seen=2" in o and "flags_equal=True" in o and "identical_across_ranks=True" in o for o in outs)
 
 
 @pytest.mark.gpu
