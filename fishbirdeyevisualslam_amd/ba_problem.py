@@ -23,3 +23,20 @@ def local_ba_args(p, with_odom=1, wF=1.0, wB=1.0, stop_flag=None):
     out = dict(kf_Tcw=keep["kf_Tcw"], mp_xw=keep["mp_xw"], mpb_xw=keep["mpb_xw"], obs_outlier=keep["obs_outlier"],
                bobs_outlier=keep["bobs_outlier"])
     return a, out, keep
+
+
+DEV_FIELDS = ("kf_Tcw", "mp_xw", "mpb_xw", "obs_kf", "obs_mp", "obs_uv", "obs_inv_sigma2", "bobs_kf", "bobs_mpb", "bobs_xc",
+              "bobs_inv_sigma2", "obs_outlier", "bobs_outlier")
+
+
+def local_ba_args_dev(p, device="cuda:0", **kw):
+    """fb_local_ba_args for fb_local_ba_dev: the big arrays as torch tensors on the device, kf_fixed / odometry / stop flag on the host.
+    Returns (args, device tensors, host keep)."""
+    import torch
+    a, out, keep = local_ba_args(p, **kw)
+    dev = {}
+    for k in DEV_FIELDS:
+        arr = np.ascontiguousarray(keep[k])
+        dev[k] = torch.from_numpy(arr.copy()).to(device) if arr.size else torch.zeros(1, dtype=torch.from_numpy(arr.reshape(-1)[:0].copy()).dtype, device=device)
+    fill(a, **dev)
+    return a, dev, keep

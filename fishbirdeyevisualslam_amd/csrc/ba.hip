@@ -1206,6 +1206,7 @@ struct BACtl {
   int needGate;  // this slot starts with the chi2 gate
   int abort;     // terminate(): set by the host when it sees *pbStopFlag
   int trials, slots;
+  int badArgs;   // device-side graph builder (fb_local_ba_dev): 1 = index out of range, 2 = duplicate (key frame, point)
 };
 struct BASched { int its1, robust1, gate, its2; };
 struct St2 { State s[2]; };
@@ -1592,10 +1593,135 @@ struct BASchedule {
   int its2;
   double delta;  // Huber delta: sqrt(5.991) local (:2290), sqrt(5.99) global (:1836)
 };
-static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, const BASchedule &sc);
+struct DevIn { hipStream_t stream = nullptr; };  // fb_local_ba_dev: the big arrays of fb_local_ba_args are DEVICE pointers
+static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, const BASchedule &sc, const DevIn *dv = nullptr);
+
+// ---- device-side graph builder (fb_local_ba_dev): what local_ba_impl's host passes do, as kernels ----------------------
+namespace {
+struct BuildIn {
+  const int32_t *obs_kf, *obs_mp; const float *obs_uv, *obs_inv;
+  const int32_t *bobs_kf, *bobs_mpb; const float *bobs_xc, *bobs_inv;
+  const float *kf_Tcw, *mp_xw, *mpb_xw;
+  int nF, nB, n_kf, n_mp, n_mpb, odom;
+  double wF, wB;
+};
+// per edge: the flat edge record (Optimizer.cc:2346-2367, 2399-2414) + the counts of the two CSR structures
+__global__ void k_bld_edges(BuildIn I, const int *poseIdx, int *e_pt, int *e_kf, int *e_pj, uint8_t *e_type, uint8_t *e_level,
+                            float *e_meas, double *e_info, int *lm_cnt, int *ps_cnt, int *bad) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= I.nF + I.nB) return;
+  int pt, kf;
+  if (e < I.nF) {
+    pt = I.obs_mp[e]; kf = I.obs_kf[e];
+    if (!(pt >= 0 && pt < I.n_mp && kf >= 0 && kf < I.n_kf)) { atomicOr(bad, 1); pt = 0; kf = 0; }
+    e_type[e] = T_PROJ;
+    e_meas[3 * e] = I.obs_uv[2 * e]; e_meas[3 * e + 1] = I.obs_uv[2 * e + 1]; e_meas[3 * e + 2] = 0.0f;
+    e_info[e] = I.odom ? (1.0 * (double)I.obs_inv[e]) * I.wF : (double)I.obs_inv[e];
+  } else {
+    const int i = e - I.nF;
+    int pb = I.bobs_mpb[i];
+    kf = I.bobs_kf[i];
+    if (!(pb >= 0 && pb < I.n_mpb && kf >= 0 && kf < I.n_kf)) { atomicOr(bad, 1); pb = 0; kf = 0; }
+    pt = I.n_mp + pb;
+    e_type[e] = T_XYZ;
+    for (int k = 0; k < 3; k++) e_meas[3 * e + k] = I.bobs_xc[3 * i + k];
+    e_info[e] = (1.0 * (double)I.bobs_inv[i]) * I.wB;
+  }
+  e_pt[e] = pt; e_kf[e] = kf; e_level[e] = 0;
+  const int pj = poseIdx[kf];
+  e_pj[e] = pj;
+  atomicAdd(&lm_cnt[pt + 1], 1);
+  if (pj >= 0) atomicAdd(&ps_cnt[pj + 1], 1);
+}
+__global__ void k_bld_state(BuildIn I, SE3 *poses, double *pts, float *kfT) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < I.n_kf) {
+    poses[i] = fb::se3_from_float12(I.kf_Tcw + 12 * i);
+    for (int k = 0; k < 12; k++) kfT[12 * i + k] = I.kf_Tcw[12 * i + k];
+  }
+  if (i < 3 * I.n_mp) pts[i] = I.mp_xw[i];
+  if (i < 3 * I.n_mpb) pts[3 * I.n_mp + i] = I.mpb_xw[i];
+}
+// in-place: cnt[0] = 0, cnt[i + 1] = count of bucket i  ->  exclusive starts; one workgroup, n up to millions
+__global__ __launch_bounds__(1024) void k_bld_scan(int *cnt, int n, int *fill) {
+  __shared__ int s_w[16], s_run;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) s_run = 0;
+  __syncthreads();
+  for (int base = 0; base <= n; base += 1024) {
+    const int i = base + tid;
+    const int v = i <= n ? cnt[i] : 0;
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    int off = s_run;
+    for (int w = 0; w < wv; w++) off += s_w[w];
+    const int incl = off + inc;
+    if (i <= n) { cnt[i] = incl; if (fill && i < n) fill[i] = incl; }  // start of bucket i = inclusive sum up to cnt[i] (cnt[0] = 0)
+    __syncthreads();
+    if (tid == 1023) s_run = incl;
+    __syncthreads();
+  }
+}
+__global__ void k_bld_scatter(int nE, const int *e_pt, const int *e_pj, int *fillL, int *fillP, int *lm_edges, int *ps_edges) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nE) return;
+  lm_edges[atomicAdd(&fillL[e_pt[e]], 1)] = e;
+  if (e_pj[e] >= 0) ps_edges[atomicAdd(&fillP[e_pj[e]], 1)] = e;
+}
+// a landmark's edges in ascending edge index (the order the host builder produces: sums must not depend on the atomics'
+// order) + a key frame observes a point at most once (map<KeyFrame*, size_t>)
+__global__ void k_bld_sort_lm(int npt, const int *lm_start, int *lm_edges, const int *e_kf, int *bad) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= npt) return;
+  const int a0 = lm_start[l], a1 = lm_start[l + 1];
+  for (int i = a0 + 1; i < a1; i++) {
+    const int v = lm_edges[i];
+    int j = i - 1;
+    while (j >= a0 && lm_edges[j] > v) { lm_edges[j + 1] = lm_edges[j]; j--; }
+    lm_edges[j + 1] = v;
+  }
+  for (int i = a0; i < a1; i++)
+    for (int j = i + 1; j < a1; j++)
+      if (e_kf[lm_edges[i]] == e_kf[lm_edges[j]]) atomicOr(bad, 2);
+}
+// a key frame's edges in ascending edge index: bitonic sort of its segment in LDS (one workgroup per free key frame)
+__global__ __launch_bounds__(1024) void k_bld_sort_ps(const int *ps_start, int *ps_edges, int cap, int *bad) {
+  extern __shared__ int s_v[];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const int a0 = ps_start[k], n = ps_start[k + 1] - a0;
+  int m = 1;
+  while (m < n) m <<= 1;
+  if (m > cap) { if (tid == 0) atomicOr(bad, 4); return; }  // one key frame with more observations than the LDS sort holds
+  for (int i = tid; i < m; i += 1024) s_v[i] = i < n ? ps_edges[a0 + i] : 0x7fffffff;
+  __syncthreads();
+  for (int kk = 2; kk <= m; kk <<= 1)
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < m; i += 1024) {
+        const int p = i ^ j;
+        if (p > i) {
+          const int a = s_v[i], b = s_v[p];
+          const bool up = (i & kk) == 0;
+          if ((a > b) == up) { s_v[i] = b; s_v[p] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < n; i += 1024) ps_edges[a0 + i] = s_v[i];
+}
+__global__ void k_bld_check(const int *bad, BACtl *c) {
+  if (*bad) { c->badArgs = *bad; c->phase = 2; }
+}
+}  // namespace
 static const BASchedule kLocalSchedule = {5, 1, true, 10, (double)(float)sqrt(5.991)};
 
 extern "C" int fb_local_ba(const fb_local_ba_args *A) { return local_ba_impl(A, 0, Xchg(), kLocalSchedule); }
+extern "C" int fb_local_ba_dev(const fb_local_ba_args *A, void *stream) {
+  DevIn dv;
+  dv.stream = fb::as_stream(stream);
+  return local_ba_impl(A, 0, Xchg(), kLocalSchedule, &dv);
+}
 
 extern "C" int fb_global_ba(const fb_local_ba_args *A, int n_iterations, int robust) {
   FB_ARG(n_iterations >= 0);
@@ -1644,7 +1770,7 @@ extern "C" int fb_shutdown(void) {
   return FB_OK;
 }
 
-static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, const BASchedule &sc) {
+static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, const BASchedule &sc, const DevIn *dv) {
   FB_TRY(fb::check_device());
   const int world = X.world;
   const bool timing = getenv("FB_BA_TIMING") != nullptr;  // host-side phase times on stderr (probe)
@@ -1653,6 +1779,9 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
     if (timing) fprintf(stderr, "[fb_local_ba] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tStart).count());
   };
   const bool sharded = X.active();
+  const bool devIn = dv != nullptr;   // observations / poses / points / result arrays live in HBM (fb_local_ba_dev)
+  hipStream_t s0 = devIn ? dv->stream : nullptr;
+  FB_ARG(!(devIn && sharded));
   auto reduce = [&](double *buf, int n, int op) -> int { return sharded ? X.reduce_host(buf, n, op) : FB_OK; };
   // (sharded: a rank must not return alone on ITS argument error -- the others would wait for it in the first exchange;
   // the agreement block below reports it on every rank together)
@@ -1715,12 +1844,15 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   size_t stageBytes = 0;
   auto reserve = [&](size_t bytes) { const size_t off = stageBytes; stageBytes += (bytes + 255) & ~(size_t)255; return off; };
   const int nE1 = std::max(nE, 1), nO1 = std::max(nO, 1);
-  const size_t o_poseIdx = reserve((size_t)n_kf * 4), o_ept = reserve((size_t)nE1 * 4), o_ekf = reserve((size_t)nE1 * 4),
+  // small, host-built arrays first: the device-input variant uploads only this header
+  const size_t o_poseIdx = reserve((size_t)n_kf * 4), o_fixed = reserve(n_kf), o_oi = reserve((size_t)nO1 * 4), o_oj = reserve((size_t)nO1 * 4),
+               o_oz = reserve((size_t)nO1 * sizeof(SE3)), o_oinfo = reserve((size_t)nO1 * 8), o_ods = reserve((size_t)(np + 1) * 4),
+               o_ode = reserve((size_t)(2 * nO1) * 4);
+  const size_t headerBytes = stageBytes;
+  const size_t o_lms = reserve((size_t)(npt + 1) * 4), o_pss = reserve((size_t)(np + 1) * 4);   // (zeroed together by the device builder)
+  const size_t o_ept = reserve((size_t)nE1 * 4), o_ekf = reserve((size_t)nE1 * 4),
                o_epj = reserve((size_t)nE1 * 4), o_etype = reserve(nE1), o_elevel = reserve(nE1), o_emeas = reserve((size_t)nE1 * 12),
-               o_einfo = reserve((size_t)nE1 * 8), o_lms = reserve((size_t)(npt + 1) * 4), o_lme = reserve((size_t)nE1 * 4),
-               o_pss = reserve((size_t)(np + 1) * 4), o_pse = reserve((size_t)nE1 * 4), o_oi = reserve((size_t)nO1 * 4),
-               o_oj = reserve((size_t)nO1 * 4), o_oz = reserve((size_t)nO1 * sizeof(SE3)), o_oinfo = reserve((size_t)nO1 * 8),
-               o_ods = reserve((size_t)(np + 1) * 4), o_ode = reserve((size_t)(2 * nO1) * 4), o_fixed = reserve(n_kf),
+               o_einfo = reserve((size_t)nE1 * 8), o_lme = reserve((size_t)nE1 * 4), o_pse = reserve((size_t)nE1 * 4),
                o_poses = reserve((size_t)n_kf * sizeof(SE3)), o_pts = reserve((size_t)std::max(npt, 1) * 24),
                o_kfT = reserve((size_t)n_kf * 48);
   if (stage.size() < stageBytes) stage.resize(stageBytes);
@@ -1736,6 +1868,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   double *pts = reinterpret_cast<double *>(hs + o_pts);
   memcpy(h_poseIdx, poseIdx.data(), (size_t)n_kf * 4);
   memcpy(hs + o_fixed, A->kf_fixed, n_kf);
+  if (!devIn) {
   memcpy(hs + o_kfT, A->kf_Tcw, (size_t)n_kf * 48);
   // one pass over the observations fills the per-edge arrays and counts the two CSR structures, a second one scatters
   for (int l = 0; l <= npt; l++) lm_start[l] = 0;
@@ -1810,6 +1943,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   for (int k = 0; k < n_kf; k++) poses[k] = fb::se3_from_float12(A->kf_Tcw + 12 * k);
   for (int i = 0; i < 3 * n_mp; i++) pts[i] = A->mp_xw[i];
   for (int i = 0; i < 3 * A->n_mpb; i++) pts[3 * n_mp + i] = A->mpb_xw[i];
+  }  // !devIn
   for (int i = 0; i < nO; i++) {
     FB_ARG(A->odom_kf_i[i] >= 0 && A->odom_kf_i[i] < n_kf && A->odom_kf_j[i] >= 0 && A->odom_kf_j[i] < n_kf);
     o_i[i] = A->odom_kf_i[i]; o_j[i] = A->odom_kf_j[i]; o_info[i] = A->odom_info[i];
@@ -1835,8 +1969,50 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   const int lmPerWg = ((npt + nWg - 1) / nWg + CHUNK - 1) / CHUNK * CHUNK;
   nWg = std::max(1, (npt + lmPerWg - 1) / std::max(lmPerWg, 1));
   lap("host preprocessing done");
-  fb::DevBuf d_stage, d_scratch;
-  FB_TRY(d_stage.upload(hs, stageBytes));
+  fb::DevBuf d_stage, d_scratch, d_bld;
+  if (!devIn) {
+    FB_TRY(d_stage.upload(hs, stageBytes));
+  } else {
+    // only the header travels; the edge records, both CSR structures and the double-precision state are built by kernels
+    // from the caller's device arrays (same contents as the host passes above, incl. the ascending edge order inside a
+    // landmark / a key frame that the sums depend on)
+    FB_TRY(d_stage.alloc(stageBytes));
+    uint8_t *dsb = d_stage.as<uint8_t>();
+    FB_HIP(hipMemcpyAsync(dsb, hs, headerBytes, hipMemcpyHostToDevice, s0));
+    FB_ARG(A->kf_Tcw && (n_mp == 0 || A->mp_xw) && (A->n_mpb == 0 || A->mpb_xw));
+    FB_ARG(nF == 0 || (A->obs_kf && A->obs_mp && A->obs_uv && A->obs_inv_sigma2 && A->obs_outlier));
+    FB_ARG(nB == 0 || (A->bobs_kf && A->bobs_mpb && A->bobs_xc && A->bobs_inv_sigma2 && A->bobs_outlier));
+    FB_TRY(d_bld.alloc(((size_t)npt + np + 2) * 4 + 16));
+    int *fillL = d_bld.as<int>(), *fillP = fillL + npt + 1, *badDev = fillP + np + 1;
+    FB_HIP(hipMemsetAsync(dsb + o_lms, 0, (o_ept - o_lms), s0));   // lm_start | ps_start (counts accumulate into them)
+    FB_HIP(hipMemsetAsync(d_bld.p, 0, d_bld.bytes, s0));
+    BuildIn I;
+    I.obs_kf = A->obs_kf; I.obs_mp = A->obs_mp; I.obs_uv = A->obs_uv; I.obs_inv = A->obs_inv_sigma2;
+    I.bobs_kf = A->bobs_kf; I.bobs_mpb = A->bobs_mpb; I.bobs_xc = A->bobs_xc; I.bobs_inv = A->bobs_inv_sigma2;
+    I.kf_Tcw = A->kf_Tcw; I.mp_xw = A->mp_xw; I.mpb_xw = A->mpb_xw;
+    I.nF = nF; I.nB = nB; I.n_kf = n_kf; I.n_mp = n_mp; I.n_mpb = A->n_mpb; I.odom = odom ? 1 : 0; I.wF = (double)A->wF; I.wB = (double)A->wB;
+    int *dlms = reinterpret_cast<int *>(dsb + o_lms), *dpss = reinterpret_cast<int *>(dsb + o_pss);
+    int *dept = reinterpret_cast<int *>(dsb + o_ept), *dekf = reinterpret_cast<int *>(dsb + o_ekf), *depj = reinterpret_cast<int *>(dsb + o_epj);
+    int *dlme = reinterpret_cast<int *>(dsb + o_lme), *dpse = reinterpret_cast<int *>(dsb + o_pse);
+    int segCap = 1;
+    while (segCap < std::max(nE, 1) && segCap < 32768) segCap <<= 1;  // observations of ONE key frame: at most 32768 (128 KB of LDS)
+    { fb::ProfScope pr(fb::P_BA_MISC, s0);
+      if (nE > 0) k_bld_edges<<<(nE + 255) / 256, 256, 0, s0>>>(I, reinterpret_cast<const int *>(dsb + o_poseIdx), dept, dekf, depj, dsb + o_etype, dsb + o_elevel,
+                                                              reinterpret_cast<float *>(dsb + o_emeas), reinterpret_cast<double *>(dsb + o_einfo), dlms, dpss, badDev);
+      k_bld_state<<<(std::max(n_kf, 3 * std::max(n_mp, A->n_mpb)) + 255) / 256, 256, 0, s0>>>(I, reinterpret_cast<SE3 *>(dsb + o_poses), reinterpret_cast<double *>(dsb + o_pts),
+                                                                                              reinterpret_cast<float *>(dsb + o_kfT));
+      k_bld_scan<<<1, 1024, 0, s0>>>(dlms, npt, fillL);
+      k_bld_scan<<<1, 1024, 0, s0>>>(dpss, np, fillP);
+      if (nE > 0) {
+        k_bld_scatter<<<(nE + 255) / 256, 256, 0, s0>>>(nE, dept, depj, fillL, fillP, dlme, dpse);
+        k_bld_sort_lm<<<(npt + 255) / 256, 256, 0, s0>>>(npt, dlms, dlme, dekf, badDev);
+        if (np > 0) {
+          FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bld_sort_ps), hipFuncAttributeMaxDynamicSharedMemorySize, segCap * 4));
+          k_bld_sort_ps<<<np, 1024, (size_t)segCap * 4, s0>>>(dpss, dpse, segCap, badDev);
+        }
+      }
+      FB_HIP(hipGetLastError()); }
+  }
   lap("graph uploaded");
   uint8_t *ds = d_stage.as<uint8_t>();
   size_t scratchBytes = 0;
@@ -1850,10 +2026,10 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   }
   FB_TRY(d_scratch.alloc(scratchBytes));
   uint8_t *dc = d_scratch.as<uint8_t>();
-  FB_HIP(hipMemsetAsync(dc + c_echi2, 0, (size_t)nE1 * 8, nullptr));
+  FB_HIP(hipMemsetAsync(dc + c_echi2, 0, (size_t)nE1 * 8, s0));
   // state 0 = the staged copy, state 1 starts as the same poses / points
-  FB_HIP(hipMemcpyAsync(dc + c_pose1, ds + o_poses, (size_t)n_kf * sizeof(SE3), hipMemcpyDeviceToDevice, nullptr));
-  FB_HIP(hipMemcpyAsync(dc + c_pt1, ds + o_pts, (size_t)std::max(npt, 1) * 24, hipMemcpyDeviceToDevice, nullptr));
+  FB_HIP(hipMemcpyAsync(dc + c_pose1, ds + o_poses, (size_t)n_kf * sizeof(SE3), hipMemcpyDeviceToDevice, s0));
+  FB_HIP(hipMemcpyAsync(dc + c_pt1, ds + o_pts, (size_t)std::max(npt, 1) * 24, hipMemcpyDeviceToDevice, s0));
   const uint8_t *d_fixed = ds + o_fixed;   // kf_fixed
   const uint8_t *d_kfT0 = ds + o_kfT;      // the caller's float poses (fixed key frames are returned untouched)
   BADev D;
@@ -1925,7 +2101,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   }
   FB_TRY(d_xp.alloc((size_t)std::max(P6, 1) * 8)); FB_TRY(d_ok.alloc(4)); FB_TRY(d_scale.alloc((size_t)nUpdBlocks * 8));
   FB_TRY(d_scal.alloc(4 * 8));
-  FB_HIP(hipMemset(d_scal.p, 0, 4 * 8));
+  FB_HIP(hipMemsetAsync(d_scal.p, 0, 4 * 8, s0));
   // accumulator tiles per wave: NT<=8 -> 9, NT<=12 -> 20, NT<=16 -> 34
   auto schurKernel = NT <= 8 ? k_ba_schur<9> : (NT <= 12 ? k_ba_schur<20> : k_ba_schur<34>);
   if (!big) {
@@ -1944,12 +2120,12 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   } else {
     FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_odom<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)odomLds));
   }
-  hipStream_t s0 = nullptr;
 
   // ---- device-resident Levenberg-Marquardt (LDS-resident reduced system): no read-back inside the schedule.  Sharded:
   //      two all-reduces per slot on this stream (the Schur-reduced system; the exchange block of the linearisation), every
   //      rank enqueues the same slots and takes the same decisions from the reduced values.
-  if (!big && !getenv("FB_BA_TRACE") && !getenv("FB_BA_HOST_LM")) {
+  if (devIn && big) { fb::set_error("fb_local_ba_dev: more than 23 free key frames (use fb_local_ba)"); return FB_ERR_CAPACITY; }
+  if (!big && (devIn || (!getenv("FB_BA_TRACE") && !getenv("FB_BA_HOST_LM")))) {
     // per host thread and device (concurrent callers must not share the pinned mirror; a stream belongs to its device):
     // side stream for the abort request (does not synchronise with the null stream), pinned mirror of the control block,
     // the event the host polls
@@ -1974,6 +2150,10 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
     const int abort0 = (A->stop_flag && *A->stop_flag) ? 1 : 0;  // sharded: raised before the call on this rank only
     FB_TRY(d_abort.upload(&abort0, sizeof(int)));
     BACtl *ctl = d_ctl.as<BACtl>();
+    if (devIn) {  // a rejected graph (index out of range, duplicate observation) ends the schedule before it starts
+      k_bld_check<<<1, 1, 0, s0>>>(d_bld.as<int>() + npt + 1 + np + 1, ctl);
+      FB_HIP(hipGetLastError());
+    }
     const BASched sched = {sc.its1, sc.robust1, sc.gate ? 1 : 0, sc.its2};
     St2 st2; st2.s[0] = st[0]; st2.s[1] = st[1];
     Lb2 lb2; lb2.b[0] = lb[0]; lb2.b[1] = lb[1];
@@ -2080,6 +2260,23 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
     lap("schedule finished");
     if (rcLoop != FB_OK) return rcLoop;
     if (hCtl->phase != 2) { fb::set_error("fb_local_ba: the LM schedule did not finish"); return FB_ERR_HIP; }
+    if (devIn) {
+      if (hCtl->badArgs & 4) { fb::set_error("fb_local_ba_dev: a key frame with more than 32768 observations (use fb_local_ba)"); return FB_ERR_CAPACITY; }
+      if (hCtl->badArgs) {
+        fb::set_error(hCtl->badArgs & 1 ? "fb_local_ba_dev: observation index out of range" : "fb_local_ba_dev: duplicate (keyframe, point) observation");
+        return FB_ERR_ARG;
+      }
+      if (sc.gate) {
+        if (nF > 0) FB_HIP(hipMemcpyAsync(A->obs_outlier, d_flags.p, (size_t)nF, hipMemcpyDeviceToDevice, s0));
+        if (nB > 0) FB_HIP(hipMemcpyAsync(A->bobs_outlier, d_flags.as<uint8_t>() + nF, (size_t)nB, hipMemcpyDeviceToDevice, s0));
+      }
+      FB_HIP(hipMemcpyAsync(A->kf_Tcw, d_kfT.p, (size_t)n_kf * 48, hipMemcpyDeviceToDevice, s0));
+      if (n_mp > 0) FB_HIP(hipMemcpyAsync(A->mp_xw, d_ptOut.p, (size_t)n_mp * 12, hipMemcpyDeviceToDevice, s0));
+      if (A->n_mpb > 0) FB_HIP(hipMemcpyAsync(A->mpb_xw, d_ptOut.as<float>() + (size_t)3 * n_mp, (size_t)A->n_mpb * 12, hipMemcpyDeviceToDevice, s0));
+      FB_HIP(hipStreamSynchronize(s0));  // the scratch goes back to the pool when this function returns
+      lap("results copied (device)");
+      return FB_OK;
+    }
     std::vector<uint8_t> flags(std::max(nE, 1));
     FB_TRY(d_flags.download(flags.data(), std::max(nE, 1)));
     std::vector<float> po((size_t)std::max(npt, 1) * 3);

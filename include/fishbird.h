@@ -931,6 +931,15 @@ typedef struct fb_local_ba_args {
   uint8_t *bobs_outlier;      /* out [n_bobs]                                   */
 } fb_local_ba_args;
 int fb_local_ba(const fb_local_ba_args *args); /* host pointers */
+/* The same with the graph resident in HBM (the LocalMapping-side chain hands its results over on the device: triangulation
+ * matches -> new points -> fuse -> local BA, LocalMapping.cc:62-99): kf_Tcw, mp_xw, mpb_xw, every obs_* / bobs_* array and the
+ * two outlier arrays are DEVICE pointers; kf_fixed, the odometry edges (odom_*: at most 3 n_kf of them) and stop_flag stay
+ * HOST pointers (the host chooses the window, Optimizer.cc:2139-2227, 2419-2495).  The edge records, the CSR by landmark / by
+ * key frame and the duplicate check are built by kernels on `stream`, ordered behind the producers of the arrays; results are
+ * written back on `stream`.  The call returns when the optimisation has finished (the schedule's length is data dependent:
+ * the host watches the device-resident Levenberg-Marquardt loop), like the reference's blocking call.
+ * Capacity: <= 23 free key frames, <= 32768 observations per key frame (larger graphs: fb_local_ba).                       */
+int fb_local_ba_dev(const fb_local_ba_args *args, void *stream);
 
 /* Optimizer::BundleAdjustmentWithOdom / GlobalBundleAdjustemntWithOdom (Optimizer.cc:1778-2135) on the same graph
  * description: with_odom = 1 (Quat edges), n_odom = 0 (the pose-graph block is commented out in the reference,
