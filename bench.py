@@ -140,7 +140,9 @@ def cpu_baseline(world, nsample, rank, refs_out):
     # host has per MI355X), and N = 16 = the CPU share the one-GPU bench box grants a run (labelled as such)
     import glob
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    gpus_on_box = max(1, len(glob.glob("/sys/class/drm/renderD*")))
+    # (render nodes: one per GPU, or one per partition when the GPUs are partitioned -- the bench box lists 64 for its 8 MI355X)
+    nodes = len(glob.glob("/sys/class/drm/renderD*"))
+    gpus_on_box = nodes if 1 <= nodes <= 8 else 8
     per = max(10, min(nsample, 16))
 
     def many_cores(ncore, label):
@@ -391,6 +393,16 @@ def track_chain_leg(rank, local_rank, batches=(1, 8, 256), steps=(200, 100, 20),
             res[name] = {"ms_per_step": dt / nsteps * 1e3, "ms_per_frame_pair": dt / nsteps / B * 1e3, "frames_per_s": B * nsteps / dt, "steps": nsteps}
         tc.track_prefetched(dl[(path[pos], path[pos + 1])], sync=True)   # drain the frame already constructed
         pos += 1
+        if B == batches[-1]:   # per-kernel table of the chain (every kernel bracketed by HIP events, serial driver, no overlap)
+            L_ = tc.L
+            ents_ = (cabi.ProfEntry * 48)()
+            torch.cuda.synchronize()
+            L_.fb_prof_only(None); L_.fb_prof_reset(); L_.fb_prof_enable(1)
+            run(3, False, False)
+            L_.fb_prof_enable(0)
+            n_ = L_.fb_prof_report(ents_, 48)
+            res["kernels_ms_per_step_bracketed"] = {ents_[i].name.decode(): ents_[i].total_ms / 3 for i in sorted(range(n_), key=lambda i: -ents_[i].total_ms)}
+            res["kernels_ms_sum_bracketed"] = sum(ents_[i].total_ms for i in range(n_)) / 3
         c, T = tc.counts()
         res["counters_mean_last_frame"] = {k: float(c[i].mean()) for k, i in cabi.FB_CNT.items()}
         tp = np.stack([np.asarray(seq.Tcw_true(path[pos], b))[:3, :4].reshape(12) for b in range(B)])
@@ -669,11 +681,14 @@ def main():
         achieved = alg_per_launch / (per_launch_model_ms * 1e-3) / 1e9 if per_launch_model_ms > 0 else 0.0
         traffic, traffic_src = None, None
         try:  # PMC counters cannot be read inside this process: per-launch means of separate rocprofv3 --pmc passes
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+            tj = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+            if not os.path.exists(tj):
+                tj = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            with open(tj) as f:
                 pt = json.load(f)
             if pt.get("batch") == B and dom in pt["kernels"]:
                 traffic = pt["kernels"][dom]["hbm_bytes_per_launch"]
-                traffic_src = "profiles/r03_pmc_traffic.json: " + pt.get("method", "")
+                traffic_src = "profiles/" + os.path.basename(tj) + ": " + pt.get("method", "")
         except (OSError, ValueError, KeyError):
             pass
         ms_step = elapsed / a.steps * 1e3

@@ -1847,8 +1847,8 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   // small, host-built arrays first: the device-input variant uploads only this header
   const size_t o_poseIdx = reserve((size_t)n_kf * 4), o_fixed = reserve(n_kf), o_oi = reserve((size_t)nO1 * 4), o_oj = reserve((size_t)nO1 * 4),
                o_oz = reserve((size_t)nO1 * sizeof(SE3)), o_oinfo = reserve((size_t)nO1 * 8), o_ods = reserve((size_t)(np + 1) * 4),
-               o_ode = reserve((size_t)(2 * nO1) * 4);
-  const size_t headerBytes = stageBytes;
+               o_ode = reserve((size_t)(2 * nO1) * 4), o_ctl = reserve(sizeof(BACtl)), o_abort = reserve(16);
+  const size_t headerBytes = stageBytes;   // (the control block and the abort word ride in the header: no separate synchronous copies)
   const size_t o_lms = reserve((size_t)(npt + 1) * 4), o_pss = reserve((size_t)(np + 1) * 4);   // (zeroed together by the device builder)
   const size_t o_ept = reserve((size_t)nE1 * 4), o_ekf = reserve((size_t)nE1 * 4),
                o_epj = reserve((size_t)nE1 * 4), o_etype = reserve(nE1), o_elevel = reserve(nE1), o_emeas = reserve((size_t)nE1 * 12),
@@ -1868,6 +1868,18 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   double *pts = reinterpret_cast<double *>(hs + o_pts);
   memcpy(h_poseIdx, poseIdx.data(), (size_t)n_kf * 4);
   memcpy(hs + o_fixed, A->kf_fixed, n_kf);
+  {  // initial Levenberg-Marquardt control block + abort word of the device-resident schedule
+    BACtl init;
+    memset(&init, 0, sizeof(init));
+    // (sharded: nE / nO are this rank's view; every rank holds all edges, so `anything` agrees across the ranks)
+    const bool anything = nE + (odom ? A->n_odom : 0) > 0 && (np > 0 || npt > 0);
+    init.phase = anything ? 0 : 2;
+    init.needInit = 1;
+    memcpy(hs + o_ctl, &init, sizeof(init));
+    const int abort0 = (A->stop_flag && *A->stop_flag) ? 1 : 0;  // sharded: raised before the call on this rank only
+    memset(hs + o_abort, 0, 16);
+    memcpy(hs + o_abort, &abort0, sizeof(int));
+  }
   if (!devIn) {
   memcpy(hs + o_kfT, A->kf_Tcw, (size_t)n_kf * 48);
   // one pass over the observations fills the per-edge arrays and counts the two CSR structures, a second one scatters
@@ -2139,17 +2151,10 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
     hipStream_t sAux = pd.sAux;
     BACtl *hCtl = pd.hCtl;
     hipEvent_t evDone = pd.evDone;
-    fb::DevBuf d_ctl, d_flags, d_kfT, d_ptOut, d_xb, d_abort, d_ex;
-    BACtl init;
-    memset(&init, 0, sizeof(init));
-    // (sharded: nE / nO are this rank's view; every rank holds all edges, so `anything` agrees across the ranks)
+    fb::DevBuf d_flags, d_kfT, d_ptOut, d_xb, d_ex;
     const bool anything = nE + (odom ? A->n_odom : 0) > 0 && (np > 0 || npt > 0);
-    init.phase = anything ? 0 : 2;
-    init.needInit = 1;
-    FB_TRY(d_ctl.upload(&init, sizeof(init)));
-    const int abort0 = (A->stop_flag && *A->stop_flag) ? 1 : 0;  // sharded: raised before the call on this rank only
-    FB_TRY(d_abort.upload(&abort0, sizeof(int)));
-    BACtl *ctl = d_ctl.as<BACtl>();
+    int *const d_abortp = reinterpret_cast<int *>(ds + o_abort);
+    BACtl *ctl = reinterpret_cast<BACtl *>(ds + o_ctl);
     if (devIn) {  // a rejected graph (index out of range, duplicate observation) ends the schedule before it starts
       k_bld_check<<<1, 1, 0, s0>>>(d_bld.as<int>() + npt + 1 + np + 1, ctl);
       FB_HIP(hipGetLastError());
@@ -2200,12 +2205,12 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
         else k_ba_lin_c<false><<<linGrid, 256, linLds, s0>>>(D, st2, lb2, ctl, sched, P6, nLin256, nLin256, nullptr, xb); }
       { fb::ProfScope pr(fb::P_BA_MISC, s0);
         if (sharded) {
-          k_ba_prex<<<1, 256, 0, s0>>>(D, lb2, ctl, nLin256, nLin256, d_scale.as<double>(), nUpdBlocks, xb, d_abort.as<int>(), rank, world);
+          k_ba_prex<<<1, 256, 0, s0>>>(D, lb2, ctl, nLin256, nLin256, d_scale.as<double>(), nUpdBlocks, xb, d_abortp, rank, world);
           // exchange 2: both raw blocks -> the reduced blocks, one all-reduce
           if (rcSlot == FB_OK) rcSlot = X.sum_dev(xr.at(0), (size_t)2 * xb.stride, s0, hostScratch, xb.at(0));
-          k_ba_control<true><<<1, 256, 0, s0>>>(D, lb2, ctl, sched, nLin256, nLin256, d_scale.as<double>(), nUpdBlocks, d_scal.as<double>() + 3, P6, xr, d_abort.as<int>(), world);
+          k_ba_control<true><<<1, 256, 0, s0>>>(D, lb2, ctl, sched, nLin256, nLin256, d_scale.as<double>(), nUpdBlocks, d_scal.as<double>() + 3, P6, xr, d_abortp, world);
         } else {
-          k_ba_control<false><<<1, 256, 0, s0>>>(D, lb2, ctl, sched, nLin256, nLin256, d_scale.as<double>(), nUpdBlocks, d_scal.as<double>() + 3, P6, xb, d_abort.as<int>(), world);
+          k_ba_control<false><<<1, 256, 0, s0>>>(D, lb2, ctl, sched, nLin256, nLin256, d_scale.as<double>(), nUpdBlocks, d_scal.as<double>() + 3, P6, xb, d_abortp, world);
         } }
     };
     FB_TRY(d_flags.alloc(std::max(nE, 1)));
@@ -2246,7 +2251,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
           if (q == hipSuccess) break;
           if (q != hipErrorNotReady) { fb::set_error("fb_local_ba: %s", hipGetErrorString(q)); rcLoop = FB_ERR_HIP; break; }
           if (!abortSent && *A->stop_flag) {
-            (void)hipMemcpyAsync(d_abort.p, &one, sizeof(int), hipMemcpyHostToDevice, sAux);
+            (void)hipMemcpyAsync(d_abortp, &one, sizeof(int), hipMemcpyHostToDevice, sAux);
             abortSent = true;
           }
           // a BA lasts milliseconds and the flag only has to reach the device before the running slot (~0.1 ms) ends:

@@ -54,7 +54,7 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 enum ProfId {
   P_RESIZE, P_FAST, P_OCTREE, P_DESCRIBE, P_GRID, P_BIRDCAM, P_HAMMING, P_PROJ_FRAME, P_PROJ_POINTS, P_BIRD_MP,
   P_BIRDVIEW, P_BOW, P_TRIANG, P_POSE, P_GATHER, P_BA_LINEARIZE, P_BA_SCHUR, P_BA_SOLVE, P_BA_UPDATE, P_BA_MISC,
-  P_PROJ_KF, P_BOW_KF, P_FRUSTUM, P_UNDISTORT, P_BLUR, P_FUSE, P_DISTINCT, P_BOWT, P_FAST56, P_FAST72, P_COUNT
+  P_PROJ_KF, P_BOW_KF, P_FRUSTUM, P_UNDISTORT, P_BLUR, P_FUSE, P_DISTINCT, P_BOWT, P_FAST56, P_FAST72, P_TRACK_GLUE, P_COUNT
 };
 extern bool g_prof_on;
 extern int g_prof_only;  // -1 = every kernel, else only this ProfId is bracketed

@@ -93,7 +93,7 @@ const char *kProfNames[P_COUNT] = {"k_resize", "k_fast<44>", "k_octree", "k_desc
                                    "k_descriptor_distance", "k_proj_frame", "k_proj_points", "k_bird_mappoints",
                                    "k_birdview", "k_match_bow", "k_match_triangulation", "k_pose_opt", "k_pose_gather", "k_ba_linearize", "k_ba_schur",
                                    "k_ba_solve", "k_ba_update", "k_ba_misc", "k_proj_kf", "k_match_bow_kf", "k_in_frustum",
-                                   "k_undistort", "k_blur", "k_kf_search", "k_distinctive", "k_bow_transform", "k_fast<56>", "k_fast<72>"};
+                                   "k_undistort", "k_blur", "k_kf_search", "k_distinctive", "k_bow_transform", "k_fast<56>", "k_fast<72>", "k_track_glue"};
 struct ProfRec { int id; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_recs;

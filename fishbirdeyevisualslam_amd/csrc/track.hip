@@ -600,7 +600,8 @@ int fb_frame_extract_dev(fb_frame *f, fb_orb *of, fb_orb *ob, const uint8_t *d_f
                                   f->kps.as<fb_keypoint>(), f->desc.as<uint8_t>(), f->n.as<int32_t>(), s));
   FB_TRY(fb_undistort_keypoints_dev(f->kps.as<fb_keypoint>(), f->n.as<int32_t>(), B, cap, f->P.K, f->P.D, f->kps_un.as<fb_keypoint>(), s));
   FB_TRY(fb_grid_build_batch_dev(f->kps_un.as<fb_keypoint>(), f->n.as<int32_t>(), B, cap, &f->gF, f->cs.as<int32_t>(), f->ci.as<int32_t>(), s));
-  k_frame_reset<<<slot_grid(f), TT, 0, s>>>(f->dev(), f->counts.as<int32_t>(), B);
+  { fb::ProfScope prof_(fb::P_TRACK_GLUE, s);
+    k_frame_reset<<<slot_grid(f), TT, 0, s>>>(f->dev(), f->counts.as<int32_t>(), B); }
   FB_HIP(hipGetLastError());
   FB_HIP(hipStreamWaitEvent(s, f->evJoin, 0));
   return FB_OK;
@@ -646,6 +647,7 @@ int fb_frame_set_pose_dev(fb_frame *f, const float *d_Tcw, void *stream) {
 int fb_frame_predict_pose_dev(fb_frame *cur, const fb_frame *last, const float *d_delta, void *stream) {
   FB_TRY(fb::check_device());
   FB_ARG(cur && last && d_delta && cur != last && cur->B == last->B);
+  fb::ProfScope prof_(fb::P_TRACK_GLUE, fb::as_stream(stream));
   k_predict_pose<<<(cur->B + 63) / 64, 64, 0, fb::as_stream(stream)>>>(d_delta, last->Tcw.as<float>(), cur->Tcw.as<float>(), cur->B);
   FB_HIP(hipGetLastError());
   return FB_OK;
@@ -674,6 +676,7 @@ namespace {
 // A matcher leaves its result in the frame's match buffer; `defer` = the pose optimisation that follows folds it into
 // mvpMapPoints / mvpMapPointsBird inside its edge kernel (fb_frame_track_dev), otherwise a commit launch does it here.
 int launch_commit(fb_frame *f, const Commit &C, hipStream_t s) {
+  fb::ProfScope prof_(fb::P_TRACK_GLUE, s);
   k_commit<<<slot_grid(f), TT, 0, s>>>(f->dev(), C);
   FB_HIP(hipGetLastError());
   return FB_OK;
@@ -691,6 +694,7 @@ int m9_impl(fb_frame *cur, const fb_map_points_bird *mpb, const int32_t *d_local
   const int B = cur->B, cap = cur->cap, lcap = cur->P.local_mpb_cap;
   fb_bird_mp_args A;
   memset(&A, 0, sizeof(A));
+  { fb::ProfScope prof_(fb::P_TRACK_GLUE, s);
   if (d_local) {
     k_m9_prepare<<<dim3((std::max(lcap, cap) + TT - 1) / TT, B), TT, 0, s>>>(bird_dev(mpb), d_local, d_n_local, lcap, cur->m9_valid.as<uint8_t>(),
                                                                           cur->m9_xw.as<float>(), cur->m9_desc.as<uint8_t>(),
@@ -699,6 +703,7 @@ int m9_impl(fb_frame *cur, const fb_map_points_bird *mpb, const int32_t *d_local
   } else {
     k_m9_prepare_all<<<slot_grid(cur), TT, 0, s>>>(bird_dev(mpb), cur->m9_n.as<int32_t>(), cur->m_bird.as<int32_t>(), cap);
     A.ref_stride = mpb->stride; A.ref_valid = cur->ones.as<uint8_t>(); A.ref_xw = mpb->xw; A.ref_desc = mpb->desc;
+  }
   }
   FB_HIP(hipGetLastError());
   A.batch = B; A.cur_stride = cap;
@@ -716,7 +721,8 @@ int m9_impl(fb_frame *cur, const fb_map_points_bird *mpb, const int32_t *d_local
 int m3_impl(fb_frame *cur, const fb_frame *last, const fb_map_points *map, float th, const fb_matcher_params *matcher, hipStream_t s) {
   M3Scratch S{cur->m3_valid.as<uint8_t>(), cur->m3_obs.as<uint8_t>(), cur->m3_xw.as<float>(), cur->m3_desc.as<uint8_t>(),
               cur->m3_oct.as<int32_t>(), cur->m3_ang.as<float>()};
-  k_m3_prepare<<<slot_grid(cur), TT, 0, s>>>(cur->dev(), last->dev(), map_dev(map), S);
+  { fb::ProfScope prof_(fb::P_TRACK_GLUE, s);
+    k_m3_prepare<<<slot_grid(cur), TT, 0, s>>>(cur->dev(), last->dev(), map_dev(map), S); }
   FB_HIP(hipGetLastError());
   fb_proj_frame_args A;
   memset(&A, 0, sizeof(A));
@@ -796,6 +802,7 @@ int fb_frame_pose_optimization_dev(fb_frame *f, const fb_map_points *map, const 
 int fb_frame_discard_outliers_dev(fb_frame *f, const fb_map_points *map, void *stream) {
   FB_TRY(fb::check_device());
   FB_ARG(f && map_ok(f, map));
+  fb::ProfScope prof_(fb::P_TRACK_GLUE, fb::as_stream(stream));
   k_discard<<<f->B, WG, 0, fb::as_stream(stream)>>>(f->dev(), map_dev(map), f->counts.as<int32_t>(), f->B);
   FB_HIP(hipGetLastError());
   return FB_OK;
@@ -819,7 +826,7 @@ int fb_frame_match_bird_points_dev(fb_frame *cur, fb_frame *ref, fb_map_points_b
   const size_t lds = (size_t)cur->cap * 4;
   if (lds > 150 * 1024) { fb::set_error("fb_frame_match_bird_points: %d key points per frame beyond the LDS slot table", cur->cap); return FB_ERR_CAPACITY; }
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bird_commit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  fb::ProfScope prof_(fb::P_FRUSTUM, s);
+  fb::ProfScope prof_(fb::P_TRACK_GLUE, s);
   k_bird_commit<<<cur->B, WG, lds, s>>>(cur->dev(), ref->dev(), bird_dev(mpb), cur->m8_m12.as<int32_t>(), filter_size,
                                        cur->counts.as<int32_t>(), cur->B);
   FB_HIP(hipGetLastError());
@@ -842,6 +849,7 @@ int fb_frame_search_local_points_dev(fb_frame *f, const fb_map_points *map, cons
 int fb_frame_finish_dev(fb_frame *f, const fb_map_points *map, void *stream) {
   FB_TRY(fb::check_device());
   FB_ARG(f && map_ok(f, map));
+  fb::ProfScope prof_(fb::P_TRACK_GLUE, fb::as_stream(stream));
   k_finish<<<f->B, WG, 0, fb::as_stream(stream)>>>(f->dev(), map_dev(map), f->counts.as<int32_t>(), f->B);
   FB_HIP(hipGetLastError());
   return FB_OK;
