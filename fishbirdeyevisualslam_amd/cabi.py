@@ -234,7 +234,7 @@ class LocalBAArgs(C.Structure):
 
 class FrameParams(C.Structure):
     _fields_ = [("batch", _i32), ("front_width", _i32), ("front_height", _i32), ("bird_width", _i32), ("bird_height", _i32),
-                ("orb", OrbParams), ("K", _f32 * 4), ("D", _f32 * 4), ("Tbc", _f32 * 12), ("Tcb", _f32 * 12),
+                ("orb", OrbParams), ("bird_nfeatures", _i32), ("K", _f32 * 4), ("D", _f32 * 4), ("Tbc", _f32 * 12), ("Tcb", _f32 * 12),
                 ("pixel2meter", C.c_double), ("meter2pixel", C.c_double), ("rear_axle_to_center", C.c_double),
                 ("map_cap", _i32), ("local_mp_cap", _i32), ("local_mpb_cap", _i32)]
 
@@ -285,7 +285,7 @@ def fill(struct, **kw):
 EXPORTS = [
     "fb_abi_version", "fb_last_error", "fb_device_count", "fb_set_device", "fb_shutdown",
     "fb_prof_enable", "fb_prof_only", "fb_prof_reset", "fb_prof_report",
-    "fb_orb_create", "fb_orb_destroy", "fb_orb_get_tables", "fb_orb_capacity", "fb_orb_extract", "fb_orb_extract_batch_dev",
+    "fb_orb_create", "fb_orb_destroy", "fb_orb_get_tables", "fb_orb_capacity", "fb_orb_set_output_stride", "fb_orb_extract", "fb_orb_extract_batch_dev",
     "fb_orb_get_level", "fb_orb_get_blurred_level", "fb_orb_debug_candidates", "fb_orb_debug_timers", "fb_grid_build_batch_dev", "fb_bird_keys_to_cam_dev", "fb_bird_guidance", "fb_bird_guidance_dev",
     "fb_descriptor_distance_dev", "fb_descriptor_distance",
     "fb_match_projection_frame_dev", "fb_match_projection_frame",

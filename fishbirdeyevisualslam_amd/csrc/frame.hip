@@ -176,7 +176,7 @@ __global__ __launch_bounds__(GUIDE_THREADS) void k_bird_guidance(fb_bird_guidanc
 // 8 key points per 256-thread workgroup -- thousands of independent row walks in flight instead of 32 at a time inside
 // one workgroup, whose serialised byte loads made the one-kernel version 0.29 ms per frame at batch 1 (rocprof, round 3)
 // -- and the stable compaction by one workgroup per image.
-__global__ __launch_bounds__(256) void k_bird_flags(fb_bird_guidance_args A) {
+__global__ __launch_bounds__(256) void k_bird_flags(fb_bird_guidance_args A, int aligned4) {
   const int b = blockIdx.y, tid = threadIdx.x;
   const int n = min(max(A.n_in[b], 0), A.kp_stride);
   const int i = blockIdx.x * 8 + (tid >> 5), sub = tid & 31;
@@ -195,8 +195,32 @@ __global__ __launch_bounds__(256) void k_bird_flags(fb_bird_guidance_args A) {
     const size_t row = (size_t)pt1x + sub;       // size_t row = pt1x; row < pt2x; row++
     if ((float)row < pt2x && row < (size_t)A.rows) {
       const uint8_t *src = icp + row * (size_t)A.pitch;
-      for (size_t col = (size_t)pt1y; (float)col < pt2y && col < (size_t)A.cols; col++)
-        if (src[col] >= 10) { hit = true; break; }
+      // columns [c0, c1): size_t col = pt1y; col < pt2y && col < cols (at most 21 of them)
+      const size_t c0 = (size_t)pt1y;
+      size_t c1 = (size_t)pt2y;
+      if ((float)c1 < pt2y) c1++;                 // first integer >= pt2y
+      if (c1 > (size_t)A.cols) c1 = (size_t)A.cols;
+      if (aligned4) {
+        // the <= 21 bytes as <= 6 aligned dwords requested together (a byte loop costs one dependent round trip per
+        // column); a byte b is >= 10  <=>  ((b & 0x7f) + 0x76) | b  has bit 7 set
+        const size_t d0 = c0 >> 2;
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const size_t d = d0 + k;
+          if (d * 4 >= c1) break;
+          const uint32_t v = reinterpret_cast<const uint32_t *>(src)[d];
+          uint32_t m = (((v & 0x7f7f7f7fu) + 0x76767676u) | v) & 0x80808080u;
+          const long long lo = (long long)c0 - (long long)(d * 4), hi = (long long)c1 - (long long)(d * 4);  // valid bytes [lo, hi)
+          if (lo > 0) m &= 0xffffffffu << (8 * (int)lo);
+          if (hi < 4) m &= 0xffffffffu >> (8 * (int)(4 - hi));
+          any |= m;
+        }
+        hit = any != 0u;
+      } else {
+        for (size_t col = c0; col < c1; col++)
+          if (src[col] >= 10) { hit = true; break; }
+      }
     }
     if (mask) {
       const int my = (int)(kpt.y + 0.5f), mx = (int)(kpt.x + 0.5f);
@@ -285,7 +309,8 @@ int fb_bird_guidance_dev(const fb_bird_guidance_args *A, void *stream) {
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bird_guidance), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   fb::ProfScope prof_(fb::P_BIRDCAM, fb::as_stream(stream));
   if (A->keep && A->kp_stride > 0 && A->batch <= 65535) {
-    k_bird_flags<<<dim3((A->kp_stride + 7) / 8, A->batch), 256, 0, fb::as_stream(stream)>>>(*A);
+    const int aligned4 = (A->pitch % 4 == 0) && ((uintptr_t)A->contour % 4 == 0) ? 1 : 0;
+    k_bird_flags<<<dim3((A->kp_stride + 7) / 8, A->batch), 256, 0, fb::as_stream(stream)>>>(*A, aligned4);
     k_bird_compact<<<A->batch, GUIDE_THREADS, 0, fb::as_stream(stream)>>>(*A);
   } else {
     k_bird_guidance<<<A->batch, GUIDE_THREADS, lds, fb::as_stream(stream)>>>(*A);

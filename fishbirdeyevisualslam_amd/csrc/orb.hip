@@ -50,6 +50,7 @@ struct LevelInfo {
 
 struct OrbK {
   int nlevels, iniTh, minTh, totalCells, outStride, capOut;
+  int kpStride;  // entries per image in the caller's key-point / descriptor arrays (= capOut unless fb_orb_set_output_stride)
   int fastTileBytes, fastMaxOut, fastMaxPix;  // LDS carve of k_fast
   int fastTP;                                 // tile pitch instantiation of k_fast (44 / 56 / 72)
   int dbg;  // FB_FAST_DBG ablation switch (0 = normal)
@@ -1364,7 +1365,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(OrbK K, const uint8_
     const int byteVal = nib | (hi << 4);
     const int b1 = __shfl_down(byteVal, 2, 64), b2 = __shfl_down(byteVal, 4, 64), b3 = __shfl_down(byteVal, 6, 64);
     const uint32_t dw = (uint32_t)byteVal | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16) | ((uint32_t)b3 << 24);
-    const long long o = (long long)b * K.capOut + first + j;
+    const long long o = (long long)b * K.kpStride + first + j;
     if ((lane & 7) == 0) reinterpret_cast<uint32_t *>(desc + o * 32)[lane >> 3] = dw;
     if (lane == 0) {
       fb_keypoint kp;
@@ -1399,6 +1400,7 @@ struct fb_orb {
     if (evJoin) (void)hipEventDestroy(evJoin);
     if (sideStream) (void)hipStreamDestroy(sideStream);
   }
+  int kpStride = 0;  // fb_orb_set_output_stride (0 = the capacity)
   // workspace, valid for (w, h, batchCap)
   int w = 0, h = 0, batchCap = 0;
   OrbK K;
@@ -1465,6 +1467,7 @@ int prepare(fb_orb *o, int w, int h, int batch) {
   K.iniTh = p.ini_th_fast;
   K.minTh = p.min_th_fast;
   K.capOut = capacity_of(p);
+  K.kpStride = o->kpStride > 0 ? o->kpStride : K.capOut;
   for (int i = 0; i < 16; i++) K.umax[i] = o->t.umax[i];
   long long pyrOff = 0, candOff = 0, blurOff = 0;
   int cells = 0, outOff = 0, maxNodes = 0, strips = 0;
@@ -1665,6 +1668,13 @@ extern "C" {
 int fb_orb_capacity(const fb_orb_params *params) {
   if (!params) return FB_ERR_ARG;
   return capacity_of(*params);
+}
+
+int fb_orb_set_output_stride(fb_orb *h, int kp_stride) {
+  FB_ARG(h && (kp_stride == 0 || kp_stride >= capacity_of(h->p)));
+  h->kpStride = kp_stride;
+  h->K.kpStride = kp_stride > 0 ? kp_stride : capacity_of(h->p);  // (the workspace itself does not depend on it)
+  return FB_OK;
 }
 
 int fb_orb_create(const fb_orb_params *params, fb_orb **out) {

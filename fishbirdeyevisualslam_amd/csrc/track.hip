@@ -488,6 +488,7 @@ int fb_frame_create(const fb_frame_params *p, fb_frame **out) {
   FB_ARG(p->front_width > 0 && p->front_height > 0 && p->bird_width > 0 && p->bird_height > 0);
   FB_ARG(p->orb.nlevels >= 1 && p->orb.nlevels <= FB_MAX_LEVELS && p->orb.nfeatures > 0 && p->orb.scale_factor > 1.0f);
   FB_ARG(p->map_cap >= 1 && p->local_mp_cap >= 1 && p->local_mpb_cap >= 1);
+  FB_ARG(p->bird_nfeatures >= 0 && p->bird_nfeatures <= p->orb.nfeatures);
   FB_TRY(fb::check_device());
   fb_frame *f = new (std::nothrow) fb_frame();
   if (!f) { fb::set_error("fb_frame_create: out of memory"); return FB_ERR_HIP; }
@@ -572,11 +573,18 @@ int fb_frame_extract_dev(fb_frame *f, fb_orb *of, fb_orb *ob, const uint8_t *d_f
   FB_ARG(front_stride >= f->P.front_width && bird_stride >= f->P.bird_width);
   FB_ARG(!d_mask || d_contour);  // the detect mask rides in the contour kernel
   if (d_contour) FB_ARG(bird_image_stride == (size_t)bird_stride * f->P.bird_height);  // contour / mask share the bird image's geometry
-  hipStream_t s = fb::as_stream(stream), sb = f->sBird;
+  // (while every kernel is bracketed for a per-kernel table -- fb_prof_enable without fb_prof_only -- the bird chain stays on
+  // the caller's stream, so that the table shows each kernel on its own)
+  const bool fork = !(fb::g_prof_on && fb::g_prof_only < 0);
+  hipStream_t s = fb::as_stream(stream), sb = fork ? f->sBird : s;
   const int B = f->B, cap = f->cap;
+  FB_TRY(fb_orb_set_output_stride(of, cap));  // both extractors write into the frame's arrays (one stride)
+  FB_TRY(fb_orb_set_output_stride(ob, cap));
   // bird chain on the handle's stream, beside the front chain
-  FB_HIP(hipEventRecord(f->evFork, s));
-  FB_HIP(hipStreamWaitEvent(sb, f->evFork, 0));
+  if (fork) {
+    FB_HIP(hipEventRecord(f->evFork, s));
+    FB_HIP(hipStreamWaitEvent(sb, f->evFork, 0));
+  }
   {
     fb_keypoint *k0 = d_contour ? f->bkps_pre.as<fb_keypoint>() : f->bkps.as<fb_keypoint>();
     uint8_t *d0 = d_contour ? f->bdesc_pre.as<uint8_t>() : f->bdesc.as<uint8_t>();
@@ -594,7 +602,7 @@ int fb_frame_extract_dev(fb_frame *f, fb_orb *of, fb_orb *ob, const uint8_t *d_f
     FB_TRY(fb_bird_keys_to_cam_dev(f->bkps.as<fb_keypoint>(), f->nb.as<int32_t>(), B, cap, f->P.bird_width, f->P.bird_height,
                                    f->P.pixel2meter, f->P.rear_axle_to_center, f->P.Tcb, f->bcam.as<float>(), sb));
     FB_TRY(fb_grid_build_batch_dev(f->bkps.as<fb_keypoint>(), f->nb.as<int32_t>(), B, cap, &f->gB, f->bcs.as<int32_t>(), f->bci.as<int32_t>(), sb));
-    FB_HIP(hipEventRecord(f->evJoin, sb));
+    if (fork) FB_HIP(hipEventRecord(f->evJoin, sb));
   }
   FB_TRY(fb_orb_extract_batch_dev(of, d_front, B, f->P.front_width, f->P.front_height, front_stride, front_image_stride,
                                   f->kps.as<fb_keypoint>(), f->desc.as<uint8_t>(), f->n.as<int32_t>(), s));
@@ -603,7 +611,7 @@ int fb_frame_extract_dev(fb_frame *f, fb_orb *of, fb_orb *ob, const uint8_t *d_f
   { fb::ProfScope prof_(fb::P_TRACK_GLUE, s);
     k_frame_reset<<<slot_grid(f), TT, 0, s>>>(f->dev(), f->counts.as<int32_t>(), B); }
   FB_HIP(hipGetLastError());
-  FB_HIP(hipStreamWaitEvent(s, f->evJoin, 0));
+  if (fork) FB_HIP(hipStreamWaitEvent(s, f->evJoin, 0));
   return FB_OK;
 }
 

@@ -17,13 +17,14 @@ VIEW_FIELDS = (("n", np.int32, ()), ("kps", cabi.KP_DTYPE, ("cap",)), ("kps_un",
                ("map_point_bird", np.int32, ("cap",)), ("bird_outlier", np.uint8, ("cap",)), ("Tcw", np.float32, (12,)))
 
 
-def frame_params(batch, front_wh, bird_wh, K, D, map_cap, local_mp_cap, local_mpb_cap, orb=None):
+def frame_params(batch, front_wh, bird_wh, K, D, map_cap, local_mp_cap, local_mpb_cap, orb=None, bird_nfeatures=0):
     Tbc, Tcb = synth.extrinsics()
     p = cabi.FrameParams()
     fill(p, batch=batch, front_width=front_wh[0], front_height=front_wh[1], bird_width=bird_wh[0], bird_height=bird_wh[1],
          K=[float(x) for x in K], D=[float(x) for x in D], Tbc=[float(x) for x in Tbc[:3, :4].reshape(12)],
          Tcb=[float(x) for x in Tcb[:3, :4].reshape(12)], pixel2meter=synth.PIXEL2METER, meter2pixel=synth.METER2PIXEL,
-         rear_axle_to_center=synth.REAR_AXLE_TO_CENTER, map_cap=map_cap, local_mp_cap=local_mp_cap, local_mpb_cap=local_mpb_cap)
+         rear_axle_to_center=synth.REAR_AXLE_TO_CENTER, map_cap=map_cap, local_mp_cap=local_mp_cap, local_mpb_cap=local_mpb_cap,
+         bird_nfeatures=bird_nfeatures)
     p.orb = cabi.OrbParams(**(orb or synth.ORB_DEFAULT))
     return p
 
@@ -41,7 +42,7 @@ def alloc_view(batch, cap):
 
 class TrackChain:
     def __init__(self, batch, front_wh=(1280, 720), bird_wh=(512, 512), K=(500.0, 500.0, 640.0, 360.0), D=(0, 0, 0, 0),
-                 map_cap=None, bird_cap=None, device="cuda:0", orb=None, use_lists=False):
+                 map_cap=None, bird_cap=None, device="cuda:0", orb=None, use_lists=False, bird_nfeatures=0):
         self.L = lib()
         self.B = batch
         self.dev = torch.device(device)
@@ -52,10 +53,13 @@ class TrackChain:
         self.cap = self.L.fb_orb_capacity(C.byref(orbp))
         self.map_cap = map_cap or self.cap
         self.bird_cap = bird_cap or 2 * self.cap
-        self.params = frame_params(batch, front_wh, bird_wh, K, D, self.map_cap, self.map_cap, self.bird_cap, orb)
+        self.params = frame_params(batch, front_wh, bird_wh, K, D, self.map_cap, self.map_cap, self.bird_cap, orb, bird_nfeatures)
         self.orb_f, self.orb_b = C.c_void_p(), C.c_void_p()
         check(self.L.fb_orb_create(C.byref(orbp), C.byref(self.orb_f)), "fb_orb_create")
-        check(self.L.fb_orb_create(C.byref(orbp), C.byref(self.orb_b)), "fb_orb_create")
+        orbb = cabi.OrbParams(**(orb or synth.ORB_DEFAULT))
+        if bird_nfeatures:
+            orbb.nfeatures = bird_nfeatures
+        check(self.L.fb_orb_create(C.byref(orbb), C.byref(self.orb_b)), "fb_orb_create")
         self.tables = cabi.OrbTables()
         check(self.L.fb_orb_get_tables(self.orb_f, C.byref(self.tables)), "fb_orb_get_tables")
         # three handles: frame j lives in frames[j % 3]; with the pipelined driver frame k+1 is being constructed on the

@@ -107,6 +107,9 @@ int fb_orb_get_tables(const fb_orb *h, fb_orb_tables *out);
 /* Output capacity per image.  DistributeOctTree stops at >= N nodes, so a level can
  * return up to N+2 keypoints (ORBextractor.cc:669,729): capacity = nfeatures + 8*nlevels. */
 int fb_orb_capacity(const fb_orb_params *params);
+/* Entries per image in the output arrays of fb_orb_extract_batch_dev when the caller's arrays are wider than the
+ * capacity (an fb_frame shares one stride between a 2000-feature front and a 1000-feature bird extractor).  0 = capacity. */
+int fb_orb_set_output_stride(fb_orb *h, int kp_stride);
 
 /* replaces ORBextractor::operator() (ORBextractor.cc:1043-1105), host buffers.
  * image: u8, row-major, `stride` bytes per row.  keypoints/descriptors must hold
@@ -748,6 +751,8 @@ typedef struct fb_frame_params {
   int32_t batch;                    /* sequences side by side; 1 = the reference's single Frame                        */
   int32_t front_width, front_height, bird_width, bird_height;
   fb_orb_params orb;                /* ORBextractor.* of the settings file: capacity and level tables (Frame.cc:299-306)  */
+  int32_t bird_nfeatures;           /* features of the bird extractor (the reference: cv::ORB::create(2000), Frame.cc:337;
+                                       BASELINE configs[2]: 1000 bird edges); 0 = orb.nfeatures.  <= orb.nfeatures        */
   float K[4];                       /* Camera.fx, fy, cx, cy (Tracking.cc:61-75)                                        */
   float D[4];                       /* Camera.k1, k2, p1, p2, fed to the fisheye model as k1..k4 (Frame.cc:657);
                                        D[0] == 0: mvKeysUn = mvKeys (Frame.cc:640-644)                                  */

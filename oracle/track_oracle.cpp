@@ -151,8 +151,10 @@ int orc_frame_extract(orc_frame *f, const uint8_t *front, int front_stride, cons
   std::vector<fb_keypoint> pre(B * cap);
   std::vector<uint8_t> pred(B * cap * 32);
   std::vector<int32_t> npre(B, 0);
+  fb_orb_params pb = f->P.orb;
+  if (f->P.bird_nfeatures > 0) pb.nfeatures = f->P.bird_nfeatures;
   for (size_t b = 0; b < B; b++)  // the E9 substitution: ORBextractor on the bird image (:337-339, :355)
-    orc_orb_extract(&f->P.orb, bird + b * bbytes, f->P.bird_width, f->P.bird_height, bird_stride, pre.data() + b * cap,
+    orc_orb_extract(&pb, bird + b * bbytes, f->P.bird_width, f->P.bird_height, bird_stride, pre.data() + b * cap,
                     pred.data() + b * cap * 32, &npre[b]);
   t1 = now();
   f->stage_s[1] = t1 - t0;

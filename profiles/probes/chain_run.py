@@ -12,7 +12,7 @@ nframes = 11
 seq = SQ.Sequence(B, nframes, seed=9000 + B, device="cuda:0")
 imgs = [seq.render(k) for k in range(nframes)]
 mask = torch.from_numpy(seq.mask.copy()).cuda()
-tc = TR.TrackChain(B, (1280, 720), (512, 512), K=seq.Kc, D=seq.D, map_cap=2 * 2064, bird_cap=8 * 2064)
+tc = TR.TrackChain(B, (1280, 720), (512, 512), K=seq.Kc, D=seq.D, map_cap=2 * 2064, bird_cap=8 * 2064, bird_nfeatures=int(os.environ.get('BIRD', '1000')))
 tc.extract(*imgs[nframes - 1], mask); v_end = tc.view("cur")
 tc.extract(*imgs[0], mask); v0 = tc.view("cur")
 M, MB, mp0, mpb0, Tcw0 = seq.build_map(v0, tc.tables, map_cap=tc.map_cap, bird_cap=tc.bird_cap, extra_views=[(nframes - 1, v_end)])

@@ -57,10 +57,10 @@ def _lists(M, MB, seed):
     return (lm, nlm), (lb, nlb)
 
 
-def _run(B, K, front_wh, bird_wh, fx, use_lists, seed, granular=False, contour=True, pipelined=False):
+def _run(B, K, front_wh, bird_wh, fx, use_lists, seed, granular=False, contour=True, pipelined=False, bird_nfeatures=0):
     from oracle import pyoracle as O
     seq = S.Sequence(B, K, seed=seed, front_wh=front_wh, bird_wh=bird_wh, fx=fx, fy=fx, device="cuda:0")
-    tc = T.TrackChain(B, front_wh, bird_wh, K=seq.Kc, D=seq.D, use_lists=use_lists)
+    tc = T.TrackChain(B, front_wh, bird_wh, K=seq.Kc, D=seq.D, use_lists=use_lists, bird_nfeatures=bird_nfeatures)
     oc = O.OracleChain(tc.params, tc.map_cap, tc.bird_cap, use_lists=use_lists)
     import torch
     mask_d = torch.from_numpy(seq.mask).cuda() if contour else None
@@ -126,6 +126,9 @@ def _run(B, K, front_wh, bird_wh, fx, use_lists, seed, granular=False, contour=T
 def test_chain_six_frames_full_size():
     """BASELINE configs[2] geometry: 1280x720 front + 512x512 bird, fisheye.yaml distortion, contour + mask, 2 sequences."""
     worst, stats = _run(2, 6, (1280, 720), (512, 512), 500.0, use_lists=False, seed=9000)
+    # the bench's configuration: a 1000-feature bird extractor writing into the frame's 2064-entry rows
+    worst_b, stats_b = _run(2, 4, (1280, 720), (512, 512), 500.0, use_lists=False, seed=9010, bird_nfeatures=1000)
+    worst = max(worst, worst_b)
     print("track chain 1280x720+512x512, 5 tracked frames x 2 sequences: worst relative pose difference %.3g; counters of sequence 0 %s" % (worst, stats))
 
 
