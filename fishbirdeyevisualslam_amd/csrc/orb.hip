@@ -1765,11 +1765,13 @@ int fb_orb_extract_batch_dev(fb_orb *o, const uint8_t *d_images, int batch, int 
     FB_HIP(hipEventRecord(o->evFork, s));
     FB_HIP(hipStreamWaitEvent(sBlur, o->evFork, 0));
   }
+#ifndef FB_ORB_ABLATE_BLUR  // probe build only (profiles/probes/ablate_blur.sh): what the step costs without the blur launch (results are then wrong)
   {
     fb::ProfScope prof_(fb::P_BLUR, sBlur);
     k_blur<<<dim3((K.blurStrips[nl] + 3) / 4, batch), 256, 0, sBlur>>>(K, d_images, (long long)image_stride, stride, o->pyr.as<uint8_t>(),
                                                                         o->blur.as<uint8_t>());
   }
+#endif
   if (fork) FB_HIP(hipEventRecord(o->evJoin, sBlur));
   static const int octWideMax = getenv("FB_OCT_WIDE_MAX") ? atoi(getenv("FB_OCT_WIDE_MAX")) : 512;
   const bool octWide = nl * batch <= octWideMax;  // few workgroups: 1024 threads each (two such workgroups fill a CU's wave slots)
