@@ -314,7 +314,8 @@ def host_fed_leg(pipe, front, bird, B, steps=12):
             bufs[k & 1][0].copy_(pin_f, non_blocking=True)
             bufs[k & 1][1].copy_(pin_b, non_blocking=True)
             ev[k & 1].record(sC)
-    # copy alone
+    # copy alone (one untimed pass first: the first touch of freshly pinned pages is slow)
+    upload(0); upload(1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(4):

@@ -1,0 +1,17 @@
+# Collects the round-3 profile evidence on the GPU box (run from the repo root through gpurun); outputs under gpurun_out/r03/.
+# Same four passes as round 2 on the configs[2] step (the extractor kernels are unchanged) + the kernel tables of the tracking chain.
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r03; mkdir -p $O
+CMD="python3 bench.py --serial --no-ba --cpu-sample 0 --no-single --no-chain --steps 10"
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $CMD > $O/kt.log 2>&1
+python3 profiles/probes/rocpd_stats.py $O/kt/kt_results.db > $O/r03_bench_serial_b256_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f -- $CMD > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w -- $CMD > $O/write.log 2>&1
+python3 profiles/probes/make_traffic_json.py $O/fetch/f_results.db $O/write/w_results.db 256 $O/r03_pmc_traffic.json > $O/r03_pmc_fetch_write_b256.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $O/c1 -o c1 -- python3 profiles/probes/chain_run.py 1 60 > $O/chain_b1.log 2>&1
+python3 profiles/probes/rocpd_stats.py $O/c1/c1_results.db > $O/r03_chain_b1_kernel_stats.csv
+rocprofv3 --kernel-trace --stats -d $O/c256 -o c256 -- python3 profiles/probes/chain_run.py 256 10 > $O/chain_b256.log 2>&1
+python3 profiles/probes/rocpd_stats.py $O/c256/c256_results.db > $O/r03_chain_b256_kernel_stats.csv
+rm -rf $O/kt $O/fetch $O/write $O/c1 $O/c256
+echo collected
