@@ -188,6 +188,8 @@ class ORBextractor {
   std::vector<float> GetInverseScaleFactors() const { return {t_.inv_scale_factor, t_.inv_scale_factor + p_.nlevels}; }
   std::vector<float> GetScaleSigmaSquares() const { return {t_.level_sigma2, t_.level_sigma2 + p_.nlevels}; }
   std::vector<float> GetInverseScaleSigmaSquares() const { return {t_.inv_level_sigma2, t_.inv_level_sigma2 + p_.nlevels}; }
+  fb_orb *handle() const { return h_; }              // for the device-resident Frame (DeviceFrame below)
+  const fb_orb_params &params() const { return p_; }
 
  private:
   fb_orb_params p_;
@@ -487,6 +489,70 @@ class Optimizer {
     return ninl;
   }
 };
+
+// ---- the device-resident Frame and the per-frame chain ------------------------------------------------------------
+// DeviceFrame = the reference's Frame with its per-key-point members in HBM (fb_frame, include/fishbird.h); the methods
+// below carry the names of the reference functions they stand for and only ENQUEUE on `stream`.  TrackedFrame() is what
+// Tracking::Track runs for a frame in state OK (TrackWithMotionModel + TrackLocalMap, Tracking.cc:1312-1441) followed by the
+// one read-back the state machine needs; retries / LOST handling stay with the caller.
+struct DeviceMap {                 // the caller's MapPoint / MapPointBird tables on the device + the local-map index lists
+  fb_map_points points{};
+  fb_map_points_bird birdPoints{};
+  const int32_t *localPoints = nullptr, *nLocalPoints = nullptr;      // mvpLocalMapPoints (nullptr = the whole table)
+  const int32_t *localBirdPoints = nullptr, *nLocalBirdPoints = nullptr;  // Map::GetLocalMapPointsBird()
+};
+
+class DeviceFrame {
+ public:
+  explicit DeviceFrame(const fb_frame_params &p) : p_(p) { check(fb_frame_create(&p_, &h_)); }
+  ~DeviceFrame() { fb_frame_destroy(h_); }
+  DeviceFrame(const DeviceFrame &) = delete;
+  DeviceFrame &operator=(const DeviceFrame &) = delete;
+  fb_frame *handle() const { return h_; }
+  int batch() const { return p_.batch; }
+
+  // Frame::Frame(imGray, BirdGray, ..., birdviewmask, ..., birdviewContourICP, ..., extractor, ...) from host images
+  void Construct(ORBextractor &front, ORBextractor &bird, const uint8_t *imGray, int stride, const uint8_t *birdGray, int birdStride,
+                 const uint8_t *contourICP, const uint8_t *mask, void *stream = nullptr) {
+    check(fb_frame_extract(h_, front.handle(), bird.handle(), imGray, stride, birdGray, birdStride, contourICP, mask, stream));
+  }
+  void SetPose(const float *d_Tcw, void *stream = nullptr) { check(fb_frame_set_pose_dev(h_, d_Tcw, stream)); }
+
+  struct TrackResult {             // what Tracking reads after a frame (one synchronisation)
+    std::vector<int32_t> counts;   // [FB_CNT_COUNT][batch]
+    std::vector<float> Tcw;        // [batch][12]
+    int count(int slot, int b = 0) const { return counts[(size_t)slot * (counts.size() / FB_CNT_COUNT) + b]; }
+    bool trackedWithMotionModel(int b = 0) const { return count(FB_CNT_PROJ_MATCHES, b) >= 20 && count(FB_CNT_MATCHES_MAP, b) >= 10; }  // Tracking.cc:1351,1384
+    bool trackedLocalMap(int b = 0) const { return count(FB_CNT_MATCHES_INLIERS, b) >= 30; }                                              // :1438
+  };
+  // Tracking::Track, state OK: this frame against `last`; d_deltaT = rows 0..2 of detlaT (Tracking.cc:1316) on the device
+  TrackResult TrackedFrame(DeviceFrame &last, const DeviceMap &map, const float *d_deltaT, float wB = 1.f, float wF = 1.f, void *stream = nullptr) {
+    fb_track_args T{};
+    T.map = map.points; T.mpb = map.birdPoints; T.d_delta = d_deltaT;
+    T.d_local_mp = map.localPoints; T.d_n_local_mp = map.nLocalPoints; T.d_local_mpb = map.localBirdPoints; T.d_n_local_mpb = map.nLocalBirdPoints;
+    T.wB = wB; T.wF = wF;
+    check(fb_frame_track_dev(h_, last.h_, &T, stream));
+    TrackResult r;
+    r.counts.resize((size_t)FB_CNT_COUNT * p_.batch);
+    r.Tcw.resize((size_t)12 * p_.batch);
+    check(fb_frame_counts(h_, r.counts.data(), r.Tcw.data(), stream));
+    return r;
+  }
+
+ private:
+  fb_frame_params p_;
+  fb_frame *h_ = nullptr;
+};
+
+// the one-call-per-reference-function forms on device frames (results stay in the frames; counts via fb_frame_counts)
+inline void SearchByProjection(const ORBmatcher &, DeviceFrame &cur, const DeviceFrame &last, const DeviceMap &map, float th, float nnratio = 0.9f,
+                               bool checkOri = true, void *stream = nullptr) {  // ORBmatcher::SearchByProjection(Frame&, const Frame&, th, mono)
+  const fb_matcher_params m{nnratio, checkOri ? 1 : 0};
+  check(fb_frame_search_by_projection_dev(cur.handle(), last.handle(), &map.points, th, &m, stream));
+}
+inline void PoseOptimizationWithBird(DeviceFrame &f, const DeviceMap &map, float wB = 1.f, float wF = 1.f, int which = 0, void *stream = nullptr) {
+  check(fb_frame_pose_optimization_dev(f.handle(), &map.points, &map.birdPoints, FB_POSE_FRONT_BIRD, wB, wF, which, stream));
+}
 
 }  // namespace fishbird
 #endif

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime_api.h>  // the host owns its map tables on the device: plain hipMalloc / hipMemcpy
 
 #include "../../include/fishbird.h"
+#include "../../fishbirdeyevisualslam_amd/host/fishbird_host.hpp"  // part (b) goes through the C++ mirror (DeviceFrame)
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define CK(expr) do { int rc_ = (expr); if (rc_ != 0) { std::fprintf(stderr, "%s failed (%d): %s\n", #expr, rc_, fb_last_error()); return 1; } } while (0)
@@ -175,9 +176,9 @@ int main(int argc, char **argv) {
   std::memcpy(fp.Tbc, Tbc, sizeof(Tbc)); std::memcpy(fp.Tcb, Tcb, sizeof(Tcb));
   fp.pixel2meter = 0.03984; fp.meter2pixel = 25.1; fp.rear_axle_to_center = 1.393;
   fp.map_cap = cap; fp.local_mp_cap = cap; fp.local_mpb_cap = 2 * cap;
-  fb_frame *fr[2] = {nullptr, nullptr};
-  CK(fb_frame_create(&fp, &fr[0]));
-  CK(fb_frame_create(&fp, &fr[1]));
+  fishbird::ORBextractor exFront(2000, 1.2f, 8, 15, 5), exBird(2000, 1.2f, 8, 15, 5);
+  fishbird::DeviceFrame frameA(fp), frameB(fp);
+  fishbird::DeviceFrame *fr[2] = {&frameA, &frameB};
   // map tables on the device: the C-ABI carries no allocator, the host uses its HIP runtime
   struct Dev { void *p = nullptr; };
   auto up = [&](Dev &d, const void *h, size_t n) -> int {
@@ -206,29 +207,33 @@ int main(int argc, char **argv) {
       up(d_desc, fd.data(), (size_t)cap * 32) || up(d_bn, &nbird, 4) || up(d_bxw, bxw2.data(), bxw2.size() * 4) ||
       up(d_bdesc, bdesc2.data(), bdesc2.size()) || up(d_delta, Tcw0, 48) || up(d_mp, mp0.data(), (size_t)cap * 4) ||
       up(d_mpb, mpb0.data(), (size_t)cap * 4) || up(d_T, Tcw0, 48)) { std::fprintf(stderr, "device allocation failed\n"); return 1; }
-  fb_track_args T;
-  std::memset(&T, 0, sizeof(T));
-  T.map.stride = cap; T.map.n = (int32_t *)d_n.p; T.map.bad = (uint8_t *)d_bad.p; T.map.obs_pos = (uint8_t *)d_obs.p; T.map.xw = (float *)d_xw.p;
-  T.map.normal = (float *)d_nrm.p; T.map.max_dist = (float *)d_max.p; T.map.min_dist = (float *)d_min.p; T.map.desc = (uint8_t *)d_desc.p;
-  T.mpb.stride = 2 * cap; T.mpb.n = (int32_t *)d_bn.p; T.mpb.xw = (float *)d_bxw.p; T.mpb.desc = (uint8_t *)d_bdesc.p;
-  T.d_delta = (float *)d_delta.p; T.wB = 1.f; T.wF = 1.f;
-  CK(fb_frame_extract(fr[0], of, ob, front.data(), FW, bird.data(), BW, nullptr, nullptr, nullptr));
-  CK(fb_frame_set_map_points_dev(fr[0], (int32_t *)d_mp.p, (int32_t *)d_mpb.p, nullptr));
-  CK(fb_frame_set_pose_dev(fr[0], (float *)d_T.p, nullptr));
-  std::vector<int32_t> counts(FB_CNT_COUNT);
-  float Tout[12];
+  fishbird::DeviceMap dmap;
+  dmap.points.stride = cap; dmap.points.n = (int32_t *)d_n.p; dmap.points.bad = (uint8_t *)d_bad.p; dmap.points.obs_pos = (uint8_t *)d_obs.p;
+  dmap.points.xw = (float *)d_xw.p; dmap.points.normal = (float *)d_nrm.p; dmap.points.max_dist = (float *)d_max.p;
+  dmap.points.min_dist = (float *)d_min.p; dmap.points.desc = (uint8_t *)d_desc.p;
+  dmap.birdPoints.stride = 2 * cap; dmap.birdPoints.n = (int32_t *)d_bn.p; dmap.birdPoints.xw = (float *)d_bxw.p; dmap.birdPoints.desc = (uint8_t *)d_bdesc.p;
   std::vector<double> t_h_extract, t_h_track, t_h_frame;
-  int cur = 1;
-  for (int it = 0; it < warm + iters; it++) {
-    const double a0 = now_ms();
-    CK(fb_frame_extract(fr[cur], of, ob, front.data(), FW, bird.data(), BW, nullptr, nullptr, nullptr));
-    const double a1 = now_ms();
-    CK(fb_frame_track_dev(fr[cur], fr[cur ^ 1], &T, nullptr));
-    CK(fb_frame_counts(fr[cur], counts.data(), Tout, nullptr));   // the one synchronisation of the frame
-    const double a2 = now_ms();
-    if (it >= warm) { t_h_extract.push_back(a1 - a0); t_h_track.push_back(a2 - a1); t_h_frame.push_back(a2 - a0); }
-    cur ^= 1;
+  fishbird::DeviceFrame::TrackResult res;
+  try {
+    fr[0]->Construct(exFront, exBird, front.data(), FW, bird.data(), BW, nullptr, nullptr);
+    CK(fb_frame_set_map_points_dev(fr[0]->handle(), (int32_t *)d_mp.p, (int32_t *)d_mpb.p, nullptr));
+    fr[0]->SetPose((float *)d_T.p);
+    int cur = 1;
+    for (int it = 0; it < warm + iters; it++) {
+      const double a0 = now_ms();
+      fr[cur]->Construct(exFront, exBird, front.data(), FW, bird.data(), BW, nullptr, nullptr);   // Frame::Frame from host images
+      const double a1 = now_ms();
+      res = fr[cur]->TrackedFrame(*fr[cur ^ 1], dmap, (float *)d_delta.p);                          // the chain + the one synchronisation
+      const double a2 = now_ms();
+      if (it >= warm) { t_h_extract.push_back(a1 - a0); t_h_track.push_back(a2 - a1); t_h_frame.push_back(a2 - a0); }
+      cur ^= 1;
+    }
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "frame handle path failed: %s\n", e.what());
+    return 1;
   }
+  std::vector<int32_t> counts(FB_CNT_COUNT);
+  for (int i = 0; i < FB_CNT_COUNT; i++) counts[i] = res.count(i);
   std::printf("{\"iterations\": %d, \"warmup\": %d, \"keypoints_front\": %d, \"keypoints_bird\": %d, \"front_matches\": %d, \"bird_matches\": %d, "
               "\"pose_inliers\": %d, \"host_pointer_ms_median\": {\"fb_orb_extract_front\": %.4f, \"fb_orb_extract_bird\": %.4f, "
               "\"host_grids_and_bird_cam\": %.4f, \"fb_match_projection_frame\": %.4f, \"fb_match_bird_mappoints\": %.4f, "
@@ -238,7 +243,6 @@ int main(int argc, char **argv) {
               iters, warm, nf, nb, nm3, nm9, ninl, median(t_ef), median(t_eb), median(t_grid), median(t_m3), median(t_m9), median(t_gather),
               median(t_pose), median(t_frame), median(t_h_extract), median(t_h_track), median(t_h_frame), counts[FB_CNT_PROJ_MATCHES],
               counts[FB_CNT_POSE1_INLIERS], counts[FB_CNT_LOCAL_MATCHES], counts[FB_CNT_POSE2_INLIERS], counts[FB_CNT_BIRD_KF_MATCHES]);
-  fb_frame_destroy(fr[0]); fb_frame_destroy(fr[1]);
   fb_orb_destroy(of); fb_orb_destroy(ob);
   return 0;
 }

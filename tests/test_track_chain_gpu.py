@@ -57,7 +57,7 @@ def _lists(M, MB, seed):
     return (lm, nlm), (lb, nlb)
 
 
-def _run(B, K, front_wh, bird_wh, fx, use_lists, seed, granular=False, contour=True, pipelined=False, bird_nfeatures=0):
+def _run(B, K, front_wh, bird_wh, fx, use_lists, seed, granular=False, contour=True, pipelined=False, bird_nfeatures=0, check_workload=True):
     from oracle import pyoracle as O
     seq = S.Sequence(B, K, seed=seed, front_wh=front_wh, bird_wh=bird_wh, fx=fx, fy=fx, device="cuda:0")
     tc = T.TrackChain(B, front_wh, bird_wh, K=seq.Kc, D=seq.D, use_lists=use_lists, bird_nfeatures=bird_nfeatures)
@@ -112,11 +112,12 @@ def _run(B, K, front_wh, bird_wh, fx, use_lists, seed, granular=False, contour=T
             scale = max(1.0, float(np.abs(ot["xw"][bb, :nt]).max()))
             assert np.abs(gt["xw"][bb, :nt] - ot["xw"][bb, :nt]).max() / scale <= REL_TOL
         cnt = o["counts"]
-        # the chain must be doing real work on every frame: it tracks (Tracking.cc:1384: nmatchesMap >= 10; :1438: >= 30 inliers)
-        assert (cnt[cabi.FB_CNT["MATCHES_MAP"]] >= 10).all() and (cnt[cabi.FB_CNT["MATCHES_INLIERS"]] >= 30).all(), cnt[:12].T
-        for bb in range(B):
-            Tt = np.asarray(seq.Tcw_true(k, bb))[:3, :4].reshape(12)
-            assert np.abs(o["Tcw"][bb] - Tt).max() < 0.2, ("tracking drifted from the true pose", k, bb)
+        if check_workload:
+            # the chain must be doing real work on every frame: it tracks (Tracking.cc:1384: nmatchesMap >= 10; :1438: >= 30 inliers)
+            assert (cnt[cabi.FB_CNT["MATCHES_MAP"]] >= 10).all() and (cnt[cabi.FB_CNT["MATCHES_INLIERS"]] >= 30).all(), cnt[:12].T
+            for bb in range(B):
+                Tt = np.asarray(seq.Tcw_true(k, bb))[:3, :4].reshape(12)
+                assert np.abs(o["Tcw"][bb] - Tt).max() < 0.2, ("tracking drifted from the true pose", k, bb)
         stats.append(cnt[:12, 0].tolist())
     tc.close()
     oc.close()
