@@ -101,6 +101,47 @@ struct DevBuf {
   template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// One staged transfer per host-pointer call.  The drop-in entry points used to upload every argument array with its own
+// synchronous hipMemcpy (16 of them for SearchByProjection: ~0.2 ms of a 0.33 ms call, `host_abi` in bench.py): the arrays of a
+// call are now packed into one page-locked block (per host thread, grows on demand), travel with ONE copy into one device
+// block, and the outputs come back with one copy.  in() = input only; out() = output, optionally uploaded first (in/out
+// arrays: entries the kernel does not write keep the caller's contents).
+void *pinned_scratch(size_t bytes);  // per-thread page-locked block of at least `bytes` (nullptr on failure, error set)
+struct Stager {
+  struct Item { void **field; const void *src; void *dst; size_t bytes, off; };
+  std::vector<Item> ins, outs;
+  DevBuf dev;
+  uint8_t *pin = nullptr;
+  size_t inBytes = 0, total = 0;
+  static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+  void in(void **field, const void *src, size_t bytes) { if (src) ins.push_back({field, src, nullptr, bytes, 0}); }
+  void out(void **field, void *host, size_t bytes, bool copy_in) { if (host) outs.push_back({field, copy_in ? host : nullptr, host, bytes, 0}); }
+  int commit(hipStream_t s) {
+    size_t off = 0;
+    for (auto &it : ins) { it.off = off; off += up256(it.bytes ? it.bytes : 1); }
+    inBytes = off;
+    for (auto &it : outs) { it.off = off; off += up256(it.bytes ? it.bytes : 1); }
+    total = off ? off : 256;
+    pin = static_cast<uint8_t *>(pinned_scratch(total));
+    if (!pin) return FB_ERR_HIP;
+    FB_TRY(dev.alloc(total));
+    bool anyOutIn = false;
+    for (auto &it : ins) if (it.bytes) memcpy(pin + it.off, it.src, it.bytes);
+    for (auto &it : outs) if (it.src && it.bytes) { memcpy(pin + it.off, it.src, it.bytes); anyOutIn = true; }
+    const size_t upBytes = anyOutIn ? total : inBytes;
+    if (upBytes) FB_HIP(hipMemcpyAsync(dev.p, pin, upBytes, hipMemcpyHostToDevice, s));
+    for (auto &it : ins) *it.field = dev.as<uint8_t>() + it.off;
+    for (auto &it : outs) *it.field = dev.as<uint8_t>() + it.off;
+    return FB_OK;
+  }
+  int fetch(hipStream_t s) {  // waits for the stream, then hands the outputs to the caller's arrays
+    if (total > inBytes) FB_HIP(hipMemcpyAsync(pin + inBytes, dev.as<uint8_t>() + inBytes, total - inBytes, hipMemcpyDeviceToHost, s));
+    FB_HIP(hipStreamSynchronize(s));
+    for (auto &it : outs) if (it.bytes) memcpy(it.dst, pin + it.off, it.bytes);
+    return FB_OK;
+  }
+};
+
 // Column sums of up to 32 per-lane values over the 64 lanes as a reduce-scatter butterfly: at the step with mask m a
 // lane sends one half of its values to lane^m, keeps the other half and adds what it receives, so the value count halves
 // every step (16 + 8 + 4 + 2 + 1 + 1 = 32 fp64 exchanges instead of 6 per value).  On return v[0] of lane L is the sum

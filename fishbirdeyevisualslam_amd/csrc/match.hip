@@ -1106,30 +1106,27 @@ int fb_match_birdview_dev(const fb_birdview_args *A, void *stream) {
   return FB_OK;
 }
 
-// ---- host-pointer drop-ins: upload, run the same kernels, download ----------------------
-#define UP(buf, field, bytes)                                        \
-  fb::DevBuf buf;                                                    \
-  if (H->field) { FB_TRY(buf.upload(H->field, (bytes))); D.field = buf.as<std::remove_pointer<decltype(D.field)>::type>(); }
+// ---- host-pointer drop-ins: ONE staged upload, the same kernels, one staged download (fb::Stager) --------------
+#define UP(buf, field, bytes) st.in((void **)&D.field, H->field, (bytes));
+#define OUT(field, bytes, copy_in) st.out((void **)&D.field, H->field, (bytes), (copy_in));
 
 int fb_match_projection_frame(const fb_proj_frame_args *H) {
   FB_TRY(fb::check_device());
   FB_ARG(H && H->batch >= 0);
   fb_proj_frame_args D = *H;
   const size_t B = H->batch, cs = H->cur_stride, ls = H->last_stride, ncell = (size_t)H->grid.cols * H->grid.rows;
+  fb::Stager st;
   UP(b0, n_cur, B * 4) UP(b1, cur_kps, B * cs * sizeof(fb_keypoint)) UP(b2, cur_desc, B * cs * 32)
   UP(b3, cur_cell_start, B * (ncell + 1) * 4) UP(b4, cur_cell_items, B * cs * 4) UP(b5, cur_blocked, B * cs)
   UP(b6, cur_Tcw, B * 48) UP(b7, n_last, B * 4) UP(b8, last_valid, B * ls) UP(b9, last_obs_pos, B * ls)
   UP(b10, last_xw, B * ls * 12) UP(b11, last_desc, B * ls * 32) UP(b12, last_octave, B * ls * 4)
   UP(b13, last_angle, B * ls * 4)
-  fb::DevBuf o0, o1;
-  FB_TRY(o0.upload(H->match_cur_to_last, B * cs * 4));  // copy-in: entries past n keep the caller's contents
-  FB_TRY(o1.alloc(B * 4));
-  D.match_cur_to_last = o0.as<int32_t>();
-  D.nmatches = o1.as<int32_t>();
+  OUT(match_cur_to_last, B * cs * 4, true)  // copy-in: entries past n keep the caller's contents
+  OUT(nmatches, B * 4, false)
+  FB_ARG(H->match_cur_to_last && H->nmatches);
+  FB_TRY(st.commit(nullptr));
   FB_TRY(fb_match_projection_frame_dev(&D, nullptr));
-  FB_HIP(hipDeviceSynchronize());
-  FB_TRY(o0.download(H->match_cur_to_last, B * cs * 4));
-  return o1.download(H->nmatches, B * 4);
+  return st.fetch(nullptr);
 }
 
 int fb_match_projection_keyframe(const fb_proj_kf_args *H) {
@@ -1137,20 +1134,18 @@ int fb_match_projection_keyframe(const fb_proj_kf_args *H) {
   FB_ARG(H && H->batch >= 0);
   fb_proj_kf_args D = *H;
   const size_t B = H->batch, cs = H->cur_stride, ks = H->kf_stride, ncell = (size_t)H->grid.cols * H->grid.rows;
+  fb::Stager st;
   UP(b0, n_cur, B * 4) UP(b1, cur_kps, B * cs * sizeof(fb_keypoint)) UP(b2, cur_desc, B * cs * 32)
   UP(b3, cur_cell_start, B * (ncell + 1) * 4) UP(b4, cur_cell_items, B * cs * 4) UP(b5, cur_blocked, B * cs)
   UP(b6, cur_Tcw, B * 48) UP(b7, n_kf, B * 4) UP(b8, kf_valid, B * ks) UP(b9, kf_xw, B * ks * 12)
   UP(b10, kf_desc, B * ks * 32) UP(b11, kf_max_dist, B * ks * 4) UP(b12, kf_min_dist, B * ks * 4)
   UP(b13, kf_angle, B * ks * 4)
-  fb::DevBuf o0, o1;
-  FB_TRY(o0.upload(H->match_cur_to_kf, B * cs * 4));
-  FB_TRY(o1.alloc(B * 4));
-  D.match_cur_to_kf = o0.as<int32_t>();
-  D.nmatches = o1.as<int32_t>();
+  OUT(match_cur_to_kf, B * cs * 4, true)
+  OUT(nmatches, B * 4, false)
+  FB_ARG(H->match_cur_to_kf && H->nmatches);
+  FB_TRY(st.commit(nullptr));
   FB_TRY(fb_match_projection_keyframe_dev(&D, nullptr));
-  FB_HIP(hipDeviceSynchronize());
-  FB_TRY(o0.download(H->match_cur_to_kf, B * cs * 4));
-  return o1.download(H->nmatches, B * 4);
+  return st.fetch(nullptr);
 }
 
 int fb_match_projection_points(const fb_proj_points_args *H) {
@@ -1158,15 +1153,14 @@ int fb_match_projection_points(const fb_proj_points_args *H) {
   FB_ARG(H && H->batch >= 0);
   fb_proj_points_args D = *H;
   const size_t B = H->batch, cs = H->cur_stride, ms = H->mp_stride, ncell = (size_t)H->grid.cols * H->grid.rows;
+  fb::Stager st;
   UP(b0, n_cur, B * 4) UP(b1, cur_kps, B * cs * sizeof(fb_keypoint)) UP(b2, cur_desc, B * cs * 32)
   UP(b3, cur_cell_start, B * (ncell + 1) * 4) UP(b4, cur_cell_items, B * cs * 4) UP(b5, cur_blocked, B * cs)
   UP(b6, n_mp, B * 4) UP(b7, mp_track, B * ms) UP(b8, mp_obs_pos, B * ms) UP(b9, mp_proj, B * ms * 8)
   UP(b10, mp_level, B * ms * 4) UP(b11, mp_view_cos, B * ms * 4) UP(b12, mp_desc, B * ms * 32)
-  fb::DevBuf o0, o1;
-  FB_TRY(o0.upload(H->match_cur_to_mp, B * cs * 4));
-  FB_TRY(o1.alloc(B * 4));
-  D.match_cur_to_mp = o0.as<int32_t>();
-  D.nmatches = o1.as<int32_t>();
+  OUT(match_cur_to_mp, B * cs * 4, true)
+  OUT(nmatches, B * 4, false)
+  FB_ARG(H->match_cur_to_mp && H->nmatches);
   fb::DevBuf ws;  // the two-phase matcher (this call is synchronous, so a pooled block is safe as its workspace)
   static const bool onePhase = getenv("FB_M2_ONE_KERNEL") != nullptr;  // measurements / tests of the one-kernel version
   D.workspace = nullptr; D.workspace_bytes = 0;
@@ -1175,10 +1169,9 @@ int fb_match_projection_points(const fb_proj_points_args *H) {
     FB_TRY(ws.alloc(D.workspace_bytes));
     D.workspace = ws.p;
   }
+  FB_TRY(st.commit(nullptr));
   FB_TRY(fb_match_projection_points_dev(&D, nullptr));
-  FB_HIP(hipDeviceSynchronize());
-  FB_TRY(o0.download(H->match_cur_to_mp, B * cs * 4));
-  return o1.download(H->nmatches, B * 4);
+  return st.fetch(nullptr);
 }
 
 int fb_match_bird_mappoints(const fb_bird_mp_args *H) {
@@ -1186,19 +1179,17 @@ int fb_match_bird_mappoints(const fb_bird_mp_args *H) {
   FB_ARG(H && H->batch >= 0);
   fb_bird_mp_args D = *H;
   const size_t B = H->batch, cs = H->cur_stride, rs = H->ref_stride, ncell = (size_t)H->grid.cols * H->grid.rows;
+  fb::Stager st;
   UP(b0, n_cur, B * 4) UP(b1, cur_kps, B * cs * sizeof(fb_keypoint)) UP(b2, cur_desc, B * cs * 32)
   UP(b3, cur_cam_xyz, B * cs * 12) UP(b4, cur_cell_start, B * (ncell + 1) * 4) UP(b5, cur_cell_items, B * cs * 4)
   UP(b6, cur_Tcw, B * 48) UP(b7, n_ref, B * 4) UP(b8, ref_valid, B * rs) UP(b9, ref_xw, B * rs * 12)
   UP(b10, ref_desc, B * rs * 32)
-  fb::DevBuf o0, o1;
-  FB_TRY(o0.upload(H->match_cur_to_ref, B * cs * 4));  // in/out
-  FB_TRY(o1.alloc(B * 4));
-  D.match_cur_to_ref = o0.as<int32_t>();
-  D.ninliers = o1.as<int32_t>();
+  OUT(match_cur_to_ref, B * cs * 4, true)  // in/out
+  OUT(ninliers, B * 4, false)
+  FB_ARG(H->match_cur_to_ref && H->ninliers);
+  FB_TRY(st.commit(nullptr));
   FB_TRY(fb_match_bird_mappoints_dev(&D, nullptr));
-  FB_HIP(hipDeviceSynchronize());
-  FB_TRY(o0.download(H->match_cur_to_ref, B * cs * 4));
-  return o1.download(H->ninliers, B * 4);
+  return st.fetch(nullptr);
 }
 
 int fb_match_birdview(const fb_birdview_args *H) {
@@ -1206,25 +1197,25 @@ int fb_match_birdview(const fb_birdview_args *H) {
   FB_ARG(H && H->batch >= 0);
   fb_birdview_args D = *H;
   const size_t B = H->batch, cs = H->cur_stride, rs = H->ref_stride, ncell = (size_t)H->grid.cols * H->grid.rows;
+  fb::Stager st;
   UP(b0, n_cur, B * 4) UP(b1, cur_kps, B * cs * sizeof(fb_keypoint)) UP(b2, cur_desc, B * cs * 32)
   UP(b3, cur_cell_start, B * (ncell + 1) * 4) UP(b4, cur_cell_items, B * cs * 4) UP(b5, n_ref, B * 4)
   UP(b6, ref_kps, B * rs * sizeof(fb_keypoint)) UP(b7, ref_desc, B * rs * 32)
-  fb::DevBuf o0, o1, o2, o3;
-  FB_TRY(o0.upload(H->match_ref_to_cur, B * rs * 4));
-  FB_TRY(o1.upload(H->match_dist, B * rs * 4));
-  FB_TRY(o2.alloc(B * 4));
-  FB_TRY(o3.alloc(B * 4));
-  D.match_ref_to_cur = o0.as<int32_t>();
-  D.match_dist = o1.as<int32_t>();
-  D.nmatches = o2.as<int32_t>();
-  D.n_dmatches = o3.as<int32_t>();
+  OUT(match_ref_to_cur, B * rs * 4, true)
+  OUT(match_dist, B * rs * 4, true)
+  OUT(nmatches, B * 4, false)
+  OUT(n_dmatches, B * 4, false)
+  FB_ARG(H->match_ref_to_cur && H->match_dist && H->nmatches && H->n_dmatches);
+  FB_TRY(st.commit(nullptr));
   FB_TRY(fb_match_birdview_dev(&D, nullptr));
-  FB_HIP(hipDeviceSynchronize());
-  FB_TRY(o0.download(H->match_ref_to_cur, B * rs * 4));
-  FB_TRY(o1.download(H->match_dist, B * rs * 4));
-  FB_TRY(o2.download(H->nmatches, B * 4));
-  return o3.download(H->n_dmatches, B * 4);
+  return st.fetch(nullptr);
 }
+#undef OUT
+#undef UP
+// (match_kf.inc's wrappers -- loop closing / initialisation, not per-frame -- keep one pooled buffer per argument)
+#define UP(buf, field, bytes)                                        \
+  fb::DevBuf buf;                                                    \
+  if (H->field) { FB_TRY(buf.upload(H->field, (bytes))); D.field = buf.as<std::remove_pointer<decltype(D.field)>::type>(); }
 
 }  // extern "C"
 

@@ -1344,24 +1344,21 @@ int fb_pose_opt(const fb_pose_opt_args *H) {
   }
   fb_pose_opt_args D = *H;
   const size_t B = H->batch, fs = H->front_stride, bs = H->bird_stride;
-#define UPB(buf, field, bytes)                                                                           \
-  fb::DevBuf buf;                                                                                        \
-  if (H->field) { FB_TRY(buf.upload(H->field, (bytes))); D.field = buf.as<std::remove_pointer<decltype(D.field)>::type>(); }
-  UPB(b0, n_front, B * 4) UPB(b1, front_xw, B * fs * 12) UPB(b2, front_obs, B * fs * 8) UPB(b3, front_inv_sigma2, B * fs * 4)
-  UPB(b4, front_valid, B * fs) UPB(b5, n_bird, B * 4) UPB(b6, bird_xw, B * bs * 12) UPB(b7, bird_xc, B * bs * 12)
-  UPB(b8, bird_inv_sigma2, B * bs * 4) UPB(b9, bird_valid, B * bs) UPB(b10, bird_outlier, B * bs) UPB(b11, Tcw, B * 48)
-  UPB(b12, front_outlier, B * fs)
+  // one staged upload / download (fb::Stager): 13 synchronous copies were a quarter of this call at one frame per call
+  fb::Stager st;
+#define UPB(field, bytes) st.in((void **)&D.field, H->field, (bytes));
+  UPB(n_front, B * 4) UPB(front_xw, B * fs * 12) UPB(front_obs, B * fs * 8) UPB(front_inv_sigma2, B * fs * 4)
+  UPB(front_valid, B * fs) UPB(n_bird, B * 4) UPB(bird_xw, B * bs * 12) UPB(bird_xc, B * bs * 12)
+  UPB(bird_inv_sigma2, B * bs * 4) UPB(bird_valid, B * bs)
 #undef UPB
-  fb::DevBuf o1;
-  FB_TRY(o1.alloc(B * 4));
-  D.ninliers = o1.as<int32_t>();
+  st.out((void **)&D.bird_outlier, H->bird_outlier, B * bs, true);   // in/out: mvBirdOutlier
+  st.out((void **)&D.Tcw, H->Tcw, B * 48, true);
+  st.out((void **)&D.front_outlier, H->front_outlier, B * fs, true);
+  st.out((void **)&D.ninliers, H->ninliers, B * 4, false);
   // the family a mode ignores may be absent altogether: the kernel never dereferences it (n = 0 for that family)
+  FB_TRY(st.commit(nullptr));
   FB_TRY(fb_pose_opt_batch_dev(&D, nullptr));
-  FB_HIP(hipDeviceSynchronize());
-  FB_TRY(b11.download(H->Tcw, B * 48));
-  if (H->front_outlier) FB_TRY(b12.download(H->front_outlier, B * fs));
-  if (H->bird_outlier) FB_TRY(b10.download(H->bird_outlier, B * bs));
-  return o1.download(H->ninliers, B * 4);
+  return st.fetch(nullptr);
 }
 
 int fb_pose_gather_front_dev(int batch, int kp_stride, int mp_stride, const int32_t *d_n, const fb_keypoint *d_kps,

@@ -71,7 +71,28 @@ void pool_give(void *p, size_t granted) {
   g_pooled_bytes += granted;
 }
 
+// per-thread page-locked staging block of the host-pointer entry points (Stager)
+namespace {
+struct PinBlock {  // (no destructor: a thread may end after the HIP runtime has been torn down; fb_shutdown releases it)
+  void *p = nullptr;
+  size_t bytes = 0;
+};
+thread_local PinBlock g_pin;
+}  // namespace
+void *pinned_scratch(size_t bytes) {
+  if (g_pin.bytes >= bytes) return g_pin.p;
+  if (g_pin.p) { (void)hipHostFree(g_pin.p); g_pin.p = nullptr; g_pin.bytes = 0; }
+  size_t cls = 1 << 16;
+  while (cls < bytes) cls <<= 1;
+  void *p = nullptr;
+  const hipError_t e = hipHostMalloc(&p, cls, hipHostMallocDefault);
+  if (e != hipSuccess) { set_error("hipHostMalloc(%zu) -> %s", cls, hipGetErrorString(e)); (void)hipGetLastError(); return nullptr; }
+  g_pin.p = p; g_pin.bytes = cls;
+  return p;
+}
+
 void pool_release() {
+  if (g_pin.p) { (void)hipHostFree(g_pin.p); g_pin.p = nullptr; g_pin.bytes = 0; }  // the calling thread's staging block
   std::lock_guard<std::mutex> lk(g_pool_mu);
   int cur = 0;
   const bool have = hipGetDevice(&cur) == hipSuccess;

@@ -28,7 +28,7 @@ def _diff(g, o, k, b, n):
 
 def _cmp_view(g, o, tag):
     B = g["n"].shape[0]
-    assert np.array_equal(g["n"], o["n"]) and np.array_equal(g["n_bird"], o["n_bird"]), tag
+    assert np.array_equal(g["n"], o["n"]) and np.array_equal(g["n_bird"], o["n_bird"]), (tag, g["n"], o["n"], g["n_bird"], o["n_bird"])
     worst = 0.0
     for b in range(B):
         n, nb = int(o["n"][b]), int(o["n_bird"][b])
@@ -81,6 +81,8 @@ def _run(B, K, front_wh, bird_wh, fx, use_lists, seed, granular=False, contour=T
     oc.init_first(mp0, mpb0, Tcw0)
     worst, stats = 0.0, []
     frames = [seq.render(k) for k in range(K)] if pipelined else None
+    if pipelined and not contour:   # (the prefetch below takes its images from this list)
+        frames = [(f_, b_, None) for f_, b_, c_ in frames]
     if pipelined:
         tc.prefetch(*frames[1], mask_d)
     for k in range(1, K):
