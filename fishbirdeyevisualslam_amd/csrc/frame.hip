@@ -385,28 +385,19 @@ int fb_in_frustum(const fb_frustum_args *H) {
   fb_frustum_args D = *H;
   const size_t B = H->batch, ms = H->mp_stride;
   if (B == 0 || ms == 0) return FB_OK;
-  fb::DevBuf b0, b1, b2, b3, b4, b5, b6, b7, o0, o1, o2, o3, o4;
-  FB_TRY(b0.upload(H->Tcw, B * 48)); D.Tcw = b0.as<float>();
-  FB_TRY(b1.upload(H->Ow, B * 12)); D.Ow = b1.as<float>();
-  FB_TRY(b2.upload(H->n_mp, B * 4)); D.n_mp = b2.as<int32_t>();
-  if (H->mp_valid) { FB_TRY(b3.upload(H->mp_valid, B * ms)); D.mp_valid = b3.as<uint8_t>(); }
-  FB_TRY(b4.upload(H->mp_xw, B * ms * 12)); D.mp_xw = b4.as<float>();
-  FB_TRY(b5.upload(H->mp_normal, B * ms * 12)); D.mp_normal = b5.as<float>();
-  FB_TRY(b6.upload(H->mp_max_dist, B * ms * 4)); D.mp_max_dist = b6.as<float>();
-  FB_TRY(b7.upload(H->mp_min_dist, B * ms * 4)); D.mp_min_dist = b7.as<float>();
+  FB_ARG(H->in_view && H->proj && H->level && H->view_cos);
+  fb::Stager st;  // one staged upload / download
+  st.in((void **)&D.Tcw, H->Tcw, B * 48); st.in((void **)&D.Ow, H->Ow, B * 12); st.in((void **)&D.n_mp, H->n_mp, B * 4);
+  st.in((void **)&D.mp_valid, H->mp_valid, B * ms); st.in((void **)&D.mp_xw, H->mp_xw, B * ms * 12);
+  st.in((void **)&D.mp_normal, H->mp_normal, B * ms * 12); st.in((void **)&D.mp_max_dist, H->mp_max_dist, B * ms * 4);
+  st.in((void **)&D.mp_min_dist, H->mp_min_dist, B * ms * 4);
   // outputs are in/out (entries that are not in view keep their previous content)
-  FB_TRY(o0.upload(H->in_view, B * ms)); D.in_view = o0.as<uint8_t>();
-  FB_TRY(o1.upload(H->proj, B * ms * 8)); D.proj = o1.as<float>();
-  if (H->proj_xr) { FB_TRY(o2.upload(H->proj_xr, B * ms * 4)); D.proj_xr = o2.as<float>(); }
-  FB_TRY(o3.upload(H->level, B * ms * 4)); D.level = o3.as<int32_t>();
-  FB_TRY(o4.upload(H->view_cos, B * ms * 4)); D.view_cos = o4.as<float>();
+  st.out((void **)&D.in_view, H->in_view, B * ms, true); st.out((void **)&D.proj, H->proj, B * ms * 8, true);
+  st.out((void **)&D.proj_xr, H->proj_xr, B * ms * 4, true); st.out((void **)&D.level, H->level, B * ms * 4, true);
+  st.out((void **)&D.view_cos, H->view_cos, B * ms * 4, true);
+  FB_TRY(st.commit(nullptr));
   FB_TRY(fb_in_frustum_dev(&D, nullptr));
-  FB_HIP(hipDeviceSynchronize());
-  FB_TRY(o0.download(H->in_view, B * ms));
-  FB_TRY(o1.download(H->proj, B * ms * 8));
-  if (H->proj_xr) FB_TRY(o2.download(H->proj_xr, B * ms * 4));
-  FB_TRY(o3.download(H->level, B * ms * 4));
-  return o4.download(H->view_cos, B * ms * 4);
+  return st.fetch(nullptr);
 }
 
 int fb_bird_filter_matches_dev(const fb_bird_filter_args *A, void *stream) {
@@ -428,21 +419,16 @@ int fb_bird_filter_matches(const fb_bird_filter_args *H) {
   fb_bird_filter_args D = *H;
   const size_t B = H->batch, ms = H->match_stride, s1 = H->kp1_stride, s2 = H->kp2_stride;
   if (B == 0 || ms == 0) return FB_OK;
-  fb::DevBuf b0, b1, b2, b3, b4, b5, b6, b7, o0, o1;
-  FB_TRY(b0.upload(H->n_matches, B * 4)); D.n_matches = b0.as<int32_t>();
-  FB_TRY(b1.upload(H->query_idx, B * ms * 4)); D.query_idx = b1.as<int32_t>();
-  FB_TRY(b2.upload(H->train_idx, B * ms * 4)); D.train_idx = b2.as<int32_t>();
-  FB_TRY(b3.upload(H->cam_xyz1, B * s1 * 12)); D.cam_xyz1 = b3.as<float>();
-  FB_TRY(b4.upload(H->cam_xyz2, B * s2 * 12)); D.cam_xyz2 = b4.as<float>();
-  FB_TRY(b5.upload(H->Tcw1, B * 48)); D.Tcw1 = b5.as<float>();
-  FB_TRY(b6.upload(H->Tcw2, B * 48)); D.Tcw2 = b6.as<float>();
-  FB_TRY(b7.upload(H->occupied2, B * s2)); D.occupied2 = b7.as<uint8_t>();
-  FB_TRY(o0.upload(H->keep, B * ms)); D.keep = o0.as<uint8_t>();
-  FB_TRY(o1.upload(H->pt_world, B * ms * 12)); D.pt_world = o1.as<float>();
+  FB_ARG(H->keep && H->pt_world);
+  fb::Stager st;
+  st.in((void **)&D.n_matches, H->n_matches, B * 4); st.in((void **)&D.query_idx, H->query_idx, B * ms * 4);
+  st.in((void **)&D.train_idx, H->train_idx, B * ms * 4); st.in((void **)&D.cam_xyz1, H->cam_xyz1, B * s1 * 12);
+  st.in((void **)&D.cam_xyz2, H->cam_xyz2, B * s2 * 12); st.in((void **)&D.Tcw1, H->Tcw1, B * 48); st.in((void **)&D.Tcw2, H->Tcw2, B * 48);
+  st.in((void **)&D.occupied2, H->occupied2, B * s2);
+  st.out((void **)&D.keep, H->keep, B * ms, true); st.out((void **)&D.pt_world, H->pt_world, B * ms * 12, true);
+  FB_TRY(st.commit(nullptr));
   FB_TRY(fb_bird_filter_matches_dev(&D, nullptr));
-  FB_HIP(hipDeviceSynchronize());
-  FB_TRY(o0.download(H->keep, B * ms));
-  return o1.download(H->pt_world, B * ms * 12);
+  return st.fetch(nullptr);
 }
 
 int fb_undistort_keypoints_dev(const fb_keypoint *d_kps, const int32_t *d_n, int batch, int kp_stride, const float *K4,

@@ -286,18 +286,14 @@ int lds_ok(size_t bytes, const char *what) {
 }
 
 // host-pointer upload helper for a feature vector
-struct FvUp {
-  fb::DevBuf n, ids, start, items;
-  int up(const fb_feature_vector &h, fb_feature_vector &d, size_t B) {
-    FB_TRY(n.upload(h.n_nodes, B * 4));
-    FB_TRY(ids.upload(h.node_ids, B * (size_t)h.node_stride * 4));
-    FB_TRY(start.upload(h.node_start, B * (size_t)(h.node_stride + 1) * 4));
-    FB_TRY(items.upload(h.items, B * (size_t)h.item_stride * 4));
-    d = h;
-    d.n_nodes = n.as<int32_t>(); d.node_ids = ids.as<uint32_t>(); d.node_start = start.as<int32_t>(); d.items = items.as<int32_t>();
-    return FB_OK;
-  }
-};
+// a DBoW2::FeatureVector's four arrays join the call's staged upload (fb::Stager)
+void stage_fv(fb::Stager &st, const fb_feature_vector &h, fb_feature_vector &d, size_t B) {
+  d = h;
+  st.in((void **)&d.n_nodes, h.n_nodes, B * 4);
+  st.in((void **)&d.node_ids, h.node_ids, B * (size_t)h.node_stride * 4);
+  st.in((void **)&d.node_start, h.node_start, B * (size_t)(h.node_stride + 1) * 4);
+  st.in((void **)&d.items, h.items, B * (size_t)h.item_stride * 4);
+}
 
 }  // namespace
 
@@ -354,72 +350,60 @@ int fb_match_triangulation_dev(const fb_triangulation_args *A, void *stream) {
   return FB_OK;
 }
 
-#define UPF(buf, field, bytes)                                                                             \
-  fb::DevBuf buf;                                                                                          \
-  if (H->field) { FB_TRY(buf.upload(H->field, (bytes))); D.field = buf.as<std::remove_pointer<decltype(D.field)>::type>(); }
+// host-pointer drop-ins: one staged upload, the same kernels, one staged download (fb::Stager, fb_common.h)
+#define UPF(buf, field, bytes) st.in((void **)&D.field, H->field, (bytes));
 
 int fb_match_bow(const fb_bow_args *H) {
   FB_TRY(fb::check_device());
-  FB_ARG(H && H->batch >= 0);
+  FB_ARG(H && H->batch >= 0 && H->match_f_to_kf && H->nmatches);
   fb_bow_args D = *H;
   const size_t B = H->batch, ks = H->kf_stride, fs = H->f_stride;
+  fb::Stager st;
   UPF(b0, n_kf, B * 4) UPF(b1, kf_kps, B * ks * sizeof(fb_keypoint)) UPF(b2, kf_desc, B * ks * 32) UPF(b3, kf_has_mp, B * ks)
   UPF(b4, n_f, B * 4) UPF(b5, f_kps, B * fs * sizeof(fb_keypoint)) UPF(b6, f_desc, B * fs * 32)
-  FvUp u1, u2;
-  FB_TRY(u1.up(H->kf_fv, D.kf_fv, B));
-  FB_TRY(u2.up(H->f_fv, D.f_fv, B));
-  fb::DevBuf o0, o1;
-  FB_TRY(o0.upload(H->match_f_to_kf, B * fs * 4));  // copy-in: entries past n keep the caller's contents
-  FB_TRY(o1.alloc(B * 4));
-  D.match_f_to_kf = o0.as<int32_t>();
-  D.nmatches = o1.as<int32_t>();
+  stage_fv(st, H->kf_fv, D.kf_fv, B);
+  stage_fv(st, H->f_fv, D.f_fv, B);
+  st.out((void **)&D.match_f_to_kf, H->match_f_to_kf, B * fs * 4, true);  // copy-in: entries past n keep the caller's contents
+  st.out((void **)&D.nmatches, H->nmatches, B * 4, false);
+  FB_TRY(st.commit(nullptr));
   FB_TRY(fb_match_bow_dev(&D, nullptr));
-  FB_HIP(hipDeviceSynchronize());
-  FB_TRY(o0.download(H->match_f_to_kf, B * fs * 4));
-  return o1.download(H->nmatches, B * 4);
+  return st.fetch(nullptr);
 }
 
 int fb_match_bow_kf(const fb_bow_kf_args *H) {
   FB_TRY(fb::check_device());
-  FB_ARG(H && H->batch >= 0);
+  FB_ARG(H && H->batch >= 0 && H->matches12 && H->nmatches);
   fb_bow_kf_args D = *H;
   const size_t B = H->batch, s1 = H->kf1_stride, s2 = H->kf2_stride;
+  fb::Stager st;
   UPF(b0, n1, B * 4) UPF(b1, kps1, B * s1 * sizeof(fb_keypoint)) UPF(b2, desc1, B * s1 * 32) UPF(b3, has_mp1, B * s1)
   UPF(b4, n2, B * 4) UPF(b5, kps2, B * s2 * sizeof(fb_keypoint)) UPF(b6, desc2, B * s2 * 32) UPF(b7, has_mp2, B * s2)
-  FvUp u1, u2;
-  FB_TRY(u1.up(H->fv1, D.fv1, B));
-  FB_TRY(u2.up(H->fv2, D.fv2, B));
-  fb::DevBuf o0, o1;
-  FB_TRY(o0.upload(H->matches12, B * s1 * 4));
-  FB_TRY(o1.alloc(B * 4));
-  D.matches12 = o0.as<int32_t>();
-  D.nmatches = o1.as<int32_t>();
+  stage_fv(st, H->fv1, D.fv1, B);
+  stage_fv(st, H->fv2, D.fv2, B);
+  st.out((void **)&D.matches12, H->matches12, B * s1 * 4, true);
+  st.out((void **)&D.nmatches, H->nmatches, B * 4, false);
+  FB_TRY(st.commit(nullptr));
   FB_TRY(fb_match_bow_kf_dev(&D, nullptr));
-  FB_HIP(hipDeviceSynchronize());
-  FB_TRY(o0.download(H->matches12, B * s1 * 4));
-  return o1.download(H->nmatches, B * 4);
+  return st.fetch(nullptr);
 }
 
 int fb_match_triangulation(const fb_triangulation_args *H) {
   FB_TRY(fb::check_device());
-  FB_ARG(H && H->batch >= 0);
+  FB_ARG(H && H->batch >= 0 && H->matches12 && H->nmatches);
   fb_triangulation_args D = *H;
   const size_t B = H->batch, s1 = H->kf1_stride, s2 = H->kf2_stride;
+  fb::Stager st;
   UPF(b0, n1, B * 4) UPF(b1, kps1, B * s1 * sizeof(fb_keypoint)) UPF(b2, desc1, B * s1 * 32) UPF(b3, has_mp1, B * s1)
   UPF(b4, n2, B * 4) UPF(b5, kps2, B * s2 * sizeof(fb_keypoint)) UPF(b6, desc2, B * s2 * 32) UPF(b7, has_mp2, B * s2)
   UPF(b8, F12, B * 36) UPF(b9, Cw1, B * 12) UPF(b10, R2w, B * 36) UPF(b11, t2w, B * 12)
-  FvUp u1, u2;
-  FB_TRY(u1.up(H->fv1, D.fv1, B));
-  FB_TRY(u2.up(H->fv2, D.fv2, B));
-  fb::DevBuf o0, o1;
-  FB_TRY(o0.upload(H->matches12, B * s1 * 4));
-  FB_TRY(o1.alloc(B * 4));
-  D.matches12 = o0.as<int32_t>();
-  D.nmatches = o1.as<int32_t>();
+  stage_fv(st, H->fv1, D.fv1, B);
+  stage_fv(st, H->fv2, D.fv2, B);
+  st.out((void **)&D.matches12, H->matches12, B * s1 * 4, true);
+  st.out((void **)&D.nmatches, H->nmatches, B * 4, false);
+  FB_TRY(st.commit(nullptr));
   FB_TRY(fb_match_triangulation_dev(&D, nullptr));
-  FB_HIP(hipDeviceSynchronize());
-  FB_TRY(o0.download(H->matches12, B * s1 * 4));
-  return o1.download(H->nmatches, B * 4);
+  return st.fetch(nullptr);
 }
+#undef UPF
 
 }  // extern "C"
