@@ -1806,19 +1806,32 @@ int fb_orb_extract(fb_orb *o, const uint8_t *image, int width, int height, int s
   if (!image || width <= 0 || height <= 0) return FB_OK;  // _image.empty(): silent return, ORBextractor.cc:1046
   FB_ARG(keypoints && descriptors && stride >= width);
   const int cap = capacity_of(o->p);
-  fb::DevBuf dk, dd, dn;
-  FB_TRY(o->ownedImg.upload(image, (size_t)stride * height));
-  FB_TRY(dk.alloc((size_t)cap * sizeof(fb_keypoint)));
-  FB_TRY(dd.alloc((size_t)cap * 32));
-  FB_TRY(dn.alloc(4));
-  FB_TRY(fb_orb_extract_batch_dev(o, o->ownedImg.as<uint8_t>(), 1, width, height, stride, (size_t)stride * height,
-                                  dk.as<fb_keypoint>(), dd.as<uint8_t>(), dn.as<int32_t>(), nullptr));
-  FB_HIP(hipDeviceSynchronize());
-  FB_TRY(dn.download(n_out, 4));
+  // one page-locked block per host thread carries the image in and [n | key points | descriptors | level counts] out: one
+  // asynchronous copy each way and ONE synchronisation (five synchronous copies before)
+  const size_t imgBytes = (size_t)stride * height, kpBytes = (size_t)cap * sizeof(fb_keypoint), dBytes = (size_t)cap * 32;
+  const size_t oN = 0, oK = 256, oD = oK + ((kpBytes + 255) & ~(size_t)255), oC = oD + ((dBytes + 255) & ~(size_t)255), outBytes = oC + 256;
+  uint8_t *pin = static_cast<uint8_t *>(fb::pinned_scratch(imgBytes + outBytes));
+  if (!pin) return FB_ERR_HIP;
+  fb::DevBuf dout;
+  FB_TRY(dout.alloc(outBytes));
+  if (o->ownedImg.bytes < imgBytes || !o->ownedImg.p) FB_TRY(o->ownedImg.alloc(imgBytes));
+  memcpy(pin, image, imgBytes);
+  FB_HIP(hipMemcpyAsync(o->ownedImg.p, pin, imgBytes, hipMemcpyHostToDevice, nullptr));
+  uint8_t *dbase = dout.as<uint8_t>();
+  const int keepStride = o->kpStride;
+  if (keepStride) FB_TRY(fb_orb_set_output_stride(o, 0));  // this call's arrays hold exactly `cap` entries
+  const int rc = fb_orb_extract_batch_dev(o, o->ownedImg.as<uint8_t>(), 1, width, height, stride, imgBytes, reinterpret_cast<fb_keypoint *>(dbase + oK),
+                                          dbase + oD, reinterpret_cast<int32_t *>(dbase + oN), nullptr);
+  if (keepStride) (void)fb_orb_set_output_stride(o, keepStride);
+  FB_TRY(rc);
+  uint8_t *pout = pin + imgBytes;
+  FB_HIP(hipMemcpyAsync(pout, dbase, oC, hipMemcpyDeviceToHost, nullptr));
+  FB_HIP(hipMemcpyAsync(pout + oC, o->counts.as<int>() + (size_t)o->batchCap * o->p.nlevels, (size_t)o->p.nlevels * 4, hipMemcpyDeviceToHost, nullptr));
+  FB_HIP(hipStreamSynchronize(nullptr));
+  memcpy(n_out, pout + oN, 4);
   {  // n_out is clamped to the capacity on the device; the per-level counts tell whether anything was cut off (the
      // quadtree can end a level with up to 4 x its number of root nodes: very wide strips with a tiny feature budget)
-    int lc[FB_MAX_LEVELS] = {0};
-    FB_HIP(hipMemcpy(lc, o->counts.as<int>() + (size_t)o->batchCap * o->p.nlevels, (size_t)o->p.nlevels * 4, hipMemcpyDeviceToHost));
+    const int *lc = reinterpret_cast<const int *>(pout + oC);
     int total = 0;
     for (int l = 0; l < o->p.nlevels; l++) total += lc[l];
     if (total > cap) {
@@ -1826,8 +1839,9 @@ int fb_orb_extract(fb_orb *o, const uint8_t *image, int width, int height, int s
       return FB_ERR_CAPACITY;
     }
   }
-  FB_TRY(dk.download(keypoints, (size_t)*n_out * sizeof(fb_keypoint)));
-  return dd.download(descriptors, (size_t)*n_out * 32);
+  memcpy(keypoints, pout + oK, (size_t)*n_out * sizeof(fb_keypoint));
+  memcpy(descriptors, pout + oD, (size_t)*n_out * 32);
+  return FB_OK;
 }
 
 int fb_orb_debug_timers(fb_orb *o, uint64_t *dst16) {
