@@ -308,3 +308,16 @@ def test_triangulation_matches_feed_the_ba_on_the_device():
     assert _rel(dv["kf_Tcw"].cpu().numpy(), out_o["kf_Tcw"]) <= REL_TOL
     assert _rel(dv["mp_xw"].cpu().numpy(), out_o["mp_xw"]) <= REL_TOL
     np.testing.assert_array_equal(dv["obs_outlier"].cpu().numpy(), out_o["obs_outlier"])
+
+
+def test_shutdown_releases_and_the_library_keeps_working():
+    """fb_shutdown frees the scratch pool, the calling thread's staging block and its BA stream / event / pinned control block;
+    the next calls allocate again."""
+    import fishbirdeyevisualslam_amd as fb
+    p = synth.make_ba_problem(4300, n_kf=6, n_mp=300, n_mpb=60)
+    out_o, out_h, _, _ = _run(p, with_odom=1)
+    assert fb.lib().fb_shutdown() == 0
+    assert fb.lib().fb_shutdown() == 0
+    out_o2, out_h2, _, _ = _run(p, with_odom=1)
+    np.testing.assert_array_equal(out_h2["kf_Tcw"], out_h["kf_Tcw"])
+    np.testing.assert_array_equal(out_h2["obs_outlier"], out_h["obs_outlier"])

@@ -82,6 +82,7 @@ def test_no_cpu_fallback_without_device():
     n = C.c_int32(0)
     assert lib.fb_orb_extract(h, C.c_void_p(img.ctypes.data), 64, 64, 64, None, None, C.byref(n)) == cabi.FB_ERR_NODEVICE
     lib.fb_orb_destroy(h)
+    assert lib.fb_shutdown() == 0   # nothing to release, still fine
 
 
 def test_product_never_touches_the_oracle():
