@@ -260,7 +260,7 @@ class FrameView(C.Structure):
 
 
 FB_CNT = dict(BIRD_KF_MATCHES=0, PROJ_MATCHES=1, POSE1_INLIERS=2, MATCHES=3, MATCHES_MAP=4, BIRDVIEW_MATCHES=5, BIRD_INLIERS=6,
-              BIRD_NEW=7, TO_MATCH=8, LOCAL_MATCHES=9, POSE2_INLIERS=10, MATCHES_INLIERS=11)
+              BIRD_NEW=7, TO_MATCH=8, LOCAL_MATCHES=9, POSE2_INLIERS=10, MATCHES_INLIERS=11, BOW_MATCHES=12, BIRD_POINTS=13)
 FB_CNT_COUNT = 16
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), _i32, _i32)
@@ -305,6 +305,7 @@ EXPORTS = [
     "fb_frame_predict_pose_dev", "fb_frame_clear_map_points_dev", "fb_frame_set_map_points_dev",
     "fb_frame_bird_mappoint_match_dev", "fb_frame_search_by_projection_dev", "fb_frame_pose_optimization_dev",
     "fb_frame_discard_outliers_dev", "fb_frame_match_bird_points_dev", "fb_frame_search_local_points_dev",
-    "fb_frame_finish_dev", "fb_frame_track_dev", "fb_frame_view_dev", "fb_frame_download", "fb_frame_counts",
+    "fb_frame_finish_dev", "fb_frame_track_dev", "fb_frame_track_motion_model_dev", "fb_frame_track_local_map_dev",
+    "fb_frame_copy_dev", "fb_frame_compute_bow_dev", "fb_frame_bow_view_dev", "fb_frame_search_by_bow_dev", "fb_frame_track_reference_dev", "fb_frame_view_dev", "fb_frame_download", "fb_frame_counts",
     "fb_local_ba", "fb_local_ba_dev", "fb_local_ba_sharded", "fb_local_ba_sharded_rccl", "fb_rccl_get_unique_id", "fb_rccl_comm_init", "fb_rccl_comm_destroy", "fb_rccl_comm_info", "fb_global_ba",
 ]

@@ -87,6 +87,19 @@ __global__ __launch_bounds__(TT) void k_m3_prepare(FrameDev cur, FrameDev last, 
   S.valid[o] = v;
 }
 
+// SearchByBoW(pKF, F, ...): vpMapPointsKF[i] && !isBad() per key-frame slot (ORBmatcher.cc:196-203)
+__global__ __launch_bounds__(TT) void k_bow_prepare(FrameDev kf, MapDev map, uint8_t *has_mp) {
+  const int b = blockIdx.y, i = blockIdx.x * TT + threadIdx.x;
+  if (i >= kf.cap) return;
+  const size_t o = (size_t)b * kf.cap + i;
+  uint8_t v = 0;
+  if (i < kf.n[b]) {
+    const int id = kf.mp[o];
+    v = id >= 0 && !map.bad[(size_t)b * map.stride + id];
+  }
+  has_mp[o] = v;
+}
+
 // dense view of a vlocalMPB list for BirdMapPointMatch (ref_valid / ref_xw / ref_desc by list position)
 __global__ __launch_bounds__(TT) void k_m9_prepare(BirdMapDev mpb, const int32_t *local, const int32_t *n_local, int lcap,
                                                    uint8_t *valid, float *xw, uint8_t *desc, int32_t *n_eff, int32_t *match, int cap) {
@@ -122,14 +135,17 @@ struct SigmaTab { float inv_sigma2[FB_MAX_LEVELS]; };
 //                        mvpMapPointsBird[i] = vlocalMPB[match_bird[i]]                (ORBmatcher.cc:1891)
 //   commit 2 (after M2): mvpMapPoints[i] = mvpLocalMapPoints[match[i]] where matched  (ORBmatcher.cc:124)
 struct Commit {  // the matcher result a frame has not folded into mvpMapPoints / mvpMapPointsBird yet
-  int kind;                 // 0 none, 1 after M3 (+ M9), 2 after M2
+  int kind;                 // 0 none, 1 after M3 (+ M9), 2 after M2, 3 after SearchByBoW (replace every slot, gated)
   const int32_t *match;     // kind 1: slot of the last frame; kind 2: position in mvpLocalMapPoints
   const int32_t *src_mp;    // kind 1: LastFrame.mvpMapPoints; kind 2: the local list (NULL = the table itself)
   int src_stride;
   const int32_t *match_bird;  // kind 1: position in vlocalMPB, or NULL
   const int32_t *local_mpb;   // the vlocalMPB list (NULL = the table itself)
   int lcap_mpb;
+  const int32_t *gate;        // kind 3: the matcher's count row; a sequence below gate_min "returned false" (Tracking.cc:1212):
+  int gate_min;               //         no commit, no edges (the optimiser then leaves pose and flags alone)
 };
+__device__ __forceinline__ bool commit_gate_open(const Commit &C, int b) { return !C.gate || C.gate[b] >= C.gate_min; }
 __device__ __forceinline__ void commit_slot(const FrameDev &F, const Commit &C, int b, int i, size_t o, int &id, int &idb) {
   id = -1; idb = -1;
   if (i < F.n[b]) {
@@ -141,7 +157,13 @@ __device__ __forceinline__ void commit_slot(const FrameDev &F, const Commit &C, 
     } else if (C.kind == 2) {
       const int m = C.match[o];
       if (m >= 0) { id = C.src_mp ? C.src_mp[(size_t)b * C.src_stride + m] : m; F.mp[o] = id; }
+    } else if (C.kind == 3 && commit_gate_open(C, b)) {  // mCurrentFrame.mvpMapPoints = vpMapPointMatches (Tracking.cc:1215)
+      const int m = C.match[o];
+      id = m >= 0 ? C.src_mp[(size_t)b * C.src_stride + m] : -1;
+      F.mp[o] = id;
     }
+  } else if (C.kind == 3 && commit_gate_open(C, b)) {
+    F.mp[o] = -1;
   }
   if (i < F.nb[b]) {
     idb = F.mpb[o];
@@ -165,6 +187,7 @@ __global__ __launch_bounds__(TT) void k_edges(FrameDev F, MapDev map, BirdMapDev
   const size_t o = (size_t)b * F.cap + i;
   int id, idb;
   commit_slot(F, C, b, i, o, id, idb);
+  if (!commit_gate_open(C, b)) { id = -1; idb = -1; }
   if (id >= 0) {
     const fb_keypoint kp = F.kps_un[o];
     const float *X = map.xw + ((size_t)b * map.stride + id) * 3;
@@ -215,9 +238,12 @@ __device__ __forceinline__ int block_excl_scan(int v, int *s_w, int *total) {  /
 }
 
 // "Discard outliers" of TrackWithMotionModel (Tracking.cc:1358-1376): one workgroup per sequence
-__global__ __launch_bounds__(WG) void k_discard(FrameDev F, MapDev map, int32_t *counts, int B) {
+// and of TrackReferenceKeyFrame (:1222-1241); src_slot = the matcher count nmatches starts from; gate_min > 0: a sequence
+// whose src_slot count is below it returned before the loop (:1212-1213)
+__global__ __launch_bounds__(WG) void k_discard(FrameDev F, MapDev map, int32_t *counts, int B, int src_slot, int gate_min) {
   __shared__ int s_w[WG / 64];
   const int b = blockIdx.x, n = min(F.n[b], F.cap);
+  if (gate_min > 0 && counts[src_slot * B + b] < gate_min) return;
   int dropped = 0, inmap = 0;
   for (int i = threadIdx.x; i < n; i += WG) {
     const size_t o = (size_t)b * F.cap + i;
@@ -229,7 +255,7 @@ __global__ __launch_bounds__(WG) void k_discard(FrameDev F, MapDev map, int32_t 
   dropped = block_sum(dropped, s_w);
   inmap = block_sum(inmap, s_w);
   if (threadIdx.x == 0) {
-    counts[FB_CNT_MATCHES * B + b] = counts[FB_CNT_PROJ_MATCHES * B + b] - dropped;
+    counts[FB_CNT_MATCHES * B + b] = counts[src_slot * B + b] - dropped;
     counts[FB_CNT_MATCHES_MAP * B + b] = inmap;
   }
 }
@@ -239,14 +265,28 @@ __global__ __launch_bounds__(WG) void k_discard(FrameDev F, MapDev map, int32_t 
 // order: skip when the train slot holds a point (on entry or through an earlier PASSING match), test, on a pass take the
 // slot.  => kept(i1) = passes(i1) && i1 is the smallest passing query of its train slot && the slot was free on entry.
 // New MapPointBirds get ids in list order (mnId = nNextId++, here: the next table row).
+// only_below > 0 (TrackReferenceKeyFrame, Tracking.cc:1196-1200): numPt = GetBirdMapPointsNum() (Frame.cc:1081-1092) is
+// counted first and a sequence holding that many bird points or more skips the step (its BirdviewMatch count reads 0).
 __global__ __launch_bounds__(WG) void k_bird_commit(FrameDev cur, FrameDev ref, BirdMapDev mpb, const int32_t *m12,
-                                                    float window, int32_t *counts, int B) {
+                                                    float window, int32_t *counts, int B, int only_below) {
   extern __shared__ int s_first[];  // [cap] smallest passing query per train slot
   __shared__ int s_w[WG / 64];
   __shared__ float s_Twc1[12], s_T2[12];
   const int b = blockIdx.x, tid = threadIdx.x, cap = cur.cap;
   const size_t fo = (size_t)b * cap;
   const int nref = min(ref.nb[b], cap);
+  if (only_below > 0) {
+    int have = 0;
+    const int ncur = min(cur.nb[b], cap);
+    for (int i = tid; i < ncur; i += WG) have += cur.mpb[fo + i] >= 0;
+    have = block_sum(have, s_w);
+    if (tid == 0) counts[FB_CNT_BIRD_POINTS * B + b] = have;
+    if (have >= only_below) {
+      if (tid == 0) counts[FB_CNT_BIRDVIEW_MATCHES * B + b] = 0;
+      return;
+    }
+    __syncthreads();
+  }
   if (tid == 0) {
     fb::inv_T(ref.Tcw + (size_t)b * 12, s_Twc1);
     for (int i = 0; i < 12; i++) s_T2[i] = cur.Tcw[(size_t)b * 12 + i];
@@ -409,6 +449,9 @@ struct fb_frame {
   fb::DevBuf e_fxw, e_fobs, e_finf, e_fvalid, e_bxw, e_bxc, e_binf, e_bvalid;
   fb::DevBuf m8_m12, m8_dist, m8_n, m8_nd;
   fb::DevBuf l_seen, l_blocked, l_inview, l_obs, l_proj, l_level, l_cos, l_desc, l_n, m_local, m2_ws;
+  // mBowVec / mFeatVec (Frame.h:128-129), allocated by the first fb_frame_compute_bow_dev
+  fb::DevBuf bow_nw, bow_ids, bow_vals, fv_nn, fv_ids, fv_start, fv_items;
+  bool bowDone = false;   // !mBowVec.empty() (in the order the calls were enqueued)
   // images from host callers
   fb::DevBuf img_f, img_b, img_c, img_m;
   uint8_t *pin = nullptr;
@@ -578,6 +621,7 @@ int fb_frame_extract_dev(fb_frame *f, fb_orb *of, fb_orb *ob, const uint8_t *d_f
   const bool fork = !(fb::g_prof_on && fb::g_prof_only < 0);
   hipStream_t s = fb::as_stream(stream), sb = fork ? f->sBird : s;
   const int B = f->B, cap = f->cap;
+  f->bowDone = false;                         // a new Frame: mBowVec empty
   FB_TRY(fb_orb_set_output_stride(of, cap));  // both extractors write into the frame's arrays (one stride)
   FB_TRY(fb_orb_set_output_stride(ob, cap));
   // bird chain on the handle's stream, beside the front chain
@@ -772,6 +816,100 @@ int local_impl(fb_frame *f, const fb_map_points *map, const int32_t *d_local, co
   return fb_match_projection_points_dev(&A, s);
 }
 
+int bird_points_impl(fb_frame *cur, fb_frame *ref, fb_map_points_bird *mpb, int window_size, float filter_size,
+                     const fb_matcher_params *matcher, int only_below, hipStream_t s) {
+  fb_birdview_args A;
+  memset(&A, 0, sizeof(A));
+  A.batch = cur->B; A.cur_stride = cur->cap; A.ref_stride = cur->cap;
+  A.n_cur = cur->nb.as<int32_t>(); A.cur_kps = cur->bkps.as<fb_keypoint>(); A.cur_desc = cur->bdesc.as<uint8_t>();
+  A.cur_cell_start = cur->bcs.as<int32_t>(); A.cur_cell_items = cur->bci.as<int32_t>();
+  A.n_ref = ref->nb.as<int32_t>(); A.ref_kps = ref->bkps.as<fb_keypoint>(); A.ref_desc = ref->bdesc.as<uint8_t>();
+  A.grid = cur->gB; A.window_size = window_size; A.matcher = *matcher;
+  A.match_ref_to_cur = cur->m8_m12.as<int32_t>(); A.match_dist = cur->m8_dist.as<int32_t>();
+  A.nmatches = cur->cnt(FB_CNT_BIRDVIEW_MATCHES); A.n_dmatches = cur->m8_nd.as<int32_t>();
+  FB_TRY(fb_match_birdview_dev(&A, s));
+  const size_t lds = (size_t)cur->cap * 4;
+  if (lds > 150 * 1024) { fb::set_error("fb_frame_match_bird_points: %d key points per frame beyond the LDS slot table", cur->cap); return FB_ERR_CAPACITY; }
+  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bird_commit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  fb::ProfScope prof_(fb::P_TRACK_GLUE, s);
+  k_bird_commit<<<cur->B, WG, lds, s>>>(cur->dev(), ref->dev(), bird_dev(mpb), cur->m8_m12.as<int32_t>(), filter_size,
+                                       cur->counts.as<int32_t>(), cur->B, only_below);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+
+int discard_impl(fb_frame *f, const fb_map_points *map, int src_slot, int gate_min, hipStream_t s) {
+  fb::ProfScope prof_(fb::P_TRACK_GLUE, s);
+  k_discard<<<f->B, WG, 0, s>>>(f->dev(), map_dev(map), f->counts.as<int32_t>(), f->B, src_slot, gate_min);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+fb_feature_vector frame_fv(const fb_frame *f) {
+  fb_feature_vector v;
+  v.node_stride = f->cap; v.item_stride = f->cap;
+  v.n_nodes = f->fv_nn.as<int32_t>(); v.node_ids = f->fv_ids.as<uint32_t>(); v.node_start = f->fv_start.as<int32_t>(); v.items = f->fv_items.as<int32_t>();
+  return v;
+}
+
+// SearchByBoW(pKF, F, vpMapPointMatches) (ORBmatcher.cc:160-289): result in cur->m_front, count in FB_CNT_BOW_MATCHES
+int bow_impl(fb_frame *cur, const fb_frame *kf, const fb_map_points *map, const fb_matcher_params *matcher, hipStream_t s) {
+  { fb::ProfScope prof_(fb::P_TRACK_GLUE, s);
+    k_bow_prepare<<<slot_grid(cur), TT, 0, s>>>(kf->dev(), map_dev(map), cur->m3_valid.as<uint8_t>()); }
+  FB_HIP(hipGetLastError());
+  fb_bow_args A;
+  memset(&A, 0, sizeof(A));
+  A.batch = cur->B; A.kf_stride = cur->cap; A.f_stride = cur->cap;
+  A.n_kf = kf->n.as<int32_t>(); A.kf_kps = kf->kps_un.as<fb_keypoint>(); A.kf_desc = kf->desc.as<uint8_t>();
+  A.kf_has_mp = cur->m3_valid.as<uint8_t>(); A.kf_fv = frame_fv(kf);
+  A.n_f = cur->n.as<int32_t>(); A.f_kps = cur->kps.as<fb_keypoint>(); A.f_desc = cur->desc.as<uint8_t>(); A.f_fv = frame_fv(cur);  // F.mvKeys, :258
+  A.matcher = *matcher;
+  A.match_f_to_kf = cur->m_front.as<int32_t>(); A.nmatches = cur->cnt(FB_CNT_BOW_MATCHES);
+  return fb_match_bow_dev(&A, s);
+}
+
+Commit commit_bow(const fb_frame *cur, const fb_frame *kf, int min_matches) {
+  Commit C;
+  memset(&C, 0, sizeof(C));
+  C.kind = 3; C.match = cur->m_front.as<int32_t>(); C.src_mp = kf->mp.as<int32_t>(); C.src_stride = cur->cap;
+  C.gate = min_matches > 0 ? cur->cnt(FB_CNT_BOW_MATCHES) : nullptr; C.gate_min = min_matches;
+  return C;
+}
+
+bool track_args_ok(const fb_frame *cur, const fb_track_args *T) {
+  return T && map_ok(cur, &T->map) && bird_ok(&T->mpb) && (!T->d_local_mp || T->d_n_local_mp) && (!T->d_local_mpb || T->d_n_local_mpb) &&
+         (T->d_local_mp || T->map.stride <= cur->P.local_mp_cap) && (T->d_local_mpb || T->mpb.stride <= cur->P.local_mpb_cap);
+}
+
+const fb_matcher_params M09 = {0.9f, 1};  // ORBmatcher matcher(0.9,true), Tracking.cc:1325,2001,2726
+const fb_matcher_params M08 = {0.8f, 1};  // ORBmatcher matcher(0.8), Tracking.cc:1988
+const fb_matcher_params M07 = {0.7f, 1};  // ORBmatcher matcher(0.7,true), Tracking.cc:1207
+
+// TrackWithMotionModel (Tracking.cc:1312-1385)
+int motion_model_impl(fb_frame *cur, fb_frame *last, const fb_track_args *T, hipStream_t s) {
+  fb_map_points_bird mpb = T->mpb;
+  FB_TRY(fb_frame_predict_pose_dev(cur, last, T->d_delta, s));                                         // :1314-1320
+  FB_TRY(m9_impl(cur, &mpb, T->d_local_mpb, T->d_n_local_mpb, 10, 0.05f, &M09, s));                    // :1322-1323 -> :1999-2012
+  FB_TRY(m3_impl(cur, last, &T->map, 15.0f, &M09, s));                                                 // :1339
+  Commit C1 = commit_m9(cur, T->d_local_mpb);
+  C1.match = cur->m_front.as<int32_t>(); C1.src_mp = last->mp.as<int32_t>(); C1.src_stride = cur->cap;
+  FB_TRY(edges_and_pose(cur, &T->map, &mpb, FB_POSE_FRONT_BIRD, T->wB, T->wF, 0, C1, s));              // :1353
+  return discard_impl(cur, &T->map, FB_CNT_PROJ_MATCHES, 0, s);                                        // :1358-1376
+}
+
+// TrackLocalMap (Tracking.cc:1387-1441) + the end of Track (:1411-1424, 690-701, 721-725)
+int local_map_impl(fb_frame *cur, fb_frame *ref, const fb_track_args *T, hipStream_t s) {
+  fb_map_points_bird mpb = T->mpb;
+  FB_TRY(bird_points_impl(cur, ref, &mpb, 10, 0.05f, &M09, 0, s));                                     // :1392 -> :2724-2733
+  FB_TRY(local_impl(cur, &T->map, T->d_local_mp, T->d_n_local_mp, 1.0f, &M08, s));                     // :1396 -> :1947-1997
+  Commit C2;
+  memset(&C2, 0, sizeof(C2));
+  C2.kind = 2; C2.match = cur->m_local.as<int32_t>(); C2.src_mp = T->d_local_mp; C2.src_stride = cur->P.local_mp_cap;
+  FB_TRY(edges_and_pose(cur, &T->map, &mpb, FB_POSE_FRONT_BIRD, T->wB, T->wF, 1, C2, s));              // :1400
+  return fb_frame_finish_dev(cur, &T->map, s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -810,35 +948,14 @@ int fb_frame_pose_optimization_dev(fb_frame *f, const fb_map_points *map, const 
 int fb_frame_discard_outliers_dev(fb_frame *f, const fb_map_points *map, void *stream) {
   FB_TRY(fb::check_device());
   FB_ARG(f && map_ok(f, map));
-  fb::ProfScope prof_(fb::P_TRACK_GLUE, fb::as_stream(stream));
-  k_discard<<<f->B, WG, 0, fb::as_stream(stream)>>>(f->dev(), map_dev(map), f->counts.as<int32_t>(), f->B);
-  FB_HIP(hipGetLastError());
-  return FB_OK;
+  return discard_impl(f, map, FB_CNT_PROJ_MATCHES, 0, fb::as_stream(stream));
 }
 
 int fb_frame_match_bird_points_dev(fb_frame *cur, fb_frame *ref, fb_map_points_bird *mpb, int window_size, float filter_size,
                                    const fb_matcher_params *matcher, void *stream) {
   FB_TRY(fb::check_device());
   FB_ARG(cur && ref && cur != ref && cur->B == ref->B && cur->cap == ref->cap && bird_ok(mpb) && matcher);
-  hipStream_t s = fb::as_stream(stream);
-  fb_birdview_args A;
-  memset(&A, 0, sizeof(A));
-  A.batch = cur->B; A.cur_stride = cur->cap; A.ref_stride = cur->cap;
-  A.n_cur = cur->nb.as<int32_t>(); A.cur_kps = cur->bkps.as<fb_keypoint>(); A.cur_desc = cur->bdesc.as<uint8_t>();
-  A.cur_cell_start = cur->bcs.as<int32_t>(); A.cur_cell_items = cur->bci.as<int32_t>();
-  A.n_ref = ref->nb.as<int32_t>(); A.ref_kps = ref->bkps.as<fb_keypoint>(); A.ref_desc = ref->bdesc.as<uint8_t>();
-  A.grid = cur->gB; A.window_size = window_size; A.matcher = *matcher;
-  A.match_ref_to_cur = cur->m8_m12.as<int32_t>(); A.match_dist = cur->m8_dist.as<int32_t>();
-  A.nmatches = cur->cnt(FB_CNT_BIRDVIEW_MATCHES); A.n_dmatches = cur->m8_nd.as<int32_t>();
-  FB_TRY(fb_match_birdview_dev(&A, s));
-  const size_t lds = (size_t)cur->cap * 4;
-  if (lds > 150 * 1024) { fb::set_error("fb_frame_match_bird_points: %d key points per frame beyond the LDS slot table", cur->cap); return FB_ERR_CAPACITY; }
-  FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bird_commit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  fb::ProfScope prof_(fb::P_TRACK_GLUE, s);
-  k_bird_commit<<<cur->B, WG, lds, s>>>(cur->dev(), ref->dev(), bird_dev(mpb), cur->m8_m12.as<int32_t>(), filter_size,
-                                       cur->counts.as<int32_t>(), cur->B);
-  FB_HIP(hipGetLastError());
-  return FB_OK;
+  return bird_points_impl(cur, ref, mpb, window_size, filter_size, matcher, 0, fb::as_stream(stream));
 }
 
 int fb_frame_search_local_points_dev(fb_frame *f, const fb_map_points *map, const int32_t *d_local, const int32_t *d_n_local,
@@ -863,34 +980,102 @@ int fb_frame_finish_dev(fb_frame *f, const fb_map_points *map, void *stream) {
   return FB_OK;
 }
 
+int fb_frame_track_motion_model_dev(fb_frame *cur, fb_frame *last, const fb_track_args *T, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(cur && last && cur != last && cur->B == last->B && cur->cap == last->cap && track_args_ok(cur, T) && T->d_delta);
+  return motion_model_impl(cur, last, T, fb::as_stream(stream));
+}
+
+int fb_frame_track_local_map_dev(fb_frame *cur, fb_frame *ref, const fb_track_args *T, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(cur && ref && cur != ref && cur->B == ref->B && cur->cap == ref->cap && track_args_ok(cur, T));
+  return local_map_impl(cur, ref, T, fb::as_stream(stream));
+}
+
 int fb_frame_track_dev(fb_frame *cur, fb_frame *last, const fb_track_args *T, void *stream) {
   FB_TRY(fb::check_device());
-  FB_ARG(cur && last && T && cur != last && cur->B == last->B && cur->cap == last->cap);
-  FB_ARG(map_ok(cur, &T->map) && bird_ok(&T->mpb) && T->d_delta);
-  FB_ARG((!T->d_local_mp || T->d_n_local_mp) && (!T->d_local_mpb || T->d_n_local_mpb));
-  FB_ARG(T->d_local_mp || T->map.stride <= cur->P.local_mp_cap);
-  FB_ARG(T->d_local_mpb || T->mpb.stride <= cur->P.local_mpb_cap);
+  FB_ARG(cur && last && cur != last && cur->B == last->B && cur->cap == last->cap && track_args_ok(cur, T) && T->d_delta);
+  FB_TRY(motion_model_impl(cur, last, T, fb::as_stream(stream)));
+  return local_map_impl(cur, last, T, fb::as_stream(stream));
+}
+
+int fb_frame_compute_bow_dev(fb_frame *f, const fb_vocabulary *voc, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(f && voc);
+  if (f->bowDone) return FB_OK;  // if (mBowVec.empty()), Frame.cc:630
+  const size_t B = f->B, cap = f->cap;
+  if (!f->bow_nw.p) {
+    FB_TRY(f->bow_nw.alloc(B * 4)); FB_TRY(f->bow_ids.alloc(B * cap * 4)); FB_TRY(f->bow_vals.alloc(B * cap * 8));
+    FB_TRY(f->fv_nn.alloc(B * 4)); FB_TRY(f->fv_ids.alloc(B * cap * 4)); FB_TRY(f->fv_start.alloc(B * (cap + 1) * 4));
+    FB_TRY(f->fv_items.alloc(B * cap * 4));
+  }
+  fb_bow_transform_args A;
+  memset(&A, 0, sizeof(A));
+  A.batch = f->B; A.f_stride = f->cap; A.n_f = f->n.as<int32_t>(); A.desc = f->desc.as<uint8_t>(); A.levelsup = 4;  // Frame.cc:633
+  A.n_words = f->bow_nw.as<int32_t>(); A.bow_ids = f->bow_ids.as<uint32_t>(); A.bow_vals = f->bow_vals.as<double>();
+  A.fv_n_nodes = f->fv_nn.as<int32_t>(); A.fv_node_ids = f->fv_ids.as<uint32_t>(); A.fv_node_start = f->fv_start.as<int32_t>();
+  A.fv_items = f->fv_items.as<int32_t>();
+  FB_TRY(fb_bow_transform_dev(voc, &A, stream));
+  f->bowDone = true;
+  return FB_OK;
+}
+
+int fb_frame_copy_dev(fb_frame *dst, const fb_frame *src, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(dst && src && dst != src && dst->B == src->B && dst->cap == src->cap);
+  hipStream_t s = fb::as_stream(stream);
+  const size_t B = src->B, cap = src->cap;
+  if (src->bowDone && !dst->bow_nw.p) {
+    FB_TRY(dst->bow_nw.alloc(B * 4)); FB_TRY(dst->bow_ids.alloc(B * cap * 4)); FB_TRY(dst->bow_vals.alloc(B * cap * 8));
+    FB_TRY(dst->fv_nn.alloc(B * 4)); FB_TRY(dst->fv_ids.alloc(B * cap * 4)); FB_TRY(dst->fv_start.alloc(B * (cap + 1) * 4));
+    FB_TRY(dst->fv_items.alloc(B * cap * 4));
+  }
+#define CP(buf) FB_HIP(hipMemcpyAsync(dst->buf.p, src->buf.p, src->buf.bytes, hipMemcpyDeviceToDevice, s))
+  CP(n); CP(kps); CP(kps_un); CP(desc); CP(cs); CP(ci); CP(mp); CP(outlier);
+  CP(nb); CP(bkps); CP(bdesc); CP(bcam); CP(bcs); CP(bci); CP(mpb); CP(boutlier);
+  CP(Tcw); CP(counts);
+  if (src->bowDone) { CP(bow_nw); CP(bow_ids); CP(bow_vals); CP(fv_nn); CP(fv_ids); CP(fv_start); CP(fv_items); }
+#undef CP
+  dst->bowDone = src->bowDone;
+  return FB_OK;
+}
+
+int fb_frame_bow_view_dev(fb_frame *f, fb_bow_transform_args *v) {
+  FB_ARG(f && v && f->bowDone);
+  memset(v, 0, sizeof(*v));
+  v->batch = f->B; v->f_stride = f->cap; v->n_f = f->n.as<int32_t>(); v->desc = f->desc.as<uint8_t>(); v->levelsup = 4;
+  v->n_words = f->bow_nw.as<int32_t>(); v->bow_ids = f->bow_ids.as<uint32_t>(); v->bow_vals = f->bow_vals.as<double>();
+  v->fv_n_nodes = f->fv_nn.as<int32_t>(); v->fv_node_ids = f->fv_ids.as<uint32_t>(); v->fv_node_start = f->fv_start.as<int32_t>();
+  v->fv_items = f->fv_items.as<int32_t>();
+  return FB_OK;
+}
+
+int fb_frame_search_by_bow_dev(fb_frame *cur, const fb_frame *kf, const fb_map_points *map, const fb_matcher_params *matcher,
+                               int min_matches, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(cur && kf && cur != kf && cur->B == kf->B && cur->cap == kf->cap && map_ok(cur, map) && matcher && min_matches >= 0);
+  if (!cur->bowDone || !kf->bowDone) { fb::set_error("fb_frame_search_by_bow: ComputeBoW has not run on both frames"); return FB_ERR_ARG; }
+  hipStream_t s = fb::as_stream(stream);
+  FB_TRY(bow_impl(cur, kf, map, matcher, s));
+  return launch_commit(cur, commit_bow(cur, kf, min_matches), s);
+}
+
+int fb_frame_track_reference_dev(fb_frame *cur, fb_frame *kf, fb_frame *ref, const fb_vocabulary *voc, const fb_track_args *T,
+                                 void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(cur && kf && ref && voc && cur != kf && cur != ref && cur->B == kf->B && cur->cap == kf->cap && cur->B == ref->B && cur->cap == ref->cap);
+  FB_ARG(track_args_ok(cur, T) && T->d_delta);
+  if (!kf->bowDone) { fb::set_error("fb_frame_track_reference: the key frame's BoW is not computed (KeyFrame::ComputeBoW)"); return FB_ERR_ARG; }
   hipStream_t s = fb::as_stream(stream);
   fb_map_points_bird mpb = T->mpb;
-  // ---- TrackWithMotionModel (Tracking.cc:1312-1385)
-  FB_TRY(fb_frame_predict_pose_dev(cur, last, T->d_delta, stream));                                    // :1314-1320
-  const fb_matcher_params m09 = {0.9f, 1};  // ORBmatcher matcher(0.9,true), Tracking.cc:1325,2001,2726
-  FB_TRY(m9_impl(cur, &mpb, T->d_local_mpb, T->d_n_local_mpb, 10, 0.05f, &m09, s));                    // :1322-1323 -> :1999-2012
-  FB_TRY(m3_impl(cur, last, &T->map, 15.0f, &m09, s));                                                 // :1339
-  Commit C1 = commit_m9(cur, T->d_local_mpb);
-  C1.match = cur->m_front.as<int32_t>(); C1.src_mp = last->mp.as<int32_t>(); C1.src_stride = cur->cap;
-  FB_TRY(edges_and_pose(cur, &T->map, &mpb, FB_POSE_FRONT_BIRD, T->wB, T->wF, 0, C1, s));              // :1353
-  FB_TRY(fb_frame_discard_outliers_dev(cur, &T->map, stream));                                         // :1358-1376
-  // ---- TrackLocalMap (Tracking.cc:1387-1441)
-  FB_TRY(fb_frame_match_bird_points_dev(cur, last, &mpb, 10, 0.05f, &m09, stream));                    // :1392 -> :2724-2733
-  const fb_matcher_params m08 = {0.8f, 1};  // ORBmatcher matcher(0.8), Tracking.cc:1988
-  FB_TRY(local_impl(cur, &T->map, T->d_local_mp, T->d_n_local_mp, 1.0f, &m08, s));                     // :1396 -> :1947-1997
-  Commit C2;
-  memset(&C2, 0, sizeof(C2));
-  C2.kind = 2; C2.match = cur->m_local.as<int32_t>(); C2.src_mp = T->d_local_mp; C2.src_stride = cur->P.local_mp_cap;
-  FB_TRY(edges_and_pose(cur, &T->map, &mpb, FB_POSE_FRONT_BIRD, T->wB, T->wF, 1, C2, s));              // :1400
-  // ---- end of Track (Tracking.cc:1411-1424, 690-701, 721-725)
-  return fb_frame_finish_dev(cur, &T->map, stream);
+  FB_TRY(fb_frame_predict_pose_dev(cur, kf, T->d_delta, s));                                           // :1185-1186
+  FB_TRY(m9_impl(cur, &mpb, T->d_local_mpb, T->d_n_local_mpb, 10, 0.05f, &M09, s));                    // :1193-1194
+  FB_TRY(launch_commit(cur, commit_m9(cur, T->d_local_mpb), s));
+  FB_TRY(bird_points_impl(cur, ref, &mpb, 10, 0.05f, &M09, 10, s));                                    // :1196-1200
+  FB_TRY(fb_frame_compute_bow_dev(cur, voc, s));                                                       // :1203
+  FB_TRY(bow_impl(cur, kf, &T->map, &M07, s));                                                         // :1207-1210
+  FB_TRY(edges_and_pose(cur, &T->map, &mpb, FB_POSE_FRONT_BIRD, T->wB, T->wF, 0, commit_bow(cur, kf, 15), s));  // :1212-1220
+  return discard_impl(cur, &T->map, FB_CNT_BOW_MATCHES, 15, s);                                        // :1222-1241
 }
 
 int fb_frame_view_dev(fb_frame *f, fb_frame_view *v) {

@@ -107,6 +107,10 @@ class TrackChain:
             self.local_mpb.copy_(up(local_mpb[0])); self.n_local_mpb.copy_(up(local_mpb[1]))
             fill(self.targs, d_local_mp=self.local_mp, d_n_local_mp=self.n_local_mp, d_local_mpb=self.local_mpb,
                  d_n_local_mpb=self.n_local_mpb)
+        if hasattr(self, "targs_kf"):
+            d = self.targs_kf.d_delta
+            C.memmove(C.byref(self.targs_kf), C.byref(self.targs), C.sizeof(self.targs))
+            self.targs_kf.d_delta = d
         torch.cuda.synchronize()
 
     @property
@@ -191,6 +195,40 @@ class TrackChain:
         check(self.L.fb_frame_track_dev(self.cur, self.last, C.byref(self.targs), self._stream()), "fb_frame_track_dev")
         self.k += 1
 
+    # ---- reference key frame (Tracking::TrackReferenceKeyFrame, Tracking.cc:1180-1244) ----
+    def set_vocabulary(self, voc_arrays, L):
+        """Upload a vocabulary (the arrays of cabi.Vocabulary as numpy) once; kept for the chain's lifetime."""
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        self._voc_keep = {k: up(v) for k, v in voc_arrays.items()}
+        self.voc = cabi.Vocabulary()
+        fill(self.voc, n_nodes=len(voc_arrays["weights"]), L=L, **self._voc_keep)
+        self.kf = C.c_void_p()
+        check(self.L.fb_frame_create(C.byref(self.params), C.byref(self.kf)), "fb_frame_create")
+        self.frames.append(self.kf)   # (destroyed with the others; the rotation only uses the first three)
+        self.delta_kf = torch.zeros(self.B, 12, dtype=torch.float32, device=self.dev)
+        self.targs_kf = cabi.TrackArgs.from_buffer_copy(self.targs)
+        fill(self.targs_kf, d_delta=self.delta_kf)
+
+    def make_keyframe(self, which="last"):
+        """KeyFrame(mCurrentFrame, ...) + ComputeBoW (KeyFrame.cc:32-102) from the frame tracked most recently."""
+        check(self.L.fb_frame_copy_dev(self.kf, self._which(which), self._stream()), "fb_frame_copy_dev")
+        check(self.L.fb_frame_compute_bow_dev(self.kf, C.byref(self.voc), self._stream()), "fb_frame_compute_bow_dev")
+
+    def set_delta_kf(self, delta):
+        self.delta_kf.copy_(torch.from_numpy(np.ascontiguousarray(delta)).to(self.dev), non_blocking=True)
+
+    def track_modes(self, front, bird, contour=None, mask=None, mode="motion"):
+        """The host's choice of Tracking.cc:529-540 made by the caller: mode = "motion" (TrackWithMotionModel), "reference"
+        (TrackReferenceKeyFrame) or "motion+reference" (the fall-back when the motion model fails), then TrackLocalMap."""
+        L, s, cur, last = self.L, self._stream(), self.cur, self.last
+        self.extract(front, bird, contour, mask)
+        if "motion" in mode:
+            check(L.fb_frame_track_motion_model_dev(cur, last, C.byref(self.targs), s), "fb_frame_track_motion_model_dev")
+        if "reference" in mode:
+            check(L.fb_frame_track_reference_dev(cur, self.kf, last, C.byref(self.voc), C.byref(self.targs_kf), s), "fb_frame_track_reference_dev")
+        check(L.fb_frame_track_local_map_dev(cur, last, C.byref(self.targs), s), "fb_frame_track_local_map_dev")
+        self.k += 1
+
     def track_granular(self, front, bird, contour=None, mask=None):
         """The same chain through the one-call-per-reference-function entry points (every commit is its own launch)."""
         L, s, cur, last, T = self.L, self._stream(), self.cur, self.last, self.targs
@@ -212,7 +250,7 @@ class TrackChain:
 
     # ---- results ----
     def _which(self, which):
-        return {"last": self.last, "cur": self.cur, "prev": self.frames[(self.k - 2) % 3]}[which]
+        return {"last": self.last, "cur": self.cur, "prev": self.frames[(self.k - 2) % 3], "kf": getattr(self, "kf", None)}[which]
 
     def view(self, which="last"):
         """last = the frame tracked most recently, prev = the one before it (the reference frame of that step), cur = the next handle."""

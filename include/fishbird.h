@@ -798,6 +798,8 @@ enum {
   FB_CNT_LOCAL_MATCHES,       /* SearchByProjection(cur, mvpLocalMapPoints, th)      Tracking.cc:1995                   */
   FB_CNT_POSE2_INLIERS,       /* PoseOptimizationWithBird                            Tracking.cc:1400                   */
   FB_CNT_MATCHES_INLIERS,     /* mnMatchesInliers                                    Tracking.cc:1411-1424              */
+  FB_CNT_BOW_MATCHES,         /* nmatches = SearchByBoW(mpReferenceKF, cur, ...)     Tracking.cc:1207                   */
+  FB_CNT_BIRD_POINTS,         /* numPt = GetBirdMapPointsNum()                       Tracking.cc:1196                   */
   FB_CNT_COUNT = 16
 };
 
@@ -873,6 +875,39 @@ typedef struct fb_track_args {
   float wB, wF;                     /* Optimizer.h:52 defaults 1, 1                                                     */
 } fb_track_args;
 int fb_frame_track_dev(fb_frame *cur, fb_frame *last, const fb_track_args *args, void *stream);
+/* The two halves of fb_frame_track_dev on their own, for a host that reads the counters in between (Tracking.cc:529-540:
+ * bOK = TrackWithMotionModel(); if (!bOK) bOK = TrackReferenceKeyFrame(); ... if (bOK) bOK = TrackLocalMap()):
+ *   fb_frame_track_motion_model_dev  Tracking::TrackWithMotionModel (Tracking.cc:1312-1385); bOK = FB_CNT_MATCHES_MAP >= 10
+ *   fb_frame_track_local_map_dev     Tracking::TrackLocalMap (:1387-1441, ref = tmpRefFrame) + the end of Track (:690-725)  */
+int fb_frame_track_motion_model_dev(fb_frame *cur, fb_frame *last, const fb_track_args *args, void *stream);
+int fb_frame_track_local_map_dev(fb_frame *cur, fb_frame *ref, const fb_track_args *args, void *stream);
+
+/* Frame(const Frame &) (Frame.cc:49-82: tmpRefFrame = new Frame(mCurrentFrame), Tracking.cc:746) and the member copies of
+ * KeyFrame::KeyFrame(Frame &F, ...) (KeyFrame.cc:32-91): every member array of src into dst (same parameters), device to
+ * device on the stream, including the BoW when src has it.                                                               */
+int fb_frame_copy_dev(fb_frame *dst, const fb_frame *src, void *stream);
+
+/* Frame::ComputeBoW (Frame.cc:628-635; KeyFrame::ComputeBoW, KeyFrame.cc:93-102) on the handle: transform(mDescriptors,
+ * mBowVec, mFeatVec, 4) into buffers the handle owns; a second call on the same frame is a no-op (if (mBowVec.empty())),
+ * fb_frame_extract* empties them again.  voc = device arrays.  fb_frame_bow_view_dev hands out the device pointers
+ * (fb_bow_transform_args layout, f_stride = kp_stride).                                                                  */
+int fb_frame_compute_bow_dev(fb_frame *f, const fb_vocabulary *voc, void *stream);
+int fb_frame_bow_view_dev(fb_frame *f, fb_bow_transform_args *view);
+/* ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) (ORBmatcher.cc:160-289) with the key frame given as the frame handle
+ * it was made from (KeyFrame.cc:32-91 copies mvKeysUn, mDescriptors, mvpMapPoints): count -> FB_CNT_BOW_MATCHES, then
+ * mCurrentFrame.mvpMapPoints = vpMapPointMatches (Tracking.cc:1215) for the sequences with count >= min_matches (the
+ * others keep their mvpMapPoints, Tracking.cc:1212-1213).  Both frames need their BoW (FB_ERR_ARG otherwise).             */
+int fb_frame_search_by_bow_dev(fb_frame *cur, const fb_frame *kf, const fb_map_points *map, const fb_matcher_params *matcher,
+                               int min_matches, void *stream);
+/* Tracking::TrackReferenceKeyFrame (Tracking.cc:1180-1244, bLooseCouple = true, bHaveBird): SetPose(detlaT * kf pose) with
+ * args->d_delta = detlaT of :1185, GetLocalMapForBird, GetPerFrameMatchedBirdPoints against `ref` (tmpRefFrame) for the
+ * sequences holding fewer than 10 bird points (count -> FB_CNT_BIRD_POINTS; FB_CNT_BIRDVIEW_MATCHES reads 0 where the
+ * step was skipped), ComputeBoW, SearchByBoW(0.7), and for the sequences with >= 15 matches: mvpMapPoints = matches,
+ * PoseOptimizationWithBird (FB_CNT_POSE1_INLIERS), the outlier discard (FB_CNT_MATCHES, FB_CNT_MATCHES_MAP).  The
+ * reference's return value per sequence = FB_CNT_BOW_MATCHES >= 15 && FB_CNT_MATCHES_MAP >= 10; a sequence below 15 keeps
+ * its predicted pose, members and the two discard counters, like the early return.                                       */
+int fb_frame_track_reference_dev(fb_frame *cur, fb_frame *kf, fb_frame *ref, const fb_vocabulary *voc, const fb_track_args *args,
+                                 void *stream);
 
 /* Pointers to a frame's arrays: device pointers from fb_frame_view_dev (valid for the handle's lifetime, for harnesses
  * that keep working on the device), or host buffers the caller hands to fb_frame_download (NULL members are skipped).

@@ -218,8 +218,36 @@ class OracleChain:
         assert self.L.orc_frame_track(self.cur, self.last, C.byref(self.targs)) == 0
         self.k += 1
 
-    def view(self, which="last"):
+    # ---- reference key frame ----
+    def set_vocabulary(self, voc_arrays, L):
+        self.keep["voc"] = {k: np.ascontiguousarray(v) for k, v in voc_arrays.items()}
+        self.voc = cabi.Vocabulary()
+        cabi.fill(self.voc, n_nodes=len(voc_arrays["weights"]), L=L, **self.keep["voc"])
+        self.kf = C.c_void_p()
+        assert self.L.orc_frame_create(C.byref(self.params), C.byref(self.kf)) == 0
+        self.frames.append(self.kf)
+
+    def make_keyframe(self, which="last"):
         f = self.last if which == "last" else self.cur
+        assert self.L.orc_frame_copy(self.kf, f) == 0
+        assert self.L.orc_frame_compute_bow(self.kf, C.byref(self.voc)) == 0
+
+    def track_modes(self, front, bird, contour, mask, delta, delta_kf=None, mode="motion"):
+        self.extract(front, bird, contour, mask)
+        self.keep["delta"] = np.ascontiguousarray(delta, np.float32)
+        cabi.fill(self.targs, d_delta=self.keep["delta"])
+        if "motion" in mode:
+            assert self.L.orc_frame_track_motion_model(self.cur, self.last, C.byref(self.targs)) == 0
+        if "reference" in mode:
+            self.keep["delta_kf"] = np.ascontiguousarray(delta_kf, np.float32)
+            cabi.fill(self.targs, d_delta=self.keep["delta_kf"])
+            assert self.L.orc_frame_track_reference(self.cur, self.kf, self.last, C.byref(self.voc), C.byref(self.targs)) == 0
+            cabi.fill(self.targs, d_delta=self.keep["delta"])
+        assert self.L.orc_frame_track_local_map(self.cur, self.last, C.byref(self.targs)) == 0
+        self.k += 1
+
+    def view(self, which="last"):
+        f = self.last if which == "last" else (self.kf if which == "kf" else self.cur)
         v = cabi.FrameView()
         assert self.L.orc_frame_view(f, C.byref(v)) == 0
         B, cap = self.B, self.cap

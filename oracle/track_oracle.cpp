@@ -11,6 +11,8 @@
  *                                      FilterBirdOutlierInFront :1825-1914, SearchLocalPoints :1947-1997,
  *                                      GetLocalMapForBird :1999-2012
  *   end of Tracking::Track             :690-701 (clean VO matches), :721-725 (drop outliers)
+ *   Tracking::TrackReferenceKeyFrame   :1180-1244 with Frame::ComputeBoW (Frame.cc:628-635); the reference key frame is a
+ *                                      frame object (a KeyFrame is built from one, KeyFrame.cc:32-91)
  * mvpMapPoints / mvpMapPointsBird are indices into the caller's map tables (-1 = NULL), like the product's fb_frame.
  * The matchers / extractor / optimiser called in between are the other files of this oracle.
  */
@@ -37,6 +39,8 @@ int orc_match_projection_points(const fb_proj_points_args *A);
 int orc_match_birdview(const fb_birdview_args *A);
 int orc_in_frustum(const fb_frustum_args *A);
 int orc_pose_opt(const fb_pose_opt_args *A);
+int orc_bow_transform(const fb_vocabulary *V, const fb_bow_transform_args *A);
+int orc_match_bow(const fb_bow_args *A);
 }
 
 struct orc_frame {
@@ -50,6 +54,11 @@ struct orc_frame {
   std::vector<fb_keypoint> kps, kps_un, bkps;
   std::vector<uint8_t> desc, bdesc, outlier, boutlier;
   std::vector<float> bcam, Tcw;
+  // mBowVec / mFeatVec (Frame.h:128-129), empty until ComputeBoW
+  bool bow_done = false;
+  std::vector<int32_t> bow_nw, fv_nn, fv_start, fv_items;
+  std::vector<uint32_t> bow_ids, fv_ids;
+  std::vector<double> bow_vals;
   double stage_s[8];  // seconds inside each stage of the last orc_frame_extract / orc_frame_track call
 };
 
@@ -177,6 +186,13 @@ int orc_frame_extract(orc_frame *f, const uint8_t *front, int front_stride, cons
   orc_grid_build(f->kps_un.data(), f->n.data(), f->B, f->cap, &f->gF, f->cs.data(), f->ci.data());  // AssignFeaturesToGrid, :376
   orc_grid_build(f->bkps.data(), f->nb.data(), f->B, f->cap, &f->gB, f->bcs.data(), f->bci.data());
   std::fill(f->counts.begin(), f->counts.end(), 0);
+  f->bow_done = false;
+  return FB_OK;
+}
+
+// Frame(const Frame &) (Frame.cc:49-82) / the member copies of KeyFrame::KeyFrame(Frame &F, ...) (KeyFrame.cc:32-91)
+int orc_frame_copy(orc_frame *dst, const orc_frame *src) {
+  *dst = *src;
   return FB_OK;
 }
 
@@ -195,17 +211,15 @@ int orc_frame_set_map_points(orc_frame *f, const int32_t *mp, const int32_t *mpb
   return FB_OK;
 }
 
-// Tracking::Track for a frame in state OK: TrackWithMotionModel + TrackLocalMap + the clean-up (host pointers in T)
-int orc_frame_track(orc_frame *cur, orc_frame *last, const fb_track_args *T) {
-  const size_t B = cur->B, cap = cur->cap;
-  const fb_map_points *map = &T->map;
-  fb_map_points_bird mpbv = T->mpb;
-  fb_map_points_bird *mpb = &mpbv;
-  std::memset(cur->stage_s, 0, sizeof(cur->stage_s));
-  double t0 = now();
-  // ---- mCurrentFrame.SetPose(detlaT * mLastFrame.mTcw), Tracking.cc:1320 (4x4 * 4x4 CV_32F, small-matrix gemm path)
+}  // extern "C"
+
+namespace {
+
+// mCurrentFrame.SetPose(detlaT * src.mTcw), Tracking.cc:1320 / :1186 (4x4 * 4x4 CV_32F, small-matrix gemm path)
+void set_predicted_pose(orc_frame *cur, const orc_frame *src, const float *delta) {
+  const size_t B = cur->B;
   for (size_t b = 0; b < B; b++) {
-    const float *D = T->d_delta + b * 12, *L = last->Tcw.data() + b * 12;
+    const float *D = delta + b * 12, *L = src->Tcw.data() + b * 12;
     float *C = cur->Tcw.data() + b * 12;
     for (int r = 0; r < 3; r++)
       for (int c = 0; c < 4; c++) {
@@ -214,7 +228,11 @@ int orc_frame_track(orc_frame *cur, orc_frame *last, const fb_track_args *T) {
         C[r * 4 + c] = s;
       }
   }
-  // ---- GetLocalMapForBird, :1322-1323 -> :1999-2012
+}
+
+// GetLocalMapForBird, Tracking.cc:1999-2012
+void local_map_for_bird(orc_frame *cur, const fb_track_args *T, const fb_map_points_bird *mpb) {
+  const size_t B = cur->B, cap = cur->cap;
   {
     const int lcap = T->d_local_mpb ? cur->P.local_mpb_cap : mpb->stride;
     std::vector<uint8_t> valid(B * lcap, 0), rdesc(B * (size_t)lcap * 32, 0);
@@ -249,10 +267,11 @@ int orc_frame_track(orc_frame *cur, orc_frame *last, const fb_track_args *T) {
         if (m >= 0) cur->mpb[b * cap + i] = T->d_local_mpb ? T->d_local_mpb[b * lcap + m] : m;
       }
   }
-  double t1 = now();
-  cur->stage_s[2] = t1 - t0;
-  t0 = t1;
-  // ---- fill(mvpMapPoints, NULL); SearchByProjection(cur, last, 15, mono), :1330-1339
+}
+
+// fill(mvpMapPoints, NULL); SearchByProjection(cur, last, 15, mono), Tracking.cc:1330-1339
+void search_by_projection_last(orc_frame *cur, const orc_frame *last, const fb_map_points *map) {
+  const size_t B = cur->B, cap = cur->cap;
   {
     std::fill(cur->mp.begin(), cur->mp.end(), -1);
     std::vector<uint8_t> valid(B * cap, 0), obs(B * cap, 0), ldesc(B * cap * 32, 0);
@@ -288,17 +307,16 @@ int orc_frame_track(orc_frame *cur, orc_frame *last, const fb_track_args *T) {
         cur->mp[b * cap + i] = m >= 0 ? last->mp[b * cap + m] : -1;
       }
   }
-  t1 = now();
-  cur->stage_s[3] = t1 - t0;
-  t0 = t1;
-  // ---- Optimizer::PoseOptimizationWithBird(&mCurrentFrame), :1353
-  pose_optimization(cur, map, mpb, FB_POSE_FRONT_BIRD, T->wB, T->wF, FB_CNT_POSE1_INLIERS);
-  t1 = now();
-  cur->stage_s[4] = t1 - t0;
-  t0 = t1;
-  // ---- Discard outliers, :1358-1376
+}
+
+// the "Discard outliers" loop of TrackWithMotionModel (Tracking.cc:1358-1376) and TrackReferenceKeyFrame (:1221-1241);
+// nmatches starts from the matcher's return value (src_slot).  gate: sequences whose gate_slot counter is below gate_min
+// returned before the loop (TrackReferenceKeyFrame :1209-1210)
+void discard_outliers(orc_frame *cur, const fb_map_points *map, int src_slot, bool gate = false, int gate_slot = 0, int gate_min = 0) {
+  const size_t B = cur->B, cap = cur->cap;
   for (size_t b = 0; b < B; b++) {
-    int nmatches = cnt(cur, FB_CNT_PROJ_MATCHES)[b], nmatchesMap = 0;
+    if (gate && cnt(cur, gate_slot)[b] < gate_min) continue;
+    int nmatches = cnt(cur, src_slot)[b], nmatchesMap = 0;
     for (int i = 0; i < cur->n[b]; i++) {
       const size_t o = b * cap + i;
       if (cur->mp[o] < 0) continue;
@@ -308,7 +326,12 @@ int orc_frame_track(orc_frame *cur, orc_frame *last, const fb_track_args *T) {
     cnt(cur, FB_CNT_MATCHES)[b] = nmatches;
     cnt(cur, FB_CNT_MATCHES_MAP)[b] = nmatchesMap;
   }
-  // ---- TrackLocalMap: GetPerFrameMatchedBirdPoints, :1392 -> :2724-2733
+}
+
+// GetPerFrameMatchedBirdPoints (Tracking.cc:2724-2733) with tmpRefFrame = last; only_below > 0: only for the sequences
+// whose frame holds fewer bird map points than that (TrackReferenceKeyFrame, :1196-1200)
+void per_frame_matched_bird_points(orc_frame *cur, orc_frame *last, fb_map_points_bird *mpb, int only_below) {
+  const size_t B = cur->B, cap = cur->cap;
   {
     std::vector<int32_t> m12(B * cap, -1), mdist(B * cap, 0), ndm(B, 0);
     fb_birdview_args A;
@@ -322,6 +345,12 @@ int orc_frame_track(orc_frame *cur, orc_frame *last, const fb_track_args *T) {
     orc_match_birdview(&A);
     // FilterBirdOutlierInFront(tmpRefFrame, &mCurrentFrame, vDMatches12, 0.05), :1825-1914
     for (size_t b = 0; b < B; b++) {
+      if (only_below > 0) {  // int numPt = GetBirdMapPointsNum(); if (numPt < 10), Tracking.cc:1196-1200 (Frame.cc:1081-1092)
+        int numPt = 0;
+        for (int i = 0; i < cur->nb[b]; i++) numPt += cur->mpb[b * cap + i] >= 0;
+        cnt(cur, FB_CNT_BIRD_POINTS)[b] = numPt;
+        if (numPt >= only_below) { cnt(cur, FB_CNT_BIRDVIEW_MATCHES)[b] = 0; continue; }  // the matcher did not run for this sequence
+      }
       const float *T1 = last->Tcw.data() + b * 12, *T2 = cur->Tcw.data() + b * 12;
       float Twc1[12];  // Converter::invT(Tcw1), Converter.cc:176-187
       for (int r = 0; r < 3; r++) {
@@ -364,10 +393,11 @@ int orc_frame_track(orc_frame *cur, orc_frame *last, const fb_track_args *T) {
       cnt(cur, FB_CNT_BIRD_NEW)[b] = buildNew;
     }
   }
-  t1 = now();
-  cur->stage_s[5] = t1 - t0;
-  t0 = t1;
-  // ---- SearchLocalPoints, :1396 -> :1947-1997
+}
+
+// SearchLocalPoints, Tracking.cc:1947-1997
+void search_local_points(orc_frame *cur, const fb_track_args *T, const fb_map_points *map) {
+  const size_t B = cur->B, cap = cur->cap;
   {
     const int lcap = T->d_local_mp ? cur->P.local_mp_cap : map->stride;
     std::vector<uint8_t> seen(B * (size_t)map->stride, 0), blocked(B * cap, 0), lvalid(B * (size_t)lcap, 0), inview(B * (size_t)lcap, 0),
@@ -432,14 +462,11 @@ int orc_frame_track(orc_frame *cur, orc_frame *last, const fb_track_args *T) {
         if (m >= 0) cur->mp[b * cap + i] = T->d_local_mp ? T->d_local_mp[b * lcap + m] : m;
       }
   }
-  t1 = now();
-  cur->stage_s[6] = t1 - t0;
-  t0 = t1;
-  // ---- Optimizer::PoseOptimizationWithBird(&mCurrentFrame), :1400
-  pose_optimization(cur, map, mpb, FB_POSE_FRONT_BIRD, T->wB, T->wF, FB_CNT_POSE2_INLIERS);
-  t1 = now();
-  cur->stage_s[7] = t1 - t0;
-  // ---- mnMatchesInliers (:1411-1424), clean VO matches (:690-701), drop outliers (:721-725)
+}
+
+// mnMatchesInliers (Tracking.cc:1411-1424), clean VO matches (:690-701), drop outliers (:721-725)
+void finish_frame(orc_frame *cur, const fb_map_points *map) {
+  const size_t B = cur->B, cap = cur->cap;
   for (size_t b = 0; b < B; b++) {
     int inl = 0;
     for (int i = 0; i < cur->n[b]; i++) {
@@ -457,7 +484,126 @@ int orc_frame_track(orc_frame *cur, orc_frame *last, const fb_track_args *T) {
     }
     cnt(cur, FB_CNT_MATCHES_INLIERS)[b] = inl;
   }
+}
+
+// TrackLocalMap (Tracking.cc:1387-1441) + the end of Track
+void track_local_map(orc_frame *cur, orc_frame *last, const fb_track_args *T, fb_map_points_bird *mpb) {
+  const fb_map_points *map = &T->map;
+  double t0 = now();
+  per_frame_matched_bird_points(cur, last, mpb, 0);                                              // :1392
+  double t1 = now();
+  cur->stage_s[5] = t1 - t0;
+  t0 = t1;
+  search_local_points(cur, T, map);                                                              // :1396
+  t1 = now();
+  cur->stage_s[6] = t1 - t0;
+  t0 = t1;
+  pose_optimization(cur, map, mpb, FB_POSE_FRONT_BIRD, T->wB, T->wF, FB_CNT_POSE2_INLIERS);      // :1400
+  t1 = now();
+  cur->stage_s[7] = t1 - t0;
+  finish_frame(cur, map);
+}
+
+}  // namespace
+
+extern "C" {
+
+// Tracking::Track for a frame in state OK: TrackWithMotionModel + TrackLocalMap + the clean-up (host pointers in T)
+int orc_frame_track_motion_model(orc_frame *cur, orc_frame *last, const fb_track_args *T) {
+  const fb_map_points *map = &T->map;
+  fb_map_points_bird mpbv = T->mpb;
+  std::memset(cur->stage_s, 0, sizeof(cur->stage_s));
+  double t0 = now();
+  set_predicted_pose(cur, last, T->d_delta);                                                     // :1314-1320
+  local_map_for_bird(cur, T, &mpbv);                                                             // :1322-1323
+  double t1 = now();
+  cur->stage_s[2] = t1 - t0;
+  t0 = t1;
+  search_by_projection_last(cur, last, map);                                                     // :1330-1339
+  t1 = now();
+  cur->stage_s[3] = t1 - t0;
+  t0 = t1;
+  pose_optimization(cur, map, &mpbv, FB_POSE_FRONT_BIRD, T->wB, T->wF, FB_CNT_POSE1_INLIERS);    // :1353
+  t1 = now();
+  cur->stage_s[4] = t1 - t0;
+  discard_outliers(cur, map, FB_CNT_PROJ_MATCHES);                                               // :1358-1376
   return FB_OK;
+}
+
+int orc_frame_track_local_map(orc_frame *cur, orc_frame *last, const fb_track_args *T) {
+  fb_map_points_bird mpbv = T->mpb;
+  track_local_map(cur, last, T, &mpbv);
+  return FB_OK;
+}
+
+// Frame::ComputeBoW (Frame.cc:628-635): if (mBowVec.empty()) transform(descriptors, mBowVec, mFeatVec, 4)
+int orc_frame_compute_bow(orc_frame *f, const fb_vocabulary *voc) {
+  if (f->bow_done) return FB_OK;
+  const size_t B = f->B, cap = f->cap;
+  f->bow_nw.assign(B, 0); f->fv_nn.assign(B, 0); f->bow_ids.assign(B * cap, 0); f->bow_vals.assign(B * cap, 0.0);
+  f->fv_ids.assign(B * cap, 0); f->fv_start.assign(B * (cap + 1), 0); f->fv_items.assign(B * cap, 0);
+  fb_bow_transform_args A;
+  std::memset(&A, 0, sizeof(A));
+  A.batch = f->B; A.f_stride = f->cap; A.n_f = f->n.data(); A.desc = f->desc.data(); A.levelsup = 4;
+  A.n_words = f->bow_nw.data(); A.bow_ids = f->bow_ids.data(); A.bow_vals = f->bow_vals.data();
+  A.fv_n_nodes = f->fv_nn.data(); A.fv_node_ids = f->fv_ids.data(); A.fv_node_start = f->fv_start.data(); A.fv_items = f->fv_items.data();
+  const int rc = orc_bow_transform(voc, &A);
+  f->bow_done = rc == FB_OK;
+  return rc;
+}
+
+// Tracking::TrackReferenceKeyFrame (Tracking.cc:1180-1244), bLooseCouple = true (System.cc:32), bHaveBird.
+// kf = mpReferenceKF (its BoW computed, KeyFrame.cc:93-102), last = tmpRefFrame, T->d_delta = detlaT of :1185.
+int orc_frame_track_reference(orc_frame *cur, orc_frame *kf, orc_frame *last, const fb_vocabulary *voc, const fb_track_args *T) {
+  const size_t B = cur->B, cap = cur->cap;
+  const fb_map_points *map = &T->map;
+  fb_map_points_bird mpbv = T->mpb;
+  if (!kf->bow_done) return FB_ERR_ARG;
+  set_predicted_pose(cur, kf, T->d_delta);                       // :1185-1186
+  local_map_for_bird(cur, T, &mpbv);                             // :1193-1194
+  per_frame_matched_bird_points(cur, last, &mpbv, 10);           // :1196-1200
+  orc_frame_compute_bow(cur, voc);                               // :1203
+  std::vector<uint8_t> has_mp(B * cap, 0);
+  std::vector<int32_t> match(B * cap, -1);
+  for (size_t b = 0; b < B; b++)
+    for (int i = 0; i < kf->n[b]; i++) {                         // pMP && !pMP->isBad(), ORBmatcher.cc:196-203
+      const int id = kf->mp[b * cap + i];
+      has_mp[b * cap + i] = id >= 0 && !map->bad[b * map->stride + id];
+    }
+  fb_bow_args A;
+  std::memset(&A, 0, sizeof(A));
+  A.batch = cur->B; A.kf_stride = cur->cap; A.f_stride = cur->cap;
+  A.n_kf = kf->n.data(); A.kf_kps = kf->kps_un.data(); A.kf_desc = kf->desc.data(); A.kf_has_mp = has_mp.data();
+  A.kf_fv.node_stride = cur->cap; A.kf_fv.item_stride = cur->cap; A.kf_fv.n_nodes = kf->fv_nn.data(); A.kf_fv.node_ids = kf->fv_ids.data();
+  A.kf_fv.node_start = kf->fv_start.data(); A.kf_fv.items = kf->fv_items.data();
+  A.n_f = cur->n.data(); A.f_kps = cur->kps.data(); A.f_desc = cur->desc.data();   // F.mvKeys (ORBmatcher.cc:258)
+  A.f_fv.node_stride = cur->cap; A.f_fv.item_stride = cur->cap; A.f_fv.n_nodes = cur->fv_nn.data(); A.f_fv.node_ids = cur->fv_ids.data();
+  A.f_fv.node_start = cur->fv_start.data(); A.f_fv.items = cur->fv_items.data();
+  A.matcher.nnratio = 0.7f; A.matcher.check_orientation = 1;     // ORBmatcher matcher(0.7,true), :1207
+  A.match_f_to_kf = match.data(); A.nmatches = cnt(cur, FB_CNT_BOW_MATCHES);
+  orc_match_bow(&A);                                             // :1210
+  // per sequence from here on: if (nmatches < 15) return false, :1212-1213
+  for (size_t b = 0; b < B; b++) {
+    if (cnt(cur, FB_CNT_BOW_MATCHES)[b] < 15) continue;
+    for (size_t i = 0; i < cap; i++) {                           // mCurrentFrame.mvpMapPoints = vpMapPointMatches, :1215
+      const int m = (int)i < cur->n[b] ? match[b * cap + i] : -1;
+      cur->mp[b * cap + i] = m >= 0 ? kf->mp[b * cap + m] : -1;
+    }
+  }
+  {  // PoseOptimizationWithBird for the sequences that went on (:1217-1220): the others keep pose, flags and counter
+    std::vector<int32_t> n_keep = cur->n, nb_keep = cur->nb;
+    for (size_t b = 0; b < B; b++)
+      if (cnt(cur, FB_CNT_BOW_MATCHES)[b] < 15) { cur->n[b] = 0; cur->nb[b] = 0; }  // no edges: the optimiser leaves the sequence alone
+    pose_optimization(cur, map, &mpbv, FB_POSE_FRONT_BIRD, T->wB, T->wF, FB_CNT_POSE1_INLIERS);
+    cur->n = n_keep; cur->nb = nb_keep;
+  }
+  discard_outliers(cur, map, FB_CNT_BOW_MATCHES, true, FB_CNT_BOW_MATCHES, 15);   // :1222-1241
+  return FB_OK;
+}
+
+int orc_frame_track(orc_frame *cur, orc_frame *last, const fb_track_args *T) {
+  orc_frame_track_motion_model(cur, last, T);
+  return orc_frame_track_local_map(cur, last, T);
 }
 
 int orc_frame_view(orc_frame *f, fb_frame_view *v) {

@@ -39,7 +39,7 @@ def _cmp_view(g, o, tag):
         rel = float(np.abs(g["Tcw"][b] - o["Tcw"][b]).max() / max(1.0, np.abs(o["Tcw"][b]).max()))
         worst = max(worst, rel)
         assert rel <= REL_TOL, (tag, b, rel)
-    assert np.array_equal(g["counts"][:12], o["counts"][:12]), (tag, g["counts"][:12].T, o["counts"][:12].T)
+    assert np.array_equal(g["counts"][:14], o["counts"][:14]), (tag, g["counts"][:14].T, o["counts"][:14].T)
     return worst
 
 
@@ -185,3 +185,67 @@ def test_chain_host_images():
         for k in ("kps_bird", "desc_bird", "bird_cam_xyz", "map_point_bird", "bird_outlier"):
             assert np.array_equal(v_dev[k][b, :nb], v_host[k][b, :nb]), k
     tc.close()
+
+
+def test_chain_reference_keyframe_path():
+    """Tracking::TrackReferenceKeyFrame (Tracking.cc:1180-1244) on frame handles -- SetPose from the key frame, GetLocalMapForBird,
+    the numPt < 10 branch, ComputeBoW, SearchByBoW(0.7), the < 15 early return, pose optimisation, discard -- alone, and as the
+    fall-back after TrackWithMotionModel (Tracking.cc:535-540), with TrackLocalMap behind it and a new key frame mid-drive.
+    Sequence 1 has a short vlocalMPB list (<= 10 entries: GetLocalMapForBird matches nothing, so the per-frame bird match
+    runs inside TrackReferenceKeyFrame); sequence 2's first key frame holds no map points (SearchByBoW returns 0: the
+    early return).  The vocabulary is a synthetic 5-ary tree of depth 5 (the reference ships none)."""
+    import torch
+    from oracle import pyoracle as O
+    from test_bow_transform import make_vocabulary
+    B, K, wh, bwh = 3, 7, (640, 480), (384, 384)
+    seq = S.Sequence(B, K, seed=9700, front_wh=wh, bird_wh=bwh, fx=250.0, fy=250.0, device="cuda:0")
+    tc = T.TrackChain(B, wh, bwh, K=seq.Kc, D=seq.D, use_lists=True)
+    oc = O.OracleChain(tc.params, tc.map_cap, tc.bird_cap, use_lists=True)
+    mask_d = torch.from_numpy(seq.mask).cuda()
+    h = lambda t: t.cpu().numpy()
+    f, b, c = seq.render(0)
+    tc.extract(f, b, c, mask_d)
+    oc.extract(h(f), h(b), h(c), seq.mask)
+    v0 = tc.view("cur")
+    M, MB, mp0, mpb0, Tcw0 = seq.build_map(v0, tc.tables, map_cap=tc.map_cap, bird_cap=tc.bird_cap)
+    lm, lb = _lists(M, MB, 9705)
+    lb[1][1] = 8                      # sequence 1: vlocalMPB.size() <= 10
+    mp0 = mp0.copy()
+    mp0[2, :] = -1                    # sequence 2: the first key frame has no map points
+    tc.set_map(M, MB, lm, lb)
+    oc.set_map(M, MB, lm, lb)
+    vv, vk, first_leaf = make_vocabulary(9701, k=5, L=5)
+    tc.set_vocabulary(vk, 5)
+    oc.set_vocabulary(vk, 5)
+    tc.set_map(M, MB, lm, lb)         # (again: the key-frame argument block copies the map pointers)
+    tc.init_first(mp0, mpb0, Tcw0)
+    oc.init_first(mp0, mpb0, Tcw0)
+    tc.make_keyframe("last")
+    oc.make_keyframe("last")
+    kf_at, seen = 0, dict(ref_ok=0, gated=0, bird_branch=0)
+    modes = {1: "reference", 2: "motion", 3: "motion+reference", 4: "reference", 5: "motion", 6: "motion+reference"}
+    for k in range(1, K):
+        f, b, c = seq.render(k)
+        d, dk = seq.delta(k), seq.delta_between(kf_at, k)
+        tc.set_delta(d)
+        tc.set_delta_kf(dk)
+        tc.track_modes(f, b, c, mask_d, mode=modes[k])
+        oc.track_modes(h(f), h(b), h(c), seq.mask, d, dk, mode=modes[k])
+        g, o = tc.view(), oc.view()
+        _cmp_view(g, o, "frame %d (%s)" % (k, modes[k]))
+        gt, ot = tc.bird_table_host(), oc.bird_table_host()
+        assert np.array_equal(gt["n"], ot["n"]) and np.array_equal(gt["desc"], ot["desc"])
+        cnt = o["counts"]
+        if "reference" in modes[k]:
+            bow, pts = cnt[cabi.FB_CNT["BOW_MATCHES"]], cnt[cabi.FB_CNT["BIRD_POINTS"]]
+            seen["ref_ok"] += int((bow >= 15).sum()); seen["gated"] += int((bow < 15).sum()); seen["bird_branch"] += int((pts < 10).sum())
+        print("frame", k, modes[k], cnt[:14].T.tolist())
+        if k == 3:                    # CreateNewKeyFrame from the frame just tracked
+            tc.make_keyframe("last")
+            oc.make_keyframe("last")
+            kf_at = 3
+            _cmp_view(tc.view("kf"), oc.view("kf"), "key frame")
+    # every branch was exercised
+    assert seen["ref_ok"] >= 6 and seen["gated"] >= 1 and seen["bird_branch"] >= 1, seen
+    tc.close()
+    oc.close()

@@ -73,3 +73,24 @@ def test_pose_feeds_the_next_frame():
     assert int(b["counts"][cabi.FB_CNT["PROJ_MATCHES"], 0]) < int(a["counts"][cabi.FB_CNT["PROJ_MATCHES"], 0])
     oc.close()
     oc2.close()
+
+
+def test_oracle_reference_keyframe_path():
+    """TrackReferenceKeyFrame (Tracking.cc:1180-1244) in the oracle chain: BoW matches against the key frame give a pose at
+    the true one; a vocabulary that separates the two frames' features ("< 15 matches") leaves the frame as predicted."""
+    from test_bow_transform import make_vocabulary
+    seq, oc, imgs, (M, MB, mp0, mpb0), v0 = _chain(K=4)
+    v, vk, first_leaf = make_vocabulary(9700, k=5, L=5)
+    oc.set_vocabulary(vk, 5)
+    oc.make_keyframe("last")       # frame 0 becomes the reference key frame
+    for k, mode in ((1, "reference"), (2, "motion"), (3, "motion+reference")):
+        oc.track_modes(imgs[k][0], imgs[k][1], imgs[k][2], seq.mask, seq.delta(k), seq.delta_between(0, k), mode=mode)
+        vw = oc.view()
+        c = {name: int(vw["counts"][i, 0]) for name, i in cabi.FB_CNT.items()}
+        print(k, mode, c)
+        if "reference" in mode:
+            assert c["BOW_MATCHES"] >= 15 and c["MATCHES"] <= c["BOW_MATCHES"] and c["MATCHES_MAP"] >= 10, c
+        assert c["MATCHES_INLIERS"] >= 30, c
+        Tt = np.asarray(seq.Tcw_true(k, 0))[:3, :4].reshape(12)
+        assert np.abs(vw["Tcw"][0] - Tt).max() < 0.05, (k, np.abs(vw["Tcw"][0] - Tt).max())
+    oc.close()
