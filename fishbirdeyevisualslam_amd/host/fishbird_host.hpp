@@ -524,14 +524,38 @@ class DeviceFrame {
     int count(int slot, int b = 0) const { return counts[(size_t)slot * (counts.size() / FB_CNT_COUNT) + b]; }
     bool trackedWithMotionModel(int b = 0) const { return count(FB_CNT_PROJ_MATCHES, b) >= 20 && count(FB_CNT_MATCHES_MAP, b) >= 10; }  // Tracking.cc:1351,1384
     bool trackedLocalMap(int b = 0) const { return count(FB_CNT_MATCHES_INLIERS, b) >= 30; }                                              // :1438
+    bool trackedReferenceKeyFrame(int b = 0) const { return count(FB_CNT_BOW_MATCHES, b) >= 15 && count(FB_CNT_MATCHES_MAP, b) >= 10; }   // :1212,1243
   };
   // Tracking::Track, state OK: this frame against `last`; d_deltaT = rows 0..2 of detlaT (Tracking.cc:1316) on the device
   TrackResult TrackedFrame(DeviceFrame &last, const DeviceMap &map, const float *d_deltaT, float wB = 1.f, float wF = 1.f, void *stream = nullptr) {
-    fb_track_args T{};
-    T.map = map.points; T.mpb = map.birdPoints; T.d_delta = d_deltaT;
-    T.d_local_mp = map.localPoints; T.d_n_local_mp = map.nLocalPoints; T.d_local_mpb = map.localBirdPoints; T.d_n_local_mpb = map.nLocalBirdPoints;
-    T.wB = wB; T.wF = wF;
+    const fb_track_args T = Args(map, d_deltaT, wB, wF);
     check(fb_frame_track_dev(h_, last.h_, &T, stream));
+    return Result(stream);
+  }
+
+  // the pieces of Tracking::Track a state machine chooses between (Tracking.cc:529-540, 640-643), each one enqueue + one read-back:
+  //   bOK = TrackWithMotionModel(); if (!bOK) bOK = TrackReferenceKeyFrame(); if (bOK) bOK = TrackLocalMap();
+  TrackResult TrackWithMotionModel(DeviceFrame &last, const DeviceMap &map, const float *d_deltaT, float wB = 1.f, float wF = 1.f, void *stream = nullptr) {
+    const fb_track_args T = Args(map, d_deltaT, wB, wF);
+    check(fb_frame_track_motion_model_dev(h_, last.h_, &T, stream));
+    return Result(stream);
+  }
+  // mpReferenceKF = the frame handle the key frame was made from (CopyFrom + ComputeBoW); d_deltaT = detlaT of Tracking.cc:1185
+  TrackResult TrackReferenceKeyFrame(DeviceFrame &referenceKF, DeviceFrame &tmpRefFrame, const fb_vocabulary &d_voc, const DeviceMap &map,
+                                     const float *d_deltaT, float wB = 1.f, float wF = 1.f, void *stream = nullptr) {
+    const fb_track_args T = Args(map, d_deltaT, wB, wF);
+    check(fb_frame_track_reference_dev(h_, referenceKF.h_, tmpRefFrame.h_, &d_voc, &T, stream));
+    return Result(stream);
+  }
+  TrackResult TrackLocalMap(DeviceFrame &tmpRefFrame, const DeviceMap &map, float wB = 1.f, float wF = 1.f, void *stream = nullptr) {
+    const fb_track_args T = Args(map, nullptr, wB, wF);
+    check(fb_frame_track_local_map_dev(h_, tmpRefFrame.h_, &T, stream));
+    return Result(stream);
+  }
+  void ComputeBoW(const fb_vocabulary &d_voc, void *stream = nullptr) { check(fb_frame_compute_bow_dev(h_, &d_voc, stream)); }  // Frame.cc:628-635
+  void CopyFrom(const DeviceFrame &f, void *stream = nullptr) { check(fb_frame_copy_dev(h_, f.h_, stream)); }  // Frame(const Frame&), KeyFrame(Frame&, ...)
+
+  TrackResult Result(void *stream = nullptr) {
     TrackResult r;
     r.counts.resize((size_t)FB_CNT_COUNT * p_.batch);
     r.Tcw.resize((size_t)12 * p_.batch);
@@ -540,6 +564,13 @@ class DeviceFrame {
   }
 
  private:
+  static fb_track_args Args(const DeviceMap &map, const float *d_deltaT, float wB, float wF) {
+    fb_track_args T{};
+    T.map = map.points; T.mpb = map.birdPoints; T.d_delta = d_deltaT;
+    T.d_local_mp = map.localPoints; T.d_n_local_mp = map.nLocalPoints; T.d_local_mpb = map.localBirdPoints; T.d_n_local_mpb = map.nLocalBirdPoints;
+    T.wB = wB; T.wF = wF;
+    return T;
+  }
   fb_frame_params p_;
   fb_frame *h_ = nullptr;
 };
@@ -549,6 +580,11 @@ inline void SearchByProjection(const ORBmatcher &, DeviceFrame &cur, const Devic
                                bool checkOri = true, void *stream = nullptr) {  // ORBmatcher::SearchByProjection(Frame&, const Frame&, th, mono)
   const fb_matcher_params m{nnratio, checkOri ? 1 : 0};
   check(fb_frame_search_by_projection_dev(cur.handle(), last.handle(), &map.points, th, &m, stream));
+}
+inline void SearchByBoW(const ORBmatcher &, const DeviceFrame &kf, DeviceFrame &cur, const DeviceMap &map, float nnratio = 0.7f, bool checkOri = true,
+                        int minMatches = 15, void *stream = nullptr) {  // ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) + Tracking.cc:1212-1215
+  const fb_matcher_params m{nnratio, checkOri ? 1 : 0};
+  check(fb_frame_search_by_bow_dev(cur.handle(), kf.handle(), &map.points, &m, minMatches, stream));
 }
 inline void PoseOptimizationWithBird(DeviceFrame &f, const DeviceMap &map, float wB = 1.f, float wF = 1.f, int which = 0, void *stream = nullptr) {
   check(fb_frame_pose_optimization_dev(f.handle(), &map.points, &map.birdPoints, FB_POSE_FRONT_BIRD, wB, wF, which, stream));
