@@ -458,10 +458,50 @@ def track_chain_leg(rank, local_rank, batches=(1, 8, 256), steps=(200, 100, 20),
         tp = np.stack([np.asarray(seq.Tcw_true(path[pos], b))[:3, :4].reshape(12) for b in range(B)])
         res["max_abs_pose_error_vs_truth"] = float(np.abs(T - tp).max())
         res["bird_table_points"] = float(tc.mpb["n"].float().mean().item())
+        # TrackReferenceKeyFrame (Tracking.cc:1180-1244) instead of TrackWithMotionModel: the key frame = frame 0 of the drive
+        # (copied aside, BoW computed), every frame tracked against it with its own odometry increment, TrackLocalMap behind it,
+        # one counter read-back per frame.  Vocabulary: a synthetic 10-ary tree of depth 5 (111 k nodes; the reference ships none).
+        try:
+            from fishbirdeyevisualslam_amd.bow_problem import make_vocabulary
+            if "voc" not in out:
+                out["voc"] = make_vocabulary(9900, k=10, L=5)[1]
+            tc.set_vocabulary(out["voc"], 5)
+            tc.set_map(M, MB)
+            # re-seat frame 0 as the last frame and as the key frame
+            tc.extract(*imgs[0], mask)
+            tc.init_first(mp0, mpb0, Tcw0)
+            tc.make_keyframe("last")
+            dkf = {b_: torch.from_numpy(seq.delta_between(0, b_)).to(dev) for b_ in range(nframes)}
+            near = [1, 2, 3, 2, 1, 0]   # frames close to the key frame (BoW matches need common features)
+            d01 = {(a_, b_): torch.from_numpy(seq.delta_between(a_, b_)).to(dev) for a_ in range(4) for b_ in range(4)}
+
+            def run_ref(n):
+                prev = 0
+                for i in range(n):
+                    b_ = near[i % len(near)]
+                    tc.delta.copy_(d01[(prev, b_)], non_blocking=True)
+                    tc.delta_kf.copy_(dkf[b_], non_blocking=True)
+                    tc.track_modes(*imgs[b_], mask, mode="reference")
+                    tc.counts()
+                    prev = b_
+            run_ref(len(near))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nref = max(len(near), (nsteps // len(near)) * len(near))
+            run_ref(nref)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            cR, _ = tc.counts()
+            res["reference_keyframe_dependent"] = {"ms_per_step": dt / nref * 1e3, "ms_per_frame_pair": dt / nref / B * 1e3, "frames_per_s": B * nref / dt,
+                                                   "steps": nref, "bow_matches_mean_last_frame": float(cR[cabi.FB_CNT["BOW_MATCHES"]].mean()),
+                                                   "matches_inliers_mean_last_frame": float(cR[cabi.FB_CNT["MATCHES_INLIERS"]].mean())}
+        except Exception as e:  # the motion-model numbers above stand on their own
+            res["reference_keyframe_dependent"] = {"error": repr(e)[:300]}
         out["b%d" % B] = res
         tc.close()
         del imgs, seq, tc
         torch.cuda.empty_cache()
+    out.pop("voc", None)
     # parity of the chain inside the bench: a few sequences, consecutive dependent frames, GPU vs oracle chain
     try:
         from oracle import pyoracle as O

@@ -1,5 +1,5 @@
 """Soak of the tracking chain against the oracle chain: many short drives with different seeds, image sizes, local-list modes
-and bird feature counts; every frame compared (indices, masks, counters bit-exact; pose <= 1e-4).  usage: chain_soak.py SECONDS [SEED]"""
+and bird feature counts; every frame compared (indices, masks, counters bit-exact; pose <= 1e-4).  usage: chain_soak.py SECONDS [SEED] [SHARE_OF_REFERENCE_KEY_FRAME_DRIVES]"""
 import sys, time
 sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
@@ -8,6 +8,8 @@ import test_track_chain_gpu as T
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
+ref_share = float(sys.argv[3]) if len(sys.argv) > 3 else 0.4
+branches = {}
 g = np.random.default_rng(seed0)
 t0, runs, frames, bad, worst = time.time(), 0, 0, [], 0.0
 while time.time() - t0 < budget:
@@ -21,7 +23,17 @@ while time.time() - t0 < budget:
         kw["pipelined"] = False
     desc = "seed=%d %s B=%d K=%d %s" % (seed, wh, B, K, kw)
     try:
-        w, stats = T._run(B, K, wh, bwh, fx, seed=seed, check_workload=False, **kw)
+        if g.random() < ref_share:   # drives that mix TrackWithMotionModel, TrackReferenceKeyFrame and the fall-back
+            modes = {k: str(g.choice(["motion", "reference", "motion+reference"])) for k in range(1, K)}
+            rekey = tuple(int(k) for k in range(1, K) if g.random() < 0.3)
+            pick = lambda: int(g.integers(0, B)) if g.random() < 0.4 else None
+            desc = "seed=%d %s B=%d K=%d modes=%s rekey=%s" % (seed, wh, B, K, modes, rekey)
+            seen, w = T._run_modes(B, K, wh, bwh, fx, seed, modes, rekey_at=rekey, short_list_seq=pick(), empty_kf_seq=pick(),
+                                   use_lists=kw["use_lists"], voc_kL=(int(g.choice([4, 5, 8])), 5))
+            for k_, v_ in seen.items():
+                branches[k_] = branches.get(k_, 0) + v_
+        else:
+            w, stats = T._run(B, K, wh, bwh, fx, seed=seed, check_workload=False, **kw)
         worst = max(worst, w)
         frames += B * (K - 1)
     except AssertionError as e:
@@ -29,5 +41,6 @@ while time.time() - t0 < budget:
     runs += 1
     print("[%5.0f s] %d drives, %d tracked frames, %d mismatching drives, worst relative pose difference %.3g" % (time.time() - t0, runs, frames, len(bad), worst), flush=True)
 print("RESULT: %d drives, %d tracked frames compared with the oracle chain, %d mismatching drives, worst relative pose difference %.3g" % (runs, frames, len(bad), worst))
+print("reference-key-frame branches seen (sequence-frames):", branches)
 for b in bad[:10]:
     print("MISMATCH", b)

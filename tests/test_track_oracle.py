@@ -78,7 +78,7 @@ def test_pose_feeds_the_next_frame():
 def test_oracle_reference_keyframe_path():
     """TrackReferenceKeyFrame (Tracking.cc:1180-1244) in the oracle chain: BoW matches against the key frame give a pose at
     the true one; a vocabulary that separates the two frames' features ("< 15 matches") leaves the frame as predicted."""
-    from test_bow_transform import make_vocabulary
+    from fishbirdeyevisualslam_amd.bow_problem import make_vocabulary
     seq, oc, imgs, (M, MB, mp0, mpb0), v0 = _chain(K=4)
     v, vk, first_leaf = make_vocabulary(9700, k=5, L=5)
     oc.set_vocabulary(vk, 5)
