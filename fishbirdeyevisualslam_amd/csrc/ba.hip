@@ -1033,14 +1033,17 @@ __device__ __forceinline__ void solve_lookahead(const LinBuf &B, double lambda, 
 // ------------------------------------------------------------------------------------------
 // k_ba_update: back-substitution, trial state, scale term sum x (lambda x + b)
 // ------------------------------------------------------------------------------------------
+// Four lanes per landmark (as in the linearisation): lane q takes the landmark's edges q, q + 4, ..., the partial sums meet
+// in a two-step butterfly (the same value on all four lanes), lane q < 3 then finishes coordinate q.  One lane per landmark
+// left the back-substitution of 10 k landmarks to 79 two-wave workgroups.  Threads [4 npt, 4 npt + n_kf) = key frames.
 __device__ __forceinline__ void update_body(const BADev &D, const LinBuf &B, const State &cur, const State &trial, const double *Dinv,
                                             const double *xp, double lambda, double *scalePart, int countPoses, double *s_part) {
   const int g = blockIdx.x * LIN_THREADS + threadIdx.x;
   double sc = 0;
-  if (g < D.npt) {
-    const int l = g;
-    double cl[3] = {B.bl[(size_t)3 * l], B.bl[(size_t)3 * l + 1], B.bl[(size_t)3 * l + 2]};
-    for (int cc = D.lm_start[l]; cc < D.lm_start[l + 1]; cc++) {
+  if (g < 4 * D.npt) {
+    const int l = g >> 2, q = g & 3;
+    double cl[3] = {0, 0, 0};
+    for (int cc = D.lm_start[l] + q; cc < D.lm_start[l + 1]; cc += 4) {
       const int e = D.lm_edges[cc];
       const int pj = D.e_pj[e];
       if (pj < 0 || D.e_level[e] != 0) continue;
@@ -1050,15 +1053,20 @@ __device__ __forceinline__ void update_body(const BADev &D, const LinBuf &B, con
 #pragma unroll
         for (int i = 0; i < 6; i++) cl[j] -= W[i * 3 + j] * xp[6 * pj + i];
     }
-    const double *Di = Dinv + (size_t)9 * l;
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const double xl = Di[i * 3] * cl[0] + Di[i * 3 + 1] * cl[1] + Di[i * 3 + 2] * cl[2];
-      trial.pt[3 * l + i] = cur.pt[3 * l + i] + xl;
-      sc += xl * (lambda * xl + B.bl[(size_t)3 * l + i]);
+    for (int j = 0; j < 3; j++) {
+      cl[j] += __shfl_xor(cl[j], 1, 64);
+      cl[j] += __shfl_xor(cl[j], 2, 64);
+      cl[j] += B.bl[(size_t)3 * l + j];
     }
-  } else if (g < D.npt + D.n_kf) {
-    const int k = g - D.npt;
+    if (q < 3) {
+      const double *Di = Dinv + (size_t)9 * l;
+      const double xl = Di[q * 3] * cl[0] + Di[q * 3 + 1] * cl[1] + Di[q * 3 + 2] * cl[2];
+      trial.pt[3 * l + q] = cur.pt[3 * l + q] + xl;
+      sc = xl * (lambda * xl + B.bl[(size_t)3 * l + q]);
+    }
+  } else if (g < 4 * D.npt + D.n_kf) {
+    const int k = g - 4 * D.npt;
     const int pi = D.poseIdx[k];
     if (pi < 0) trial.pose[k] = cur.pose[k];
     else {
@@ -1081,22 +1089,34 @@ __device__ __forceinline__ void update_body(const BADev &D, const LinBuf &B, con
 // Spart[0] = sum over the workgroup partials (sharded BA: the local sum that goes through the all-reduce)
 // rows > 0: the buffers are [rows][rows] matrices of which only the upper 16x16 tiles (and with them column P6, the reduced
 // right-hand side) are ever written and read: the lower tiles are skipped
+// 256-thread workgroups: 64 consecutive elements x 4 quarters of the partials (a wave = one quarter, so its loads are
+// contiguous); the quarters meet in LDS in a fixed order.  One thread per element over all nWg partials kept only 64
+// workgroups busy on 19 MB.
+constexpr int SUMPARTS_ELEMS = 64;
 __device__ __forceinline__ void sumparts_body(double *Spart, int nWg, int n, int rows = 0) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (rows > 0) {
+  __shared__ double s_q[3][SUMPARTS_ELEMS];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = blockIdx.x * SUMPARTS_ELEMS + lane;
+  bool live = i < n;
+  if (live && rows > 0) {
     const int r = i / rows, c = i - r * rows;
-    if ((r >> 4) > (c >> 4)) return;
+    live = (r >> 4) <= (c >> 4);
   }
-  // 8 independent chains: a single running sum serialises nWg memory latencies per thread
-  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int w = 0;
-  for (; w + 8 <= nWg; w += 8) {
+  const int per = (nWg + 3) >> 2, w0 = q * per, w1 = min(nWg, w0 + per);
+  // 4 independent chains per thread: a single running sum serialises the memory latencies
+  double a[4] = {0, 0, 0, 0};
+  if (live) {
+    int w = w0;
+    for (; w + 4 <= w1; w += 4) {
 #pragma unroll
-    for (int u = 0; u < 8; u++) a[u] += Spart[(size_t)(w + u) * n + i];
+      for (int u = 0; u < 4; u++) a[u] += Spart[(size_t)(w + u) * n + i];
+    }
+    for (; w < w1; w++) a[0] += Spart[(size_t)w * n + i];
   }
-  for (; w < nWg; w++) a[0] += Spart[(size_t)w * n + i];
-  Spart[i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  const double s = (a[0] + a[1]) + (a[2] + a[3]);
+  if (q > 0) s_q[q - 1][lane] = s;
+  __syncthreads();
+  if (q == 0 && live) Spart[i] = ((s + s_q[0][lane]) + s_q[1][lane]) + s_q[2][lane];
 }
 __global__ void k_ba_sumparts(double *Spart, int nWg, int n) { sumparts_body(Spart, nWg, n); }
 
@@ -1251,33 +1271,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_update_c(BADev D, Lb2 lb, St
   }
   update_body(D, lb.b[c->cur], st.s[c->cur], st.s[1 - c->cur], Dinv, xp, c->lambda, scalePart, countPoses, s_part);
 }
-// The linearisation of a slot as ONE launch of 256-thread workgroups with three roles (they are independent of each
-// other): blocks [0, nLin) = landmarks (Hll, bl, W, chi2); the next POSE_PARTS * np blocks = a quarter of the edges of one
-// free key frame each (27 partial sums of its Hpp diagonal block and bp); the last block = the odometry edges (their
-// pose-pose blocks HppO, bpO).  The dense Hpp is never materialised: k_ba_control adds the key-frame parts into the diagonal
-// blocks and bp, k_ba_solve reads diagonal blocks + HppO.  Scratch per linearisation buffer t: [HppO | bpO], poseP.
 constexpr int POSE_PARTS = 4;
-template <bool GLOBAL>
-__global__ __launch_bounds__(256) void k_ba_lin_c(BADev D, St2 st, Lb2 lb, const BACtl *c, BASched sc, int P6, int nLin, int chiSlot, OdomLin *olGlobal,
-                                                  XBLay xb) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ double s_buf[256];
-  if (c->phase == 2) return;
-  const int t = c->needInit ? c->cur : 1 - c->cur;
-  const int robust = c->phase == 0 ? sc.robust1 : 0;
-  const int bx = blockIdx.x;
-  if (bx < nLin) {
-    linearize_quad_body<256>(D, st.s[t], lb.b[t], robust, s_buf);
-  } else if (bx < nLin + POSE_PARTS * D.np) {
-    const int q = bx - nLin, k = q / POSE_PARTS, part = q - k * POSE_PARTS;
-    pose_body(D, st.s[t], lb.b[t], robust, P6, reinterpret_cast<double(*)[27]>(s_buf), k, part, POSE_PARTS, xb.at(t) + (size_t)q * 27);
-  } else {
-    OdomLin *ol = GLOBAL ? olGlobal : reinterpret_cast<OdomLin *>(smem);
-    double *tmp = GLOBAL ? nullptr : reinterpret_cast<double *>(ol + max(D.nO, 1));  // the launch reserves 108 doubles per edge behind the records
-    odom_body<GLOBAL>(D, st.s[t], lb.b[t], P6, chiSlot, ol, s_buf, xb.at(t) + xb.oH, xb.at(t) + xb.oB, true, tmp);
-  }
-}
-
 // The decision at the end of a slot (one workgroup): assemble the key frames' diagonal blocks and bp from the parts, sum the
 // chi2 / scale partials in index order (thread 0, from LDS), maximum of the diagonal (computeLambdaInit,
 // optimization_algorithm_levenberg.cpp:166-180), then the LM state machine.
@@ -1312,10 +1306,9 @@ __global__ __launch_bounds__(256) void k_ba_prex(BADev D, Lb2 lb, const BACtl *c
 }
 
 template <bool SHARDED>
-__global__ __launch_bounds__(256) void k_ba_control(BADev D, Lb2 lb, BACtl *c, BASched sc, int nLin, int chiSlot, const double *scalePart, int nScale,
-                                                    const double *okFlag, int P6, XBLay xb, const int *abortLocal, int world) {
-  __shared__ double s_m[256];
-  __shared__ double s_chiP[512], s_scaleP[512];
+__device__ __forceinline__ void control_body(const BADev &D, const Lb2 &lb, BACtl *c, const BASched &sc, int nLin, int chiSlot, const double *scalePart, int nScale,
+                                             const double *okFlag, int P6, const XBLay &xb, const int *abortLocal, int world, double *s_m /*[256]*/,
+                                             double *s_chiP /*[512]*/, double *s_scaleP /*[512]*/) {
   const int tid = threadIdx.x;
   if (c->phase == 2) { if (tid == 0) c->slots++; return; }
   const int init = c->needInit;
@@ -1422,6 +1415,44 @@ __global__ __launch_bounds__(256) void k_ba_control(BADev D, Lb2 lb, BACtl *c, B
   }
   *c = k;
 }
+
+template <bool SHARDED>
+__global__ __launch_bounds__(256) void k_ba_control(BADev D, Lb2 lb, BACtl *c, BASched sc, int nLin, int chiSlot, const double *scalePart, int nScale,
+                                                    const double *okFlag, int P6, XBLay xb, const int *abortLocal, int world) {
+  __shared__ double s_m[256];
+  __shared__ double s_chiP[512], s_scaleP[512];
+  control_body<SHARDED>(D, lb, c, sc, nLin, chiSlot, scalePart, nScale, okFlag, P6, xb, abortLocal, world, s_m, s_chiP, s_scaleP);
+}
+
+// The linearisation of a slot as ONE launch of 256-thread workgroups with three roles (they are independent of each
+// other): blocks [0, nLin) = landmarks (Hll, bl, W, chi2); the next POSE_PARTS * np blocks = a quarter of the edges of one
+// free key frame each (27 partial sums of its Hpp diagonal block and bp); the last block = the odometry edges (their
+// pose-pose blocks HppO, bpO).  The dense Hpp is never materialised: k_ba_control adds the key-frame parts into the diagonal
+// blocks and bp, k_ba_solve reads diagonal blocks + HppO.  Scratch per linearisation buffer t: [HppO | bpO], poseP.
+// (Measured and dropped: the workgroup that finishes last -- a ticket in BACtl behind a device-scope fence -- taking the slot's
+// decision itself instead of a k_ba_control launch.  A device-scope release / acquire on this part writes back and invalidates
+// the XCD's L2 (buffer_wbl2 sc1 / buffer_inv sc1), once per workgroup: the linearisation went from 21 to 49 us.)
+template <bool GLOBAL>
+__global__ __launch_bounds__(256) void k_ba_lin_c(BADev D, St2 st, Lb2 lb, const BACtl *c, BASched sc, int P6, int nLin, int chiSlot, OdomLin *olGlobal,
+                                                  XBLay xb) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ double s_buf[256];
+  if (c->phase == 2) return;
+  const int t = c->needInit ? c->cur : 1 - c->cur;
+  const int robust = c->phase == 0 ? sc.robust1 : 0;
+  const int bx = blockIdx.x;
+  if (bx < nLin) {
+    linearize_quad_body<256>(D, st.s[t], lb.b[t], robust, s_buf);
+  } else if (bx < nLin + POSE_PARTS * D.np) {
+    const int q = bx - nLin, k = q / POSE_PARTS, part = q - k * POSE_PARTS;
+    pose_body(D, st.s[t], lb.b[t], robust, P6, reinterpret_cast<double(*)[27]>(s_buf), k, part, POSE_PARTS, xb.at(t) + (size_t)q * 27);
+  } else {
+    OdomLin *ol = GLOBAL ? olGlobal : reinterpret_cast<OdomLin *>(smem);
+    double *tmp = GLOBAL ? nullptr : reinterpret_cast<double *>(ol + max(D.nO, 1));  // the launch reserves 108 doubles per edge behind the records
+    odom_body<GLOBAL>(D, st.s[t], lb.b[t], P6, chiSlot, ol, s_buf, xb.at(t) + xb.oH, xb.at(t) + xb.oB, true, tmp);
+  }
+}
+
 
 __global__ void k_ba_gate_final_c(BADev D, St2 st, const BACtl *c, uint8_t *outFlag) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1976,7 +2007,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
   const int NT = (P6 + 1 + 15) / 16;
   const int rows = NT * 16;
   const int nLinBlocks = (npt + LIN_THREADS - 1) / LIN_THREADS;
-  const int nUpdBlocks = (npt + n_kf + LIN_THREADS - 1) / LIN_THREADS;
+  const int nUpdBlocks = (4 * npt + n_kf + LIN_THREADS - 1) / LIN_THREADS;  // four lanes per landmark + one per key frame
   int nWg = std::min(getenv("FB_BA_NWG") ? atoi(getenv("FB_BA_NWG")) : 256, std::max(1, (npt + CHUNK - 1) / CHUNK));
   const int lmPerWg = ((npt + nWg - 1) / nWg + CHUNK - 1) / CHUNK * CHUNK;
   nWg = std::max(1, (npt + lmPerWg - 1) / std::max(lmPerWg, 1));
@@ -2195,7 +2226,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
       { fb::ProfScope pr(fb::P_BA_SCHUR, s0);
         schurC<<<nWg, SCHUR_THREADS, schurLds, s0>>>(D, lb2, ctl, d_Dinv.as<double>(), d_Spart.as<double>(), P6, NT, lmPerWg); }
       { fb::ProfScope pr(fb::P_BA_SOLVE, s0);
-        k_ba_sumparts_c<<<(nS + 255) / 256, 256, 0, s0>>>(ctl, d_Spart.as<double>(), nWg, nS, rows);
+        k_ba_sumparts_c<<<(nS + SUMPARTS_ELEMS - 1) / SUMPARTS_ELEMS, 256, 0, s0>>>(ctl, d_Spart.as<double>(), nWg, nS, rows);
         if (sharded) rcSlot = X.sum_dev(d_Spart.as<double>(), (size_t)nS, s0, hostScratch);  // exchange 1: the Schur-reduced system
         k_ba_solve_c<<<1, SOLVE_C_THREADS, solveLds, s0>>>(lb2, ctl, d_Spart.as<double>(), P6, NT, d_xp.as<double>(), d_scal.as<double>() + 3, xr); }
       { fb::ProfScope pr(fb::P_BA_UPDATE, s0);
@@ -2388,7 +2419,7 @@ static int local_ba_impl(const fb_local_ba_args *A, int rank, const Xchg &X, con
         { fb::ProfScope pr(fb::P_BA_SOLVE, s0);
           // the workgroup partials are summed by a full-width kernel (one workgroup reading nWg x rows^2 doubles is slow)
           const int nS = rows * rows;
-          k_ba_sumparts<<<(nS + 255) / 256, 256, 0, s0>>>(d_Spart.as<double>(), nWg, nS);
+          k_ba_sumparts<<<(nS + SUMPARTS_ELEMS - 1) / SUMPARTS_ELEMS, 256, 0, s0>>>(d_Spart.as<double>(), nWg, nS);
           const int nParts = 1;
           if (sharded) {  // exchange step 1: the Schur-reduced system
             std::vector<double> ex(nS);
