@@ -460,12 +460,12 @@ def track_chain_leg(rank, local_rank, batches=(1, 8, 256), steps=(200, 100, 20),
         res["bird_table_points"] = float(tc.mpb["n"].float().mean().item())
         # TrackReferenceKeyFrame (Tracking.cc:1180-1244) instead of TrackWithMotionModel: the key frame = frame 0 of the drive
         # (copied aside, BoW computed), every frame tracked against it with its own odometry increment, TrackLocalMap behind it,
-        # one counter read-back per frame.  Vocabulary: a synthetic 10-ary tree of depth 5 (111 k nodes; the reference ships none).
+        # one counter read-back per frame.  Vocabulary: a synthetic 10-ary tree of depth 6, the shape of the stock ORB vocabulary (1.1 M nodes; the reference ships none).
         try:
             from fishbirdeyevisualslam_amd.bow_problem import make_vocabulary
             if "voc" not in out:
-                out["voc"] = make_vocabulary(9900, k=10, L=5)[1]
-            tc.set_vocabulary(out["voc"], 5)
+                out["voc"] = make_vocabulary(9900, k=10, L=6)[1]
+            tc.set_vocabulary(out["voc"], 6)
             tc.set_map(M, MB)
             # re-seat frame 0 as the last frame and as the key frame
             tc.extract(*imgs[0], mask)

@@ -136,29 +136,31 @@ def triangulation_args(problems, nnratio=0.6, check_ori=0):
 
 
 def make_vocabulary(seed, k=10, L=3, stop_frac=0.05):
-    """Complete k-ary tree of depth L in BFS node order (node 0 = root), random node descriptors, idf-like leaf weights."""
+    """Complete k-ary tree of depth L in BFS node order (node 0 = root), random node descriptors (every node = its parent
+    with a quarter of the bits flipped, so that the descent is meaningful), idf-like leaf weights.  k = 10, L = 6 is the
+    shape of the stock ORB vocabulary (1.1 M nodes); built level by level so that it takes seconds, not minutes."""
     g = synth.rng(seed)
     n_nodes = sum(k ** l for l in range(L + 1))
     first_leaf = sum(k ** l for l in range(L))
-    child_start = np.zeros(n_nodes + 1, np.int32)
-    children = []
-    for i in range(n_nodes):
-        child_start[i] = len(children)
-        if i < first_leaf:
-            children.extend(range(i * k + 1, i * k + k + 1))
-    child_start[n_nodes] = len(children)
-    desc = synth.random_descriptors(g, n_nodes)
-    # make siblings share most bits with their parent so that the descent is meaningful
-    for i in range(1, n_nodes):
-        parent = (i - 1) // k
-        desc[i] = synth.flip_bits(g, desc[parent:parent + 1], p=0.25)[0]
+    child_start = np.minimum(np.arange(n_nodes + 1, dtype=np.int64), first_leaf) * k
+    child_start = child_start.astype(np.int32)
+    children = np.arange(1, n_nodes, dtype=np.int32)
+    desc = np.zeros((n_nodes, 32), np.uint8)
+    desc[0] = synth.random_descriptors(g, 1)[0]
+    lo = 1
+    for l in range(1, L + 1):
+        hi = lo + k ** l
+        for c0 in range(lo, hi, 65536):   # bounded scratch: 65536 x 256 random numbers at a time
+            c1 = min(hi, c0 + 65536)
+            parents = (np.arange(c0, c1) - 1) // k
+            desc[c0:c1] = synth.flip_bits(g, desc[parents], p=0.25)
+        lo = hi
     weights = np.zeros(n_nodes, np.float64)
     weights[first_leaf:] = g.uniform(0.5, 9.0, n_nodes - first_leaf)
     weights[first_leaf:][g.random(n_nodes - first_leaf) < stop_frac] = 0.0   # stopped words
     word_ids = np.full(n_nodes, -1, np.int32)
     word_ids[first_leaf:] = np.arange(n_nodes - first_leaf)
-    keep = dict(child_start=child_start, children=np.array(children, np.int32), descriptors=desc, weights=weights,
-                word_ids=word_ids)
+    keep = dict(child_start=child_start, children=children, descriptors=desc, weights=weights, word_ids=word_ids)
     v = cabi.Vocabulary()
     fill(v, n_nodes=n_nodes, L=L, **keep)
     return v, keep, first_leaf

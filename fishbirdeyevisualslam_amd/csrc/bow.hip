@@ -16,6 +16,7 @@ namespace {
 
 constexpr int BOW_T = 1024;
 constexpr int BOW_MAXF = 4096;
+constexpr int BOW_KMAX = 12;  // children per node handled with batched loads (the ORB vocabulary has 10)
 constexpr unsigned long long KEY_NONE = ~0ull;
 
 __device__ __forceinline__ void bitonic_sort(unsigned long long *key, int n2, int tid, int nt) {
@@ -33,11 +34,26 @@ __device__ __forceinline__ void bitonic_sort(unsigned long long *key, int n2, in
     }
 }
 
+// exclusive scan of one int per thread over the BOW_T-thread block (s_wv: [BOW_T / 64]); *total = block sum
+__device__ __forceinline__ int bow_excl_scan(int v, int *s_wv, int *total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+  __syncthreads();
+  if (lane == 63) s_wv[wv] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < BOW_T / 64; w++) { const int x = s_wv[w]; if (w < wv) base += x; tot += x; }
+  *total = tot;
+  return base + inc - v;
+}
+
 __global__ __launch_bounds__(BOW_T) void k_bow_transform(fb_vocabulary V, fb_bow_transform_args A) {
   __shared__ unsigned long long s_key[BOW_MAXF];
   __shared__ double s_w[BOW_MAXF];        // per feature: leaf weight; later per unique word: summed weight
   __shared__ unsigned int s_aux[BOW_MAXF]; // per feature: node id at nid_level; later scan scratch
-  __shared__ int s_cnt;
   __shared__ double s_norm;
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const size_t fo = (size_t)b * A.f_stride;
@@ -60,12 +76,28 @@ __global__ __launch_bounds__(BOW_T) void k_bow_transform(fb_vocabulary V, fb_bow
       int c0 = V.child_start[0], c1 = V.child_start[1];
       do {
         ++level;
-        int best = V.children[c0];
-        int best_d = fb::hamming256(d, reinterpret_cast<const uint4 *>(V.descriptors + (size_t)best * 32));
-        for (int c = c0 + 1; c < c1; c++) {
-          const int id = V.children[c];
-          const int dist = fb::hamming256(d, reinterpret_cast<const uint4 *>(V.descriptors + (size_t)id * 32));
-          if (dist < best_d) { best_d = dist; best = id; }
+        const int cnt = c1 - c0;
+        int best, best_d;
+        if (cnt <= BOW_KMAX) {
+          // the usual k <= 12 children: every child id, then every child descriptor, is requested before the first use (two
+          // memory round trips per level instead of two per child); indices past the node's children are clamped and ignored
+          int ids[BOW_KMAX], dist[BOW_KMAX];
+#pragma unroll
+          for (int u = 0; u < BOW_KMAX; u++) ids[u] = V.children[c0 + min(u, cnt - 1)];
+#pragma unroll
+          for (int u = 0; u < BOW_KMAX; u++) dist[u] = fb::hamming256(d, reinterpret_cast<const uint4 *>(V.descriptors + (size_t)ids[u] * 32));
+          best = ids[0]; best_d = dist[0];
+#pragma unroll
+          for (int u = 1; u < BOW_KMAX; u++)
+            if (u < cnt && dist[u] < best_d) { best_d = dist[u]; best = ids[u]; }  // first minimum wins (TemplatedVocabulary.h:1240-1247)
+        } else {
+          best = V.children[c0];
+          best_d = fb::hamming256(d, reinterpret_cast<const uint4 *>(V.descriptors + (size_t)best * 32));
+          for (int c = c0 + 1; c < c1; c++) {
+            const int id = V.children[c];
+            const int dist = fb::hamming256(d, reinterpret_cast<const uint4 *>(V.descriptors + (size_t)id * 32));
+            if (dist < best_d) { best_d = dist; best = id; }
+          }
         }
         final_id = best;
         if (level == nid_level) nid = (unsigned int)final_id;
@@ -78,7 +110,7 @@ __global__ __launch_bounds__(BOW_T) void k_bow_transform(fb_vocabulary V, fb_bow
     s_key[i] = key;
     if (i < n) { s_w[i] = w; s_aux[i] = nid; }
   }
-  if (tid == 0) { s_cnt = 0; s_norm = 0.0; }
+  if (tid == 0) s_norm = 0.0;
   __syncthreads();
   // ---- phase 2: BowVector ---------------------------------------------------------------------------------------------
   bitonic_sort(s_key, n2, tid, nt);
@@ -94,17 +126,11 @@ __global__ __launch_bounds__(BOW_T) void k_bow_transform(fb_vocabulary V, fb_bow
     const unsigned long long k = s_key[i];
     if (k != KEY_NONE && (i == 0 || (s_key[i - 1] >> 32) != (k >> 32))) heads++;
   }
-  __shared__ int s_part[BOW_T];
-  s_part[tid] = heads;
-  __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int t = 0; t < nt; t++) { const int v = s_part[t]; s_part[t] = run; run += v; }
-    s_cnt = run;
-  }
-  __syncthreads();
+  __shared__ int s_wv[BOW_T / 64];
+  __shared__ double s_sum[BOW_MAXF];   // summed weight per unique word, by rank
+  int nw;
   {
-    int rank = s_part[tid];
+    int rank = bow_excl_scan(heads, s_wv, &nw);
     for (int i = i0; i < i1; i++) {
       const unsigned long long k = s_key[i];
       if (k == KEY_NONE) break;
@@ -112,22 +138,31 @@ __global__ __launch_bounds__(BOW_T) void k_bow_transform(fb_vocabulary V, fb_bow
         double acc = s_w[(unsigned int)k];  // addWeight: the first occurrence inserts v, later ones += v, in feature order
         for (int j = i + 1; j < n2 && s_key[j] != KEY_NONE && (s_key[j] >> 32) == (k >> 32); j++) acc += s_w[(unsigned int)s_key[j]];
         bow_ids[rank] = (uint32_t)(k >> 32);
-        bow_vals[rank] = acc;
+        s_sum[rank] = acc;
         rank++;
       }
     }
   }
   __syncthreads();
-  const int nw = s_cnt;
-  if (tid == 0) {  // BowVector::normalize(L1): ascending word order
+  if (tid == 0) {  // BowVector::normalize(L1): ascending word order, one lane (the order of the additions is the result), from LDS
     double norm = 0.0;
-    for (int r = 0; r < nw; r++) norm += fabs(bow_vals[r]);
+    int r = 0;
+    for (; r + 8 <= nw; r += 8) {
+      double v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v8[u] = fabs(s_sum[r + u]);
+#pragma unroll
+      for (int u = 0; u < 8; u++) norm += v8[u];
+    }
+    for (; r < nw; r++) norm += fabs(s_sum[r]);
     s_norm = norm;
     A.n_words[b] = nw;
   }
   __syncthreads();
-  if (s_norm > 0.0)
-    for (int r = tid; r < nw; r += nt) bow_vals[r] /= s_norm;
+  {
+    const double norm = s_norm;
+    for (int r = tid; r < nw; r += nt) bow_vals[r] = norm > 0.0 ? s_sum[r] / norm : s_sum[r];
+  }
   __syncthreads();
   // ---- phase 3: FeatureVector (features with weight > 0 only, :1157-1161) ---------------------------------------------
   for (int i = tid; i < n2; i += nt) {
@@ -145,20 +180,14 @@ __global__ __launch_bounds__(BOW_T) void k_bow_transform(fb_vocabulary V, fb_bow
     valid++;
     if (i == 0 || (s_key[i - 1] >> 32) != (k >> 32)) heads++;
   }
-  s_part[tid] = heads;
   __shared__ int s_valid;
   if (tid == 0) s_valid = 0;
   __syncthreads();
-  atomicAdd(&s_valid, valid);
-  if (tid == 0) {
-    int run = 0;
-    for (int t = 0; t < nt; t++) { const int v = s_part[t]; s_part[t] = run; run += v; }
-    s_cnt = run;
-  }
-  __syncthreads();
+  if (valid) atomicAdd(&s_valid, valid);
+  int nNodes;
   int32_t *st = A.fv_node_start + (size_t)b * (A.f_stride + 1);
   {
-    int rank = s_part[tid];
+    int rank = bow_excl_scan(heads, s_wv, &nNodes);
     for (int i = i0; i < i1; i++) {
       const unsigned long long k = s_key[i];
       if (k == KEY_NONE) break;
@@ -171,7 +200,7 @@ __global__ __launch_bounds__(BOW_T) void k_bow_transform(fb_vocabulary V, fb_bow
     }
   }
   __syncthreads();
-  if (tid == 0) { st[s_cnt] = s_valid; A.fv_n_nodes[b] = s_cnt; }
+  if (tid == 0) { st[nNodes] = s_valid; A.fv_n_nodes[b] = nNodes; }
 }
 
 }  // namespace

@@ -100,7 +100,12 @@ __global__ __launch_bounds__(BOW_THREADS) void k_match_bow_t(fb_bow_args A, cons
   int *ownerB = ownerA + A.f_stride;
   int *assignA = ownerB + A.f_stride;                                // [kf item_stride]
   int *assignB = assignA + A.kf_fv.item_stride;
+  int *fitems = assignB + A.kf_fv.item_stride;                       // [f item_stride] F.mFeatVec's items: walked by every query in every round
   __shared__ int s_changed, s_n, s_hist[HISTO_LENGTH], s_ind[3];
+  {
+    const int nFi = F.n > 0 ? min(F.start[F.n], A.f_fv.item_stride) : 0;
+    for (int i = tid; i < nFi; i += nt) fitems[i] = F.items[i];
+  }
   if (descInLds) {
     const uint4 *src = reinterpret_cast<const uint4 *>(A.f_desc + fo * 32);
     uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -109,34 +114,71 @@ __global__ __launch_bounds__(BOW_THREADS) void k_match_bow_t(fb_bow_args A, cons
   for (int i = tid; i < nF; i += nt) ownerA[i] = NONE;
   for (int q = tid; q < nQ; q += nt) assignA[q] = NONE;
   __syncthreads();
+  // What a query needs in every round of the fixed point -- its key-frame feature, whether that carries a MapPoint, the
+  // frame-side node (two binary searches over the CSR in HBM) and its descriptor -- does not change between rounds: a lane
+  // resolves it once for its (at most QPT) queries and keeps it in registers; a round then only touches LDS.  (Re-deriving it
+  // per round was ~15 us of dependent global loads per round, most of the kernel.)
+  constexpr int QPT = 4;
+  const bool cached = nQ <= QPT * nt;
+  int qc0[QPT], qc1[QPT];       // candidate range in F.items, empty = the query cannot match
+  uint32_t qd[QPT][8];
+#pragma unroll
+  for (int s_ = 0; s_ < QPT; s_++) {
+    qc0[s_] = 0; qc1[s_] = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) qd[s_][w] = 0;
+    const int q = tid + s_ * nt;
+    if (cached && q < nQ) {
+      const int realIdxKF = K.items[q];
+      if (A.kf_has_mp[ko + realIdxKF]) {
+        const int fi = find_node(F, K.ids[node_of_item(K, q)]);
+        if (fi >= 0) { qc0[s_] = F.start[fi]; qc1[s_] = F.start[fi + 1]; load_desc(A.kf_desc + (ko + realIdxKF) * 32, qd[s_]); }
+      }
+    }
+  }
+  auto evaluate = [&](int q, int c0, int c1, const uint32_t *d) {
+    int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+    for (int c = c0; c < c1; c++) {
+      const int realIdxF = fitems[c];
+      if (ownerA[realIdxF] < q) continue;  // vpMapPointMatches[realIdxF] already set by an earlier feature
+      if (KFKF && !f_has_mp[fo + realIdxF]) continue;
+      const int dist = fb::hamming256(d, fdesc + realIdxF * 2);
+      if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+      else if (dist < bestDist2) bestDist2 = dist;
+    }
+    const bool low = KFKF ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW;
+    return (low && (float)bestDist1 < A.matcher.nnratio * (float)bestDist2) ? bestIdxF : NONE;
+  };
   for (int round = 0; round <= nQ + 1; round++) {
     for (int i = tid; i < nF; i += nt) ownerB[i] = NONE;
     if (tid == 0) s_changed = 0;
     __syncthreads();
-    for (int q = tid; q < nQ; q += nt) {
-      int best = NONE;
-      const int realIdxKF = K.items[q];
-      if (A.kf_has_mp[ko + realIdxKF]) {
-        const int fi = find_node(F, K.ids[node_of_item(K, q)]);
-        if (fi >= 0) {
-          uint32_t d[8];
-          load_desc(A.kf_desc + (ko + realIdxKF) * 32, d);
-          int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
-          for (int c = F.start[fi]; c < F.start[fi + 1]; c++) {
-            const int realIdxF = F.items[c];
-            if (ownerA[realIdxF] < q) continue;  // vpMapPointMatches[realIdxF] already set by an earlier feature
-            if (KFKF && !f_has_mp[fo + realIdxF]) continue;
-            const int dist = fb::hamming256(d, fdesc + realIdxF * 2);
-            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
-            else if (dist < bestDist2) bestDist2 = dist;
-          }
-          const bool low = KFKF ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW;
-          if (low && (float)bestDist1 < A.matcher.nnratio * (float)bestDist2) best = bestIdxF;
-        }
+    if (cached) {
+#pragma unroll
+      for (int s_ = 0; s_ < QPT; s_++) {
+        const int q = tid + s_ * nt;
+        if (q >= nQ) continue;
+        const int best = qc1[s_] > qc0[s_] ? evaluate(q, qc0[s_], qc1[s_], qd[s_]) : NONE;
+        assignB[q] = best;
+        if (best != assignA[q]) s_changed = 1;
+        if (best != NONE) atomicMin(&ownerB[best], q);
       }
-      assignB[q] = best;
-      if (best != assignA[q]) s_changed = 1;
-      if (best != NONE) atomicMin(&ownerB[best], q);
+    } else {
+      for (int q = tid; q < nQ; q += nt) {
+        int best = NONE;
+        const int realIdxKF = K.items[q];
+        if (A.kf_has_mp[ko + realIdxKF]) {
+          const int fi = find_node(F, K.ids[node_of_item(K, q)]);
+          if (fi >= 0) {
+            uint32_t d[8];
+            load_desc(A.kf_desc + (ko + realIdxKF) * 32, d);
+            best = evaluate(q, F.start[fi], F.start[fi + 1], d);
+          }
+        }
+        assignB[q] = best;
+        if (best != assignA[q]) s_changed = 1;
+        if (best != NONE) atomicMin(&ownerB[best], q);
+      }
     }
     __syncthreads();
     const int changed = s_changed;
@@ -303,7 +345,7 @@ int fb_match_bow_dev(const fb_bow_args *A, void *stream) {
   FB_TRY(fb::check_device());
   FB_ARG(A && A->batch >= 0 && A->kf_stride > 0 && A->f_stride > 0 && A->kf_fv.item_stride >= 0 && A->f_fv.item_stride >= 0);
   if (A->batch == 0) return FB_OK;
-  size_t lds = (size_t)A->f_stride * 32 + (size_t)A->f_stride * 8 + (size_t)A->kf_fv.item_stride * 8 + 16;
+  size_t lds = (size_t)A->f_stride * 32 + (size_t)A->f_stride * 8 + (size_t)A->kf_fv.item_stride * 8 + (size_t)A->f_fv.item_stride * 4 + 16;
   const int descInLds = lds <= 160 * 1024 - 512;
   if (!descInLds) lds -= (size_t)A->f_stride * 32;
   FB_TRY(lds_ok(lds, "fb_match_bow"));
@@ -324,7 +366,7 @@ int fb_match_bow_kf_dev(const fb_bow_kf_args *K, void *stream) {
   A.n_kf = K->n1; A.kf_kps = K->kps1; A.kf_desc = K->desc1; A.kf_has_mp = K->has_mp1; A.kf_fv = K->fv1;
   A.n_f = K->n2; A.f_kps = K->kps2; A.f_desc = K->desc2; A.f_fv = K->fv2;
   A.matcher = K->matcher; A.match_f_to_kf = nullptr; A.nmatches = K->nmatches;
-  size_t lds = (size_t)A.f_stride * 32 + (size_t)A.f_stride * 8 + (size_t)A.kf_fv.item_stride * 8 + 16;
+  size_t lds = (size_t)A.f_stride * 32 + (size_t)A.f_stride * 8 + (size_t)A.kf_fv.item_stride * 8 + (size_t)A.f_fv.item_stride * 4 + 16;
   const int descInLds = lds <= 160 * 1024 - 512;
   if (!descInLds) lds -= (size_t)A.f_stride * 32;
   FB_TRY(lds_ok(lds, "fb_match_bow_kf"));
