@@ -723,7 +723,7 @@ __device__ __forceinline__ void solve_body(const LinBuf &B, double lambda, const
       double dc = Lb[c][c];
 #pragma unroll
       for (int m = 0; m < c; m++) dc -= Lb[c][m] * Lb[c][m] * d[m];
-      if (dc < 0) neg = true;
+      if (dc == 0) neg = true;  // SimplicialLDLT: the factorisation fails on a pivot that is exactly 0, negative pivots proceed
       d[c] = dc;
       const double inv = dc != 0 ? ba_rcp(dc) : 0.0;
       dinv[c] = inv;
@@ -829,7 +829,7 @@ __device__ __forceinline__ void solve_body(const LinBuf &B, double lambda, const
 }
 
 // ------------------------------------------------------------------------------------------
-// solve_lookahead: the same LDL^T (6x6 blocks, no pivoting, fails on a negative pivot) arranged for latency -- this one
+// solve_lookahead: the same LDL^T (6x6 blocks, no pivoting, fails on a zero pivot) arranged for latency -- this one
 // workgroup sits on the critical path of every LM trial.
 //  * the right-hand side rides along as row P6 of the matrix: its panel steps ARE the forward substitution, so after the
 //    factorisation row P6 holds z = D^-1 L^-1 b and only the backward substitution remains;
@@ -904,7 +904,7 @@ __device__ __forceinline__ void solve_lookahead(const LinBuf &B, double lambda, 
       double dc = Lb[c][c];
 #pragma unroll
       for (int m = 0; m < c; m++) dc -= Lb[c][m] * Ub[c][m];
-      if (dc < 0) neg = true;
+      if (dc == 0) neg = true;  // SimplicialLDLT: the factorisation fails on a pivot that is exactly 0, negative pivots proceed
       d[c] = dc;
       const double inv = dc != 0 ? ba_rcp(dc) : 0.0;
       dinv[c] = inv;

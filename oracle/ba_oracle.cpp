@@ -339,7 +339,7 @@ struct BAProblem : LMProblem {
       // the solver sees the upper triangle only: symmetrise from it
       for (int i = 0; i < P6; i++)
         for (int j = 0; j < i; j++) S[(size_t)i * P6 + j] = S[(size_t)j * P6 + i];
-      if (!ldlt_solve(S, P6, bs.data(), x.data())) return false;
+      if (!ldlt_solve(S, P6, bs.data(), x.data(), true)) return false;
     }
     for (int l = 0; l < nl; l++) {  // xl = Dinv (bl - B^T xp)
       double cl[3] = {b[(size_t)P6 + 3 * l], b[(size_t)P6 + 3 * l + 1], b[(size_t)P6 + 3 * l + 2]};

@@ -229,12 +229,16 @@ inline void huber(double e, double delta, double rho[2]) {
 
 // Dense symmetric solve restating LinearSolverDense (solvers/linear_solver_dense.h:65-113):
 // LDL^T; returns false on a negative pivot (Eigen LDLT::isPositive() == false).
-inline bool ldlt_solve(std::vector<double> A, int n, const double *b, double *x) {
+// simplicial = the failure rule of LinearSolverEigen (solvers/linear_solver_eigen.h:94-124: SimplicialLDLT::info() !=
+// Success), which every bundle adjustment of the reference uses (Optimizer.cc:64,895,1799,2233): Eigen's LDL^T
+// factorisation stops with NumericalIssue on a pivot that is exactly 0 and carries on through negative ones (Eigen is
+// not vendored: restated from general knowledge of SimplicialCholesky_impl.h, PARITY UNPINNED).
+inline bool ldlt_solve(std::vector<double> A, int n, const double *b, double *x, bool simplicial = false) {
   std::vector<double> d(n);
   for (int j = 0; j < n; j++) {
     double dj = A[j * n + j];
     for (int k = 0; k < j; k++) dj -= A[j * n + k] * A[j * n + k] * d[k];
-    if (dj < 0) return false;
+    if (simplicial ? dj == 0 : dj < 0) return false;
     d[j] = dj;
     for (int i = j + 1; i < n; i++) {
       double s = A[i * n + j];
