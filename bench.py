@@ -167,6 +167,85 @@ def cpu_baseline(world, nsample, rank, refs_out):
             "one_core": one, "n_cores": many}
 
 
+def local_mapping_leg(L, local_rank, reps=5):
+    """What the LocalMapping thread asks of the GPU per new key frame (LocalMapping.cc:76-96, 231-476, 478-560), from
+    device-resident inputs, enqueued back to back on one stream: SearchForTriangulation of the key frame against 20
+    neighbours (M7, one batched call), the search half of Fuse into 20 neighbours and back (two batched calls),
+    LocalBundleAdjustmentWithOdom of BASELINE config 4 (fb_local_ba_dev, which ends with the one synchronisation).
+    The three problems are synthetic and independent of each other (the map mutation between them stays on the host)."""
+    import torch
+    from fishbirdeyevisualslam_amd import ba_problem, bow_problem as BP, kf_problems as KP, synth, cabi
+    dev = torch.device("cuda", local_rank)
+    held = []
+
+    def put(struct, keep):
+        made = {}
+        for k, v in keep.items():
+            if isinstance(v, np.ndarray):
+                t = torch.from_numpy(np.ascontiguousarray(v.view(np.uint8) if v.dtype == cabi.KP_DTYPE else v)).to(dev)
+                held.append(t)
+                made[k] = t
+                cabi.fill(struct, **{k: t})
+        return made
+    NB = 20
+    tp = [BP.make_triangulation_problem(6400 + i, 2000, 2000) for i in range(NB)]
+    ta, tout, (tk, k1, k2) = BP.triangulation_args(tp)
+    put(ta, tk)
+    t_out = put(ta, tout)
+    fvn = ("n_nodes", "node_ids", "node_start", "items")
+    put(ta.fv1, dict(zip(fvn, k1))); put(ta.fv2, dict(zip(fvn, k2)))
+    fuse, f_out = [], []
+    for d in range(2):
+        fp = [KP.make_kf_points_problem(6500 + 100 * d + i, 2000, 2000) for i in range(NB)]
+        ks = max(len(q["kf_kps"]) for q in fp)
+        cs = np.zeros((NB, 64 * 48 + 1), np.int32); ci = np.zeros((NB, ks), np.int32)
+        fa, fo, (kk, mk, fk) = KP.fuse_args(fp, cs, ci, th=3.0)
+        put(fa.kf, kk); put(fa.mp, mk); put(fa, fk)
+        f_out.append(put(fa, fo)["best_idx"])
+        fuse.append(fa)
+    s = torch.cuda.current_stream(dev)
+    sp = C.c_void_p(s.cuda_stream)
+    for fa in fuse:   # the neighbours' grids, built by the product's own kernel (KeyFrame::AssignFeaturesToGrid)
+        rc = L.fb_grid_build_batch_dev(C.c_void_p(fa.kf.kf_kps), C.c_void_p(fa.kf.n_kf), NB, fa.kf.kf_stride, C.byref(fa.kf.grid),
+                                       C.c_void_p(fa.kf.kf_cell_start), C.c_void_p(fa.kf.kf_cell_items), sp)
+        if rc != 0:
+            raise RuntimeError(L.fb_last_error().decode())
+    p = synth.make_ba_problem(4000, n_kf=20, n_mp=8000, n_mpb=2000)
+    parts = {"search_for_triangulation_x20": [], "fuse_search_2x20": [], "total": []}
+    for rep in range(reps + 1):
+        ba, dv, keep = ba_problem.local_ba_args_dev(p, device=dev, with_odom=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = L.fb_match_triangulation_dev(C.byref(ta), sp)
+        for fa in fuse:
+            rc = rc or L.fb_fuse_search_dev(C.byref(fa), sp)
+        rc = rc or L.fb_local_ba_dev(C.byref(ba), sp)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        if rc != 0:
+            raise RuntimeError(L.fb_last_error().decode())
+        if rep > 0:
+            parts["total"].append(t3 - t0)
+    # the parts on their own (each with its own synchronisation)
+    for name, fn in (("search_for_triangulation_x20", lambda: L.fb_match_triangulation_dev(C.byref(ta), sp)),
+                     ("fuse_search_2x20", lambda: [L.fb_fuse_search_dev(C.byref(fa), sp) for fa in fuse])):
+        for rep in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            parts[name].append(time.perf_counter() - t0)
+    med = lambda v: sorted(v)[len(v) // 2] * 1e3 if v else None
+    return {"ms_per_key_frame": med(parts["total"]),
+            "triangulation_matches_per_neighbour_mean": float(t_out["nmatches"].float().mean().item()),
+            "fuse_candidates_per_neighbour_mean": float(sum((t >= 0).sum().item() for t in f_out)) / (2 * NB),
+            "parts_ms": {"search_for_triangulation_x20": med(parts["search_for_triangulation_x20"]),
+                                                                 "fuse_search_2x20": med(parts["fuse_search_2x20"])},
+            "workload": "20 neighbours x (2000 x 2000 key points) for M7, 2 x 20 x (2000 map points into 2000 key points) for Fuse, "
+                        "configs[3] BA; device pointers, one stream, one synchronisation at the end",
+            "reference": "LocalMapping.cc:292 (SearchForTriangulation), :513,538 (Fuse), :87-96 (LocalBundleAdjustmentWithOdom)"}
+
+
 def local_ba_leg(L, rank, world_size, local_rank, reps=3):
     """Secondary measurement (not part of `value`): one LocalBundleAdjustmentWithOdom of BASELINE config 4
     (20 keyframes x 8k map points + 2k bird points).  N=1: fb_local_ba; N>1: the same problem landmark-sharded
@@ -736,6 +815,11 @@ def main():
                 fb.check(L.fb_set_device(local_rank), "fb_set_device")  # the HIP device is per thread
                 torch.cuda.set_device(local_rank)
                 box["ba"] = local_ba_leg(L, rank, world_size, local_rank)
+                if world_size == 1:
+                    try:
+                        box["ba"]["local_mapping_chain"] = local_mapping_leg(L, local_rank)
+                    except Exception as e:
+                        box["ba"]["local_mapping_chain"] = {"error": repr(e)[:300]}
             except Exception as e:
                 box["ba"] = {"error": str(e)}
         if world_size > 1:
