@@ -6,8 +6,8 @@
 //   FORB::distance                                                                    Thirdparty/DBoW2/DBoW2/FORB.cpp:85-103
 //   BowVector::addWeight / normalize(L1), FeatureVector::addFeature                   BowVector.cpp:30-84, FeatureVector.cpp:31-45
 //
-// One workgroup per image.  Phase 1: a lane walks one feature down the tree (per level: Hamming distance to the <= k
-// children, first minimum wins).  Phase 2: the (word, feature) keys are bitonic-sorted in LDS; segment heads sum their
+// Phase 1 (k_bow_descend, 64 features per workgroup): a lane walks one feature down the tree (per level: Hamming distance to
+// the <= k children, first minimum wins).  Phases 2 and 3: one workgroup per image.  Phase 2: the (word, feature) keys are bitonic-sorted in LDS; segment heads sum their
 // weights in feature order (the reference's += order), one lane adds the L1 norm in ascending word order (the std::map
 // iteration order), everyone divides.  Phase 3: the same sort on (node, feature) keys yields the FeatureVector CSR.
 #include "fb_common.h"
@@ -50,6 +50,57 @@ __device__ __forceinline__ int bow_excl_scan(int v, int *s_wv, int *total) {
   return base + inc - v;
 }
 
+// Phase 1 on its own grid: 64 features per workgroup.  One workgroup per image walking all of its features kept the whole
+// descent -- 2000 x 12 x 6 random 32-byte reads -- on ONE compute unit's L1 (the largest part of the kernel at batch 1).
+// Results per feature go through the output arrays, which phase 2 reads before it writes anything:
+//   bow_vals[i] = leaf weight, bow_ids[i] = word id, fv_node_ids[i] = node id at nid_level.
+__global__ __launch_bounds__(64) void k_bow_descend(fb_vocabulary V, fb_bow_transform_args A) {
+  const int b = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
+  const size_t fo = (size_t)b * A.f_stride;
+  if (i >= A.n_f[b] || i >= A.f_stride) return;
+  const int nid_level = V.L - A.levelsup;
+  unsigned int nid = 0;
+  uint32_t d[8];
+  const uint4 *dq = reinterpret_cast<const uint4 *>(A.desc + (fo + i) * 32);
+  const uint4 d0 = dq[0], d1 = dq[1];
+  d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+  int final_id = 0, level = 0;
+  int c0 = V.child_start[0], c1 = V.child_start[1];
+  do {
+    ++level;
+    const int cnt = c1 - c0;
+    int best, best_d;
+    if (cnt <= BOW_KMAX) {
+      // the usual k <= 12 children: every child id, then every child descriptor, is requested before the first use (two
+      // memory round trips per level instead of two per child); indices past the node's children are clamped and ignored
+      int ids[BOW_KMAX], dist[BOW_KMAX];
+#pragma unroll
+      for (int u = 0; u < BOW_KMAX; u++) ids[u] = V.children[c0 + min(u, cnt - 1)];
+#pragma unroll
+      for (int u = 0; u < BOW_KMAX; u++) dist[u] = fb::hamming256(d, reinterpret_cast<const uint4 *>(V.descriptors + (size_t)ids[u] * 32));
+      best = ids[0]; best_d = dist[0];
+#pragma unroll
+      for (int u = 1; u < BOW_KMAX; u++)
+        if (u < cnt && dist[u] < best_d) { best_d = dist[u]; best = ids[u]; }  // first minimum wins (TemplatedVocabulary.h:1240-1247)
+    } else {
+      best = V.children[c0];
+      best_d = fb::hamming256(d, reinterpret_cast<const uint4 *>(V.descriptors + (size_t)best * 32));
+      for (int c = c0 + 1; c < c1; c++) {
+        const int id = V.children[c];
+        const int dist = fb::hamming256(d, reinterpret_cast<const uint4 *>(V.descriptors + (size_t)id * 32));
+        if (dist < best_d) { best_d = dist; best = id; }
+      }
+    }
+    final_id = best;
+    if (level == nid_level) nid = (unsigned int)final_id;
+    c0 = V.child_start[final_id];
+    c1 = V.child_start[final_id + 1];
+  } while (c1 > c0 && level < 64);
+  A.bow_vals[fo + i] = V.weights[final_id];
+  A.bow_ids[fo + i] = (uint32_t)V.word_ids[final_id];
+  A.fv_node_ids[fo + i] = nid;
+}
+
 __global__ __launch_bounds__(BOW_T) void k_bow_transform(fb_vocabulary V, fb_bow_transform_args A) {
   __shared__ unsigned long long s_key[BOW_MAXF];
   __shared__ double s_w[BOW_MAXF];        // per feature: leaf weight; later per unique word: summed weight
@@ -57,58 +108,20 @@ __global__ __launch_bounds__(BOW_T) void k_bow_transform(fb_vocabulary V, fb_bow
   __shared__ double s_norm;
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const size_t fo = (size_t)b * A.f_stride;
-  const int n = A.n_f[b];
+  const int n = min(A.n_f[b], A.f_stride);
   int n2 = 1;
   while (n2 < n) n2 <<= 1;
   if (n2 < 2) n2 = 2;
-  const int nid_level = V.L - A.levelsup;
-  // ---- phase 1: descent -------------------------------------------------------------------------------------------
+  // ---- phase 1 happened in k_bow_descend: fetch its per-feature results ---------------------------------------------
   for (int i = tid; i < n2; i += nt) {
     unsigned long long key = KEY_NONE;
-    double w = 0.0;
-    unsigned int nid = 0;
     if (i < n) {
-      uint32_t d[8];
-      const uint4 *dq = reinterpret_cast<const uint4 *>(A.desc + (fo + i) * 32);
-      const uint4 d0 = dq[0], d1 = dq[1];
-      d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
-      int final_id = 0, level = 0;
-      int c0 = V.child_start[0], c1 = V.child_start[1];
-      do {
-        ++level;
-        const int cnt = c1 - c0;
-        int best, best_d;
-        if (cnt <= BOW_KMAX) {
-          // the usual k <= 12 children: every child id, then every child descriptor, is requested before the first use (two
-          // memory round trips per level instead of two per child); indices past the node's children are clamped and ignored
-          int ids[BOW_KMAX], dist[BOW_KMAX];
-#pragma unroll
-          for (int u = 0; u < BOW_KMAX; u++) ids[u] = V.children[c0 + min(u, cnt - 1)];
-#pragma unroll
-          for (int u = 0; u < BOW_KMAX; u++) dist[u] = fb::hamming256(d, reinterpret_cast<const uint4 *>(V.descriptors + (size_t)ids[u] * 32));
-          best = ids[0]; best_d = dist[0];
-#pragma unroll
-          for (int u = 1; u < BOW_KMAX; u++)
-            if (u < cnt && dist[u] < best_d) { best_d = dist[u]; best = ids[u]; }  // first minimum wins (TemplatedVocabulary.h:1240-1247)
-        } else {
-          best = V.children[c0];
-          best_d = fb::hamming256(d, reinterpret_cast<const uint4 *>(V.descriptors + (size_t)best * 32));
-          for (int c = c0 + 1; c < c1; c++) {
-            const int id = V.children[c];
-            const int dist = fb::hamming256(d, reinterpret_cast<const uint4 *>(V.descriptors + (size_t)id * 32));
-            if (dist < best_d) { best_d = dist; best = id; }
-          }
-        }
-        final_id = best;
-        if (level == nid_level) nid = (unsigned int)final_id;
-        c0 = V.child_start[final_id];
-        c1 = V.child_start[final_id + 1];
-      } while (c1 > c0 && level < 64);
-      w = V.weights[final_id];
-      if (w > 0) key = ((unsigned long long)(uint32_t)V.word_ids[final_id] << 32) | (unsigned int)i;
+      const double w = A.bow_vals[fo + i];
+      if (w > 0) key = ((unsigned long long)A.bow_ids[fo + i] << 32) | (unsigned int)i;
+      s_w[i] = w;
+      s_aux[i] = A.fv_node_ids[fo + i];
     }
     s_key[i] = key;
-    if (i < n) { s_w[i] = w; s_aux[i] = nid; }
   }
   if (tid == 0) s_norm = 0.0;
   __syncthreads();
@@ -214,6 +227,7 @@ int fb_bow_transform_dev(const fb_vocabulary *V, const fb_bow_transform_args *A,
   FB_ARG(A->n_f && A->desc && A->n_words && A->bow_ids && A->bow_vals && A->fv_n_nodes && A->fv_node_ids && A->fv_node_start && A->fv_items);
   if (A->batch == 0) return FB_OK;
   fb::ProfScope prof_(fb::P_BOWT, fb::as_stream(stream));
+  k_bow_descend<<<dim3((A->f_stride + 63) / 64, A->batch), 64, 0, fb::as_stream(stream)>>>(*V, *A);
   k_bow_transform<<<A->batch, BOW_T, 0, fb::as_stream(stream)>>>(*V, *A);
   FB_HIP(hipGetLastError());
   return FB_OK;
@@ -235,7 +249,7 @@ int fb_bow_transform(const fb_vocabulary *HV, const fb_bow_transform_args *H) {
   FB_TRY(b0.upload(H->n_f, B * 4)); D.n_f = b0.as<int32_t>();
   FB_TRY(b1.upload(H->desc, B * fs * 32)); D.desc = b1.as<uint8_t>();
   FB_TRY(o0.alloc(B * 4)); D.n_words = o0.as<int32_t>();
-  FB_TRY(o1.upload(H->bow_ids, B * fs * 4)); D.bow_ids = o1.as<uint32_t>();  // copy-in: entries past n keep the caller's contents
+  FB_TRY(o1.upload(H->bow_ids, B * fs * 4)); D.bow_ids = o1.as<uint32_t>();  // copy-in: entries past n_f keep the caller's contents (those in [count, n_f) are scratch)
   FB_TRY(o2.upload(H->bow_vals, B * fs * 8)); D.bow_vals = o2.as<double>();
   FB_TRY(o3.alloc(B * 4)); D.fv_n_nodes = o3.as<int32_t>();
   FB_TRY(o4.upload(H->fv_node_ids, B * fs * 4)); D.fv_node_ids = o4.as<uint32_t>();

@@ -601,7 +601,7 @@ typedef struct fb_vocabulary {
  * TemplatedVocabulary.h:1126-1194, per-feature descent :1217-1259, BowVector::addWeight / normalize(L1)
  * (BowVector.cpp:30-84).  Outputs per image: the BowVector as (word id ascending, value) pairs and the FeatureVector
  * in the CSR form the matchers take (fb_feature_vector).  All output arrays have f_stride entries per image
- * (fv_node_start: f_stride + 1). */
+ * (fv_node_start: f_stride + 1); entries at or beyond the returned counts (and below n_f) are scratch of the call. */
 typedef struct fb_bow_transform_args {
   int32_t batch;
   int32_t f_stride;
