@@ -491,7 +491,8 @@ __device__ __forceinline__ void odom_body(const BADev &D, const State &S, const 
   __syncthreads();
   if (tid == 0) {
     double s = 0;
-    for (int i = 0; i < 256; i++) s += s_chi[i];
+    const int nl = D.nO < 256 ? D.nO : 256;  // lanes at or beyond nO hold 0: the same sum in the same order without them
+    for (int i = 0; i < nl; i++) s += s_chi[i];
     B.chiPart[chiSlot] = s;
   }
   // phase b: lane (k, i) = row i of free pose k.  The row's diagonal block and right-hand side entry are accumulated in

@@ -851,15 +851,22 @@ __global__ __launch_bounds__(256) void k_grid_build(const fb_keypoint *__restric
   const int c0 = min(tid * chunk, ncell), c1 = min(c0 + chunk, ncell);
   int s = 0;
   for (int c = c0; c < c1; c++) s += cnt[c];
-  s_part[tid] = s;
-  __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int t = 0; t < nt; t++) { const int v = s_part[t]; s_part[t] = run; run += v; }
-    cnt[ncell] = run;
+  // exclusive scan of the 256 chunk sums: shuffles inside a wave, four wave totals through LDS (one lane walking the 256
+  // partials in LDS was half of this kernel at batch 1)
+  int run;
+  {
+    const int lane = tid & 63, wv = tid >> 6;
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) s_part[wv] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < (nt >> 6); w++) { const int x = s_part[w]; if (w < wv) base += x; tot += x; }
+    run = base + inc - s;
+    if (tid == 0) cnt[ncell] = tot;
+    __syncthreads();
   }
-  __syncthreads();
-  int run = s_part[tid];
   for (int c = c0; c < c1; c++) { const int v = cnt[c]; cnt[c] = run; fillp[c] = run; run += v; }
   __syncthreads();
   for (int i = tid; i < nk; i += nt) {

@@ -5,6 +5,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r03f; mkdir -p $O
 python3 -m pytest tests -x -q -m gpu -s > $O/r03_gpu_tests.log 2>&1
+python3 -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 tail -2 $O/r03_gpu_tests.log
 python3 bench.py > $O/r03_bench_b256.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/ba -o ba -- python3 profiles/probes/ba_run.py 7 > $O/ba.log 2>&1
