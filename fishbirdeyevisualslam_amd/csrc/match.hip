@@ -164,6 +164,21 @@ __device__ __forceinline__ TargetLds stage_target(uint8_t *smem, const Carve &cv
 // Hamming distances are done once; a query whose cached candidates are all taken and whose cache is incomplete
 // falls back to the full walk.  cacheK = 0 (LDS too small) keeps the full walk every round.
 constexpr int CACHE_K = 4;
+// (Measured and dropped, round 3: round 0 -- projection, grid walk and distances of every query -- is 78 % of this kernel for
+// one frame (profiles/probes/m3_stamps.py), so it was moved to its own grid of 256-query workgroups with the serial rule
+// resolved on candidate lists afterwards, as M2 does.  Same results, no gain: 94 instead of 97 us per frame at batch 1 (a
+// query's walk is a chain of dependent loads that is as long on its own workgroup, and the second kernel stages the grid
+// again), and 0.226 instead of 0.137 ms per step at batch 256.)
+#ifdef FB_MATCH_STAMPS
+__device__ unsigned long long g_m3_stamps[8];  // probe build only (block 0): staging | order | round 0 | later rounds | commit | rounds | launches
+#define M3_T0() unsigned long long mt_ = 0; if (blockIdx.x == 0 && threadIdx.x == 0) mt_ = __builtin_amdgcn_s_memtime();
+#define M3_TICK(slot_) if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_m3_stamps[slot_], t_ - mt_); mt_ = t_; }
+#define M3_COUNT(slot_) if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_m3_stamps[slot_], 1ull);
+#else
+#define M3_T0()
+#define M3_TICK(slot_)
+#define M3_COUNT(slot_)
+#endif
 
 __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args A, int cacheK, int descInLds) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -173,6 +188,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
   const int ncell = A.grid.cols * A.grid.rows;
   const size_t co = (size_t)b * A.cur_stride, lo = (size_t)b * A.last_stride;
   const int ncur = A.n_cur[b], nlast = A.n_last[b];
+  M3_T0()
   const Carve cv(A.cur_stride, ncell, descInLds != 0);
   const TargetLds T = stage_target(smem, cv, ncur, ncell, A.cur_kps + co, A.cur_desc + co * 32,
                                    A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co, descInLds != 0);
@@ -191,6 +207,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
   for (int i = tid; i < ncur; i += nt) ownerA[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
   for (int q = tid; q < nlast; q += nt) assignA[q] = NONE16;
   __syncthreads();
+  M3_TICK(0)
   // The search radius depends only on the octave: hand the lanes of a wave queries of the same octave so that their
   // grid walks have the same length (the query INDEX keeps deciding priorities, only the processing order changes).
   auto oct_bin = [&](int q) -> int {
@@ -206,6 +223,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
   __syncthreads();
   for (int q = tid; q < nlast; q += nt) perm[atomicAdd(&s_oct[oct_bin(q)], 1)] = (u16)q;
   __syncthreads();
+  M3_TICK(1)
 
   // full grid walk of query q against the claims in `owner`; fill = also (re)build the query's cache
   auto full_search = [&](int q, const int *owner, bool fill) -> int {
@@ -288,6 +306,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
     int *t = ownerA; ownerA = ownerB; ownerB = t;
     u16 *t16 = assignA; assignA = assignB; assignB = t16;
     __syncthreads();
+    if (round == 0) { M3_TICK(2) } else { M3_TICK(3) }
+    M3_COUNT(5)
     if (!changed) break;
   }
 
@@ -327,6 +347,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
   }
   for (int i = tid; i < ncur; i += nt) A.match_cur_to_last[co + i] = matchL[i];
   if (tid == 0) A.nmatches[b] = s_n;
+  M3_TICK(4)
+  M3_COUNT(6)
 }
 
 // ---------------------------------------------------------------------------------------
@@ -822,17 +844,21 @@ __global__ void k_descriptor_distance(const uint4 *__restrict__ a, const uint4 *
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_grid_build(const fb_keypoint *__restrict__ kps, const int32_t *__restrict__ n,
                                                     int kp_stride, fb_grid_geom g, int32_t *__restrict__ cell_start,
-                                                    int32_t *__restrict__ cell_items) {
+                                                    int32_t *__restrict__ cell_items, int itemsInLds) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int ncell = g.cols * g.rows;
   int *cnt = reinterpret_cast<int *>(smem);  // [ncell+1]
   int *fillp = cnt + ncell + 1;              // [ncell]
+  // the items are scattered, sorted per cell and written out from LDS (itemsInLds): the per-cell insertion sort on the
+  // global array was a chain of dependent global accesses per cell, 12 cells per lane -- most of this kernel at batch 1
+  int *li = fillp + ncell;                   // [kp_stride] when itemsInLds
   __shared__ int s_part[256];
   const fb_keypoint *k = kps + (size_t)b * kp_stride;
   int32_t *cs = cell_start + (size_t)b * (ncell + 1);
-  int32_t *ci = cell_items + (size_t)b * kp_stride;
-  const int nk = n[b];
+  int32_t *cig = cell_items + (size_t)b * kp_stride;
+  int *ci = itemsInLds ? li : cig;
+  const int nk = min(max(n[b], 0), kp_stride);
   for (int i = tid; i <= ncell; i += nt) cnt[i] = 0;
   __syncthreads();
   auto cell_of = [&](const fb_keypoint &kp) -> int {
@@ -885,6 +911,11 @@ __global__ __launch_bounds__(256) void k_grid_build(const fb_keypoint *__restric
     }
   }
   for (int i = tid; i <= ncell; i += nt) cs[i] = cnt[i];
+  if (itemsInLds) {
+    __syncthreads();
+    const int nitems = cnt[ncell];
+    for (int i = tid; i < nitems; i += nt) cig[i] = li[i];
+  }
 }
 
 // Frame.cc:365-373: BirdPixel2BaseXY (Converter.cc:284-292) then BaseXY2CamXYZ (:312-318)
@@ -975,11 +1006,13 @@ int fb_grid_build_batch_dev(const fb_keypoint *d_keypoints, const int32_t *d_n, 
   FB_ARG(geom && batch >= 0 && kp_stride > 0 && geom->cols > 0 && geom->rows > 0);
   if (batch == 0) return FB_OK;
   const int ncell = geom->cols * geom->rows;
-  const size_t lds = (size_t)(2 * ncell + 1) * 4;
+  size_t lds = (size_t)(2 * ncell + 1) * 4 + (size_t)kp_stride * 4;
+  int itemsInLds = 1;
+  if (lds > LDS_BUDGET) { itemsInLds = 0; lds = (size_t)(2 * ncell + 1) * 4; }
   FB_TRY(check_lds(lds, "fb_grid_build_batch_dev"));
   FB_TRY(set_max_lds(k_grid_build, lds));
   fb::ProfScope prof_(fb::P_GRID, fb::as_stream(stream));
-  k_grid_build<<<batch, 256, lds, fb::as_stream(stream)>>>(d_keypoints, d_n, kp_stride, *geom, d_cell_start, d_cell_items);
+  k_grid_build<<<batch, 256, lds, fb::as_stream(stream)>>>(d_keypoints, d_n, kp_stride, *geom, d_cell_start, d_cell_items, itemsInLds);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -1038,6 +1071,12 @@ int fb_match_projection_keyframe_dev(const fb_proj_kf_args *A, void *stream) {
 }
 
 #ifdef FB_MATCH_STAMPS
+int fb_match_debug_m3(unsigned long long *dst8) {  // probe build only
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  FB_HIP(hipMemcpyFromSymbol(dst8, HIP_SYMBOL(g_m3_stamps), sizeof(z)));
+  FB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_m3_stamps), z, sizeof(z)));
+  return FB_OK;
+}
 int fb_match_debug_m2(int *dst4) {  // probe build only
   int z[4] = {0, 0, 0, 0};
   FB_HIP(hipMemcpyFromSymbol(dst4, HIP_SYMBOL(g_m2_rounds), sizeof(z)));

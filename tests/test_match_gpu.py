@@ -134,3 +134,17 @@ def test_birdview_match(seed, ncur, nref):
         out = _both(lambda: P.birdview_args(probs, cs, ci, check_ori=ori), "orc_match_birdview", "fb_match_birdview",
                     ["match_ref_to_cur", "match_dist", "nmatches", "n_dmatches"])
         assert out["nmatches"].min() > 10
+
+
+def test_one_kernel_version_of_search_local_points():
+    """The host-pointer entry point of M2 runs the two-phase matcher (candidate lists by many workgroups, then the serial rule
+    on the lists); FB_M2_ONE_KERNEL (read once per process, hence a child process) selects the one-workgroup-per-frame
+    kernel a _dev caller without a workspace gets.  Same parity bar."""
+    import os, subprocess, sys
+    env = dict(os.environ, FB_M2_ONE_KERNEL="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_match_gpu.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "search_by_projection_points", "-p", "no:cacheprovider"],
+                       env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
