@@ -144,6 +144,7 @@ struct Commit {  // the matcher result a frame has not folded into mvpMapPoints 
   int lcap_mpb;
   const int32_t *gate;        // kind 3: the matcher's count row; a sequence below gate_min "returned false" (Tracking.cc:1212):
   int gate_min;               //         no commit, no edges (the optimiser then leaves pose and flags alone)
+  int no_front;               // BirdOptimization (Optimizer.cc:708-835) builds bird edges only
 };
 __device__ __forceinline__ bool commit_gate_open(const Commit &C, int b) { return !C.gate || C.gate[b] >= C.gate_min; }
 __device__ __forceinline__ void commit_slot(const FrameDev &F, const Commit &C, int b, int i, size_t o, int &id, int &idb) {
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(TT) void k_edges(FrameDev F, MapDev map, BirdMapDev
   int id, idb;
   commit_slot(F, C, b, i, o, id, idb);
   if (!commit_gate_open(C, b)) { id = -1; idb = -1; }
+  if (C.no_front) id = -1;
   if (id >= 0) {
     const fb_keypoint kp = F.kps_un[o];
     const float *X = map.xw + ((size_t)b * map.stride + id) * 3;
@@ -1018,6 +1020,23 @@ int fb_frame_compute_bow_dev(fb_frame *f, const fb_vocabulary *voc, void *stream
   FB_TRY(fb_bow_transform_dev(voc, &A, stream));
   f->bowDone = true;
   return FB_OK;
+}
+
+int fb_frame_track_using_bird_dev(fb_frame *cur, fb_frame *src, fb_frame *ref, const fb_track_args *T, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(cur && src && ref && cur != src && cur != ref && cur->B == src->B && cur->cap == src->cap && cur->B == ref->B && cur->cap == ref->cap);
+  FB_ARG(track_args_ok(cur, T) && T->d_delta);
+  hipStream_t s = fb::as_stream(stream);
+  fb_map_points_bird mpb = T->mpb;
+  FB_TRY(fb_frame_predict_pose_dev(cur, src, T->d_delta, s));                                          // :2016-2034
+  FB_TRY(m9_impl(cur, &mpb, T->d_local_mpb, T->d_n_local_mpb, 10, 0.05f, &M09, s));                    // :2036
+  FB_TRY(launch_commit(cur, commit_m9(cur, T->d_local_mpb), s));
+  FB_TRY(bird_points_impl(cur, ref, &mpb, 10, 0.05f, &M09, 11, s));                                    // :2038-2053: only where numPt <= 10
+  Commit C;
+  memset(&C, 0, sizeof(C));
+  C.no_front = 1;
+  FB_TRY(edges_and_pose(cur, &T->map, &mpb, FB_POSE_BIRD, 1.0f, 1.0f, 0, C, s));                       // BirdOptimization(&mCurrentFrame, 1.0)
+  return bird_points_impl(cur, ref, &mpb, 10, 0.05f, &M09, 0, s);                                      // :2056
 }
 
 int fb_frame_copy_dev(fb_frame *dst, const fb_frame *src, void *stream) {

@@ -222,6 +222,11 @@ class TrackChain:
         (TrackReferenceKeyFrame) or "motion+reference" (the fall-back when the motion model fails), then TrackLocalMap."""
         L, s, cur, last = self.L, self._stream(), self.cur, self.last
         self.extract(front, bird, contour, mask)
+        if mode in ("bird", "bird_kf"):   # Tracking::TrackUsingBird (Tracking.cc:2014-2061): no TrackLocalMap behind it (:556)
+            src, args = (self.kf, self.targs_kf) if mode == "bird_kf" else (last, self.targs)
+            check(L.fb_frame_track_using_bird_dev(cur, src, last, C.byref(args), s), "fb_frame_track_using_bird_dev")
+            self.k += 1
+            return
         if "motion" in mode:
             check(L.fb_frame_track_motion_model_dev(cur, last, C.byref(self.targs), s), "fb_frame_track_motion_model_dev")
         if "reference" in mode:

@@ -882,6 +882,12 @@ int fb_frame_track_dev(fb_frame *cur, fb_frame *last, const fb_track_args *args,
 int fb_frame_track_motion_model_dev(fb_frame *cur, fb_frame *last, const fb_track_args *args, void *stream);
 int fb_frame_track_local_map_dev(fb_frame *cur, fb_frame *ref, const fb_track_args *args, void *stream);
 
+/* Tracking::TrackUsingBird (Tracking.cc:2014-2061: the frame of a LOST tracker that could not re-initialise, bHaveBird):
+ * SetPose(detlaT * src pose) with src = mpReferenceKF's handle (IsbirdWithRefKF == 1) or tmpRefFrame, GetLocalMapForBird,
+ * GetPerFrameMatchedBirdPoints against `ref` first for the sequences with numPt <= 10 (FB_CNT_BIRD_POINTS),
+ * Optimizer::BirdOptimization(&frame, 1.0) (bird edges only; inliers -> FB_CNT_POSE1_INLIERS), GetPerFrameMatchedBirdPoints. */
+int fb_frame_track_using_bird_dev(fb_frame *cur, fb_frame *src, fb_frame *ref, const fb_track_args *args, void *stream);
+
 /* Frame(const Frame &) (Frame.cc:49-82: tmpRefFrame = new Frame(mCurrentFrame), Tracking.cc:746) and the member copies of
  * KeyFrame::KeyFrame(Frame &F, ...) (KeyFrame.cc:32-91): every member array of src into dst (same parameters), device to
  * device on the stream, including the BoW when src has it.                                                               */

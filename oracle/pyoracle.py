@@ -236,6 +236,15 @@ class OracleChain:
         self.extract(front, bird, contour, mask)
         self.keep["delta"] = np.ascontiguousarray(delta, np.float32)
         cabi.fill(self.targs, d_delta=self.keep["delta"])
+        if mode in ("bird", "bird_kf"):
+            if mode == "bird_kf":
+                self.keep["delta_kf"] = np.ascontiguousarray(delta_kf, np.float32)
+                cabi.fill(self.targs, d_delta=self.keep["delta_kf"])
+            src = self.kf if mode == "bird_kf" else self.last
+            assert self.L.orc_frame_track_using_bird(self.cur, src, self.last, C.byref(self.targs)) == 0
+            cabi.fill(self.targs, d_delta=self.keep["delta"])
+            self.k += 1
+            return
         if "motion" in mode:
             assert self.L.orc_frame_track_motion_model(self.cur, self.last, C.byref(self.targs)) == 0
         if "reference" in mode:

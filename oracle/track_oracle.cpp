@@ -11,6 +11,7 @@
  *                                      FilterBirdOutlierInFront :1825-1914, SearchLocalPoints :1947-1997,
  *                                      GetLocalMapForBird :1999-2012
  *   end of Tracking::Track             :690-701 (clean VO matches), :721-725 (drop outliers)
+ *   Tracking::TrackUsingBird           :2014-2061
  *   Tracking::TrackReferenceKeyFrame   :1180-1244 with Frame::ComputeBoW (Frame.cc:628-635); the reference key frame is a
  *                                      frame object (a KeyFrame is built from one, KeyFrame.cc:32-91)
  * mvpMapPoints / mvpMapPointsBird are indices into the caller's map tables (-1 = NULL), like the product's fb_frame.
@@ -69,14 +70,15 @@ double now() { return std::chrono::duration<double>(std::chrono::steady_clock::n
 int *cnt(orc_frame *f, int slot) { return f->counts.data() + (size_t)slot * f->B; }
 
 // Edge construction of PoseOptimizationWithBird (Optimizer.cc:525-602) from the frame's members, then the optimiser
-void pose_optimization(orc_frame *f, const fb_map_points *map, const fb_map_points_bird *mpb, int mode, float wB, float wF, int slot) {
+void pose_optimization(orc_frame *f, const fb_map_points *map, const fb_map_points_bird *mpb, int mode, float wB, float wF, int slot,
+                       bool front = true) {
   const size_t B = f->B, cap = f->cap;
   std::vector<float> fxw(B * cap * 3), fobs(B * cap * 2), finf(B * cap), bxw(B * cap * 3), bxc(B * cap * 3), binf(B * cap);
   std::vector<uint8_t> fv(B * cap, 0), bv(B * cap, 0);
   for (size_t b = 0; b < B; b++) {
     for (int i = 0; i < f->n[b]; i++) {
       const size_t o = b * cap + i;
-      const int id = f->mp[o];
+      const int id = front ? f->mp[o] : -1;  // BirdOptimization builds no front edges
       if (id < 0) continue;
       const fb_keypoint &kpUn = f->kps_un[o];
       fv[o] = 1;
@@ -598,6 +600,18 @@ int orc_frame_track_reference(orc_frame *cur, orc_frame *kf, orc_frame *last, co
     cur->n = n_keep; cur->nb = nb_keep;
   }
   discard_outliers(cur, map, FB_CNT_BOW_MATCHES, true, FB_CNT_BOW_MATCHES, 15);   // :1222-1241
+  return FB_OK;
+}
+
+// Tracking::TrackUsingBird (Tracking.cc:2014-2061); src = mpReferenceKF or tmpRefFrame, last = tmpRefFrame
+int orc_frame_track_using_bird(orc_frame *cur, orc_frame *src, orc_frame *last, const fb_track_args *T) {
+  const fb_map_points *map = &T->map;
+  fb_map_points_bird mpbv = T->mpb;
+  set_predicted_pose(cur, src, T->d_delta);                      // :2016-2034
+  local_map_for_bird(cur, T, &mpbv);                             // :2036
+  per_frame_matched_bird_points(cur, last, &mpbv, 11);           // :2038-2053: else branch (numPt <= 10) matches first
+  pose_optimization(cur, map, &mpbv, FB_POSE_BIRD, 1.0f, 1.0f, FB_CNT_POSE1_INLIERS, false);   // BirdOptimization(&mCurrentFrame, 1.0)
+  per_frame_matched_bird_points(cur, last, &mpbv, 0);            // :2056
   return FB_OK;
 }
 

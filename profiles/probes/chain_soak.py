@@ -24,7 +24,7 @@ while time.time() - t0 < budget:
     desc = "seed=%d %s B=%d K=%d %s" % (seed, wh, B, K, kw)
     try:
         if g.random() < ref_share:   # drives that mix TrackWithMotionModel, TrackReferenceKeyFrame and the fall-back
-            modes = {k: str(g.choice(["motion", "reference", "motion+reference"])) for k in range(1, K)}
+            modes = {k: str(g.choice(["motion", "reference", "motion+reference", "bird", "bird_kf"], p=[0.3, 0.25, 0.2, 0.15, 0.1])) for k in range(1, K)}
             rekey = tuple(int(k) for k in range(1, K) if g.random() < 0.3)
             pick = lambda: int(g.integers(0, B)) if g.random() < 0.4 else None
             desc = "seed=%d %s B=%d K=%d modes=%s rekey=%s" % (seed, wh, B, K, modes, rekey)

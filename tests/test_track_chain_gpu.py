@@ -261,6 +261,15 @@ def test_chain_reference_keyframe_path():
     print("reference-key-frame path: %s, worst relative pose difference %.3g" % (seen, worst))
 
 
+def test_chain_track_using_bird():
+    """Tracking::TrackUsingBird (Tracking.cc:2014-2061), the frame of a lost tracker: pose from the last frame or from the
+    reference key frame, GetLocalMapForBird, the numPt <= 10 branch (sequence 1: a short vlocalMPB list), BirdOptimization
+    (bird edges only), GetPerFrameMatchedBirdPoints; then the tracker finds its way back through the reference key frame."""
+    modes = {1: "motion", 2: "bird", 3: "bird_kf", 4: "reference", 5: "bird", 6: "motion+reference"}
+    seen, worst = _run_modes(2, 7, (640, 480), (384, 384), 250.0, 9900, modes, rekey_at=(1,), short_list_seq=1, verbose=True)
+    print("track-using-bird path: worst relative pose difference %.3g" % worst)
+
+
 def test_frame_bow_entry_points_against_the_array_api():
     """fb_frame_compute_bow_dev / fb_frame_bow_view_dev / fb_frame_search_by_bow_dev on frame handles give what the array
     entry points (fb_bow_transform, fb_match_bow: oracle-checked in test_bow_transform.py / test_bow_gpu.py) give on the
