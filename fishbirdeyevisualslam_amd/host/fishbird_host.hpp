@@ -547,6 +547,12 @@ class DeviceFrame {
     check(fb_frame_track_reference_dev(h_, referenceKF.h_, tmpRefFrame.h_, &d_voc, &T, stream));
     return Result(stream);
   }
+  // Tracking::TrackUsingBird (Tracking.cc:2014-2061): poseSource = mpReferenceKF's handle (IsbirdWithRefKF == 1) or tmpRefFrame
+  TrackResult TrackUsingBird(DeviceFrame &poseSource, DeviceFrame &tmpRefFrame, const DeviceMap &map, const float *d_deltaT, void *stream = nullptr) {
+    const fb_track_args T = Args(map, d_deltaT, 1.f, 1.f);
+    check(fb_frame_track_using_bird_dev(h_, poseSource.h_, tmpRefFrame.h_, &T, stream));
+    return Result(stream);
+  }
   TrackResult TrackLocalMap(DeviceFrame &tmpRefFrame, const DeviceMap &map, float wB = 1.f, float wF = 1.f, void *stream = nullptr) {
     const fb_track_args T = Args(map, nullptr, wB, wF);
     check(fb_frame_track_local_map_dev(h_, tmpRefFrame.h_, &T, stream));
