@@ -79,7 +79,7 @@ class ProjFrameArgs(C.Structure):
                 ("n_last", _vp), ("last_valid", _vp), ("last_obs_pos", _vp), ("last_xw", _vp),
                 ("last_desc", _vp), ("last_octave", _vp), ("last_angle", _vp),
                 ("cam", Camera), ("grid", GridGeom), ("scale_factors", _f32 * FB_MAX_LEVELS), ("th", _f32),
-                ("matcher", MatcherParams), ("match_cur_to_last", _vp), ("nmatches", _vp)]
+                ("matcher", MatcherParams), ("match_cur_to_last", _vp), ("nmatches", _vp), ("retry_below", _i32), ("retry_th", _f32), ("retried", _vp)]
 
 
 class BirdMpArgs(C.Structure):
@@ -260,7 +260,7 @@ class FrameView(C.Structure):
 
 
 FB_CNT = dict(BIRD_KF_MATCHES=0, PROJ_MATCHES=1, POSE1_INLIERS=2, MATCHES=3, MATCHES_MAP=4, BIRDVIEW_MATCHES=5, BIRD_INLIERS=6,
-              BIRD_NEW=7, TO_MATCH=8, LOCAL_MATCHES=9, POSE2_INLIERS=10, MATCHES_INLIERS=11, BOW_MATCHES=12, BIRD_POINTS=13)
+              BIRD_NEW=7, TO_MATCH=8, LOCAL_MATCHES=9, POSE2_INLIERS=10, MATCHES_INLIERS=11, BOW_MATCHES=12, BIRD_POINTS=13, PROJ_RETRIED=14)
 FB_CNT_COUNT = 16
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), _i32, _i32)

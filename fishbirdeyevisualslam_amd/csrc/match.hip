@@ -204,8 +204,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
   if (tid < 12) s_T[tid] = A.cur_Tcw[(size_t)b * 12 + tid];
   if (tid <= FB_MAX_LEVELS) s_oct[tid] = 0;
   const uint8_t *blocked0 = A.cur_blocked ? A.cur_blocked + co : nullptr;
-  for (int i = tid; i < ncur; i += nt) ownerA[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
-  for (int q = tid; q < nlast; q += nt) assignA[q] = NONE16;
+  float thEff = A.th;   // the second attempt (retry_below > 0 and fewer matches than that) searches with retry_th
   __syncthreads();
   M3_TICK(0)
   // The search radius depends only on the octave: hand the lanes of a wave queries of the same octave so that their
@@ -243,7 +242,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
         const float v = A.cam.fy * yc * invzc + A.cam.cy;
         if (!(u < A.cam.min_x || u > A.cam.max_x) && !(v < A.cam.min_y || v > A.cam.max_y)) {
           const int oct = A.last_octave[lo + q];
-          const float radius = A.th * A.scale_factors[oct];
+          const float radius = thEff * A.scale_factors[oct];
           uint32_t d[8];
           const uint4 *dq = reinterpret_cast<const uint4 *>(A.last_desc + (lo + q) * 32);
           const uint4 d0 = dq[0], d1 = dq[1];
@@ -279,6 +278,12 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
     return best;
   };
 
+  // Tracking.cc:1339-1349 in one launch: nmatches = SearchByProjection(th); if (nmatches < 20) { fill(mvpMapPoints, NULL);
+  // nmatches = SearchByProjection(2 * th); } -- the second search starts from scratch on the staged frame
+  for (int attempt = 0; attempt < 2; attempt++) {
+  for (int i = tid; i < ncur; i += nt) ownerA[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
+  for (int q = tid; q < nlast; q += nt) assignA[q] = NONE16;
+  __syncthreads();
   for (int round = 0; round <= nlast + 1; round++) {
     for (int i = tid; i < ncur; i += nt) ownerB[i] = (blocked0 && blocked0[i]) ? -1 : NONE;
     if (tid == 0) s_changed = 0;
@@ -345,8 +350,17 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
     }
     __syncthreads();
   }
+  __syncthreads();
+  if (attempt == 0 && A.retry_below > 0 && s_n < A.retry_below) {  // (workgroup-uniform)
+    thEff = A.retry_th;
+    // matchL / binQ alias ownerB / assignB: which of the two buffers holds what is irrelevant for a search from scratch
+    __syncthreads();
+    continue;
+  }
   for (int i = tid; i < ncur; i += nt) A.match_cur_to_last[co + i] = matchL[i];
-  if (tid == 0) A.nmatches[b] = s_n;
+  if (tid == 0) { A.nmatches[b] = s_n; if (A.retried) A.retried[b] = attempt; }
+  break;
+  }
   M3_TICK(4)
   M3_COUNT(6)
 }
@@ -1169,6 +1183,7 @@ int fb_match_projection_frame(const fb_proj_frame_args *H) {
   UP(b13, last_angle, B * ls * 4)
   OUT(match_cur_to_last, B * cs * 4, true)  // copy-in: entries past n keep the caller's contents
   OUT(nmatches, B * 4, false)
+  if (H->retried) { OUT(retried, B * 4, false) } else D.retried = nullptr;
   FB_ARG(H->match_cur_to_last && H->nmatches);
   FB_TRY(st.commit(nullptr));
   FB_TRY(fb_match_projection_frame_dev(&D, nullptr));

@@ -772,7 +772,8 @@ int m9_impl(fb_frame *cur, const fb_map_points_bird *mpb, const int32_t *d_local
   return fb_match_bird_mappoints_dev(&A, s);
 }
 
-int m3_impl(fb_frame *cur, const fb_frame *last, const fb_map_points *map, float th, const fb_matcher_params *matcher, hipStream_t s) {
+int m3_impl(fb_frame *cur, const fb_frame *last, const fb_map_points *map, float th, const fb_matcher_params *matcher, hipStream_t s,
+            int retry_below = 0) {
   M3Scratch S{cur->m3_valid.as<uint8_t>(), cur->m3_obs.as<uint8_t>(), cur->m3_xw.as<float>(), cur->m3_desc.as<uint8_t>(),
               cur->m3_oct.as<int32_t>(), cur->m3_ang.as<float>()};
   { fb::ProfScope prof_(fb::P_TRACK_GLUE, s);
@@ -790,6 +791,8 @@ int m3_impl(fb_frame *cur, const fb_frame *last, const fb_map_points *map, float
   for (int i = 0; i < FB_MAX_LEVELS; i++) A.scale_factors[i] = cur->tab.scale_factor[i];
   A.th = th; A.matcher = *matcher;
   A.match_cur_to_last = cur->m_front.as<int32_t>(); A.nmatches = cur->cnt(FB_CNT_PROJ_MATCHES);
+  A.retry_below = retry_below; A.retry_th = 2.0f * th;   // Tracking.cc:1342-1349
+  A.retried = retry_below > 0 ? cur->cnt(FB_CNT_PROJ_RETRIED) : nullptr;
   return fb_match_projection_frame_dev(&A, s);
 }
 
@@ -893,11 +896,14 @@ int motion_model_impl(fb_frame *cur, fb_frame *last, const fb_track_args *T, hip
   fb_map_points_bird mpb = T->mpb;
   FB_TRY(fb_frame_predict_pose_dev(cur, last, T->d_delta, s));                                         // :1314-1320
   FB_TRY(m9_impl(cur, &mpb, T->d_local_mpb, T->d_n_local_mpb, 10, 0.05f, &M09, s));                    // :1322-1323 -> :1999-2012
-  FB_TRY(m3_impl(cur, last, &T->map, 15.0f, &M09, s));                                                 // :1339
+  FB_TRY(m3_impl(cur, last, &T->map, 15.0f, &M09, s, 20));                                             // :1339-1349 (incl. the 2 * th retry)
   Commit C1 = commit_m9(cur, T->d_local_mpb);
   C1.match = cur->m_front.as<int32_t>(); C1.src_mp = last->mp.as<int32_t>(); C1.src_stride = cur->cap;
+  // if (nmatches < 20) return false (:1351): the matches are committed, but such a sequence gets no edges (the optimiser leaves
+  // its pose and flags alone) and no discard loop
+  C1.gate = cur->cnt(FB_CNT_PROJ_MATCHES); C1.gate_min = 20;
   FB_TRY(edges_and_pose(cur, &T->map, &mpb, FB_POSE_FRONT_BIRD, T->wB, T->wF, 0, C1, s));              // :1353
-  return discard_impl(cur, &T->map, FB_CNT_PROJ_MATCHES, 0, s);                                        // :1358-1376
+  return discard_impl(cur, &T->map, FB_CNT_PROJ_MATCHES, 20, s);                                       // :1358-1376
 }
 
 // TrackLocalMap (Tracking.cc:1387-1441) + the end of Track (:1411-1424, 690-701, 721-725)

@@ -245,6 +245,10 @@ class TrackChain:
         check(L.fb_frame_predict_pose_dev(cur, last, C.c_void_p(self.delta.data_ptr()), s), "predict")
         check(L.fb_frame_bird_mappoint_match_dev(cur, C.byref(T.mpb), lb[0], lb[1], 10, C.c_float(0.05), C.byref(m09), s), "M9")
         check(L.fb_frame_search_by_projection_dev(cur, last, C.byref(T.map), C.c_float(15.0), C.byref(m09), s), "M3")
+        # the host's part of Tracking.cc:1342-1352 (wide-window retry, return false below 20 matches) is per sequence; these
+        # entry points move all sequences of the handle in lockstep, so a batch that diverges there must be split by the host
+        if (self.counts("cur")[0][cabi.FB_CNT["PROJ_MATCHES"]] < 20).any():
+            raise NotImplementedError("granular entry points: a sequence has fewer than 20 matches (retry / early return is per sequence)")
         check(L.fb_frame_pose_optimization_dev(cur, C.byref(T.map), C.byref(T.mpb), cabi.FB_POSE_FRONT_BIRD, C.c_float(1.0), C.c_float(1.0), 0, s), "pose 1")
         check(L.fb_frame_discard_outliers_dev(cur, C.byref(T.map), s), "discard")
         check(L.fb_frame_match_bird_points_dev(cur, last, C.byref(T.mpb), 10, C.c_float(0.05), C.byref(m09), s), "M8 + filter")

@@ -256,6 +256,12 @@ typedef struct fb_proj_frame_args {
   /* outputs */
   int32_t *match_cur_to_last; /* [batch][cur_stride]: index into last, or -1   */
   int32_t *nmatches;          /* [batch] return value                          */
+  /* Tracking.cc:1342-1349 in the same launch: a frame whose search returned fewer than retry_below matches (20 there) is
+   * searched again from scratch with retry_th (2 * th there); match_cur_to_last / nmatches then hold the second result.
+   * retry_below = 0: one search.                                              */
+  int32_t retry_below;
+  float retry_th;
+  int32_t *retried;           /* [batch] or NULL: 1 = the second search ran     */
 } fb_proj_frame_args;
 int fb_match_projection_frame_dev(const fb_proj_frame_args *args, void *stream);
 int fb_match_projection_frame(const fb_proj_frame_args *args); /* host pointers */
@@ -800,6 +806,7 @@ enum {
   FB_CNT_MATCHES_INLIERS,     /* mnMatchesInliers                                    Tracking.cc:1411-1424              */
   FB_CNT_BOW_MATCHES,         /* nmatches = SearchByBoW(mpReferenceKF, cur, ...)     Tracking.cc:1207                   */
   FB_CNT_BIRD_POINTS,         /* numPt = GetBirdMapPointsNum()                       Tracking.cc:1196                   */
+  FB_CNT_PROJ_RETRIED,        /* 1 = SearchByProjection ran again with 2 * th        Tracking.cc:1342-1349              */
   FB_CNT_COUNT = 16
 };
 
@@ -865,7 +872,8 @@ int fb_frame_finish_dev(fb_frame *f, const fb_map_points *map, void *stream);
 /* The OK-state path of Tracking::Track in one call: TrackWithMotionModel (Tracking.cc:1312-1385) + TrackLocalMap
  * (:1387-1441) + the end-of-Track clean-up, i.e. predict_pose, M9, M3 (th = 15), PoseOptimizationWithBird, discard,
  * M8 + filter (window 10, 0.05 m), SearchLocalPoints (th = 1, nnratio 0.8), PoseOptimizationWithBird, finish --
- * optimistically: the host checks the counters afterwards (nmatches < 20 -> its own retry with 2 * th, :1342-1349).     */
+ * per sequence as the reference does: the 2 * th retry of :1342-1349 runs inside the matcher launch, and a sequence that
+ * still has fewer than 20 matches "returns false" (:1351): its matches stay committed, pose and flags are left alone.   */
 typedef struct fb_track_args {
   fb_map_points map;
   fb_map_points_bird mpb;

@@ -303,6 +303,21 @@ void search_by_projection_last(orc_frame *cur, const orc_frame *last, const fb_m
     A.th = 15.0f; A.matcher.nnratio = 0.9f; A.matcher.check_orientation = 1;
     A.match_cur_to_last = match.data(); A.nmatches = cnt(cur, FB_CNT_PROJ_MATCHES);
     orc_match_projection_frame(&A);
+    {  // if (nmatches < 20) { fill(mvpMapPoints, NULL); nmatches = SearchByProjection(cur, last, 2 * th, mono); }, :1342-1349
+      std::vector<int32_t> n2(B, 0), match2(B * cap, -1), cnt2(B, 0);
+      bool any = false;
+      for (size_t b = 0; b < B; b++)
+        if (cnt(cur, FB_CNT_PROJ_MATCHES)[b] < 20) { n2[b] = last->n[b]; any = true; cnt(cur, FB_CNT_PROJ_RETRIED)[b] = 1; }   // the other sequences: no queries
+      if (any) {
+        A.n_last = n2.data(); A.th = 30.0f; A.match_cur_to_last = match2.data(); A.nmatches = cnt2.data();
+        orc_match_projection_frame(&A);
+        for (size_t b = 0; b < B; b++)
+          if (cnt(cur, FB_CNT_PROJ_MATCHES)[b] < 20) {
+            cnt(cur, FB_CNT_PROJ_MATCHES)[b] = cnt2[b];
+            std::memcpy(&match[b * cap], &match2[b * cap], cap * 4);
+          }
+      }
+    }
     for (size_t b = 0; b < B; b++)  // CurrentFrame.mvpMapPoints[bestIdx2] = pMP, ORBmatcher.cc:1430
       for (int i = 0; i < cur->n[b]; i++) {
         const int m = match[b * cap + i];
@@ -525,10 +540,16 @@ int orc_frame_track_motion_model(orc_frame *cur, orc_frame *last, const fb_track
   t1 = now();
   cur->stage_s[3] = t1 - t0;
   t0 = t1;
-  pose_optimization(cur, map, &mpbv, FB_POSE_FRONT_BIRD, T->wB, T->wF, FB_CNT_POSE1_INLIERS);    // :1353
+  {  // if (nmatches < 20) return false, :1351-1352: those sequences keep the matches, the predicted pose and their flags
+    std::vector<int32_t> n_keep = cur->n, nb_keep = cur->nb;
+    for (size_t b = 0; b < (size_t)cur->B; b++)
+      if (cnt(cur, FB_CNT_PROJ_MATCHES)[b] < 20) { cur->n[b] = 0; cur->nb[b] = 0; }  // no edges: the optimiser leaves the sequence alone
+    pose_optimization(cur, map, &mpbv, FB_POSE_FRONT_BIRD, T->wB, T->wF, FB_CNT_POSE1_INLIERS);  // :1353
+    cur->n = n_keep; cur->nb = nb_keep;
+  }
   t1 = now();
   cur->stage_s[4] = t1 - t0;
-  discard_outliers(cur, map, FB_CNT_PROJ_MATCHES);                                               // :1358-1376
+  discard_outliers(cur, map, FB_CNT_PROJ_MATCHES, true, FB_CNT_PROJ_MATCHES, 20);                // :1358-1376
   return FB_OK;
 }
 

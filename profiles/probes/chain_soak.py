@@ -10,6 +10,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
 ref_share = float(sys.argv[3]) if len(sys.argv) > 3 else 0.4
 branches = {}
+skipped = 0
 g = np.random.default_rng(seed0)
 t0, runs, frames, bad, worst = time.time(), 0, 0, [], 0.0
 while time.time() - t0 < budget:
@@ -28,8 +29,10 @@ while time.time() - t0 < budget:
             rekey = tuple(int(k) for k in range(1, K) if g.random() < 0.3)
             pick = lambda: int(g.integers(0, B)) if g.random() < 0.4 else None
             desc = "seed=%d %s B=%d K=%d modes=%s rekey=%s" % (seed, wh, B, K, modes, rekey)
+            few = {int(g.integers(0, B)): int(g.choice([8, 30, 60, 80, 120]))} if g.random() < 0.4 else None
+            yaw = {int(g.integers(1, K)): (int(g.integers(0, B)), float(g.choice([0.03, 0.06, 0.08])))} if g.random() < 0.4 else None
             seen, w = T._run_modes(B, K, wh, bwh, fx, seed, modes, rekey_at=rekey, short_list_seq=pick(), empty_kf_seq=pick(),
-                                   use_lists=kw["use_lists"], voc_kL=(int(g.choice([4, 5, 8])), 5))
+                                   use_lists=kw["use_lists"], voc_kL=(int(g.choice([4, 5, 8])), 5), few_points=few, yaw_error=yaw)
             for k_, v_ in seen.items():
                 branches[k_] = branches.get(k_, 0) + v_
         else:
@@ -38,9 +41,11 @@ while time.time() - t0 < budget:
         frames += B * (K - 1)
     except AssertionError as e:
         bad.append(desc + " :: " + str(e)[:300])
+    except NotImplementedError:
+        skipped += 1
     runs += 1
     print("[%5.0f s] %d drives, %d tracked frames, %d mismatching drives, worst relative pose difference %.3g" % (time.time() - t0, runs, frames, len(bad), worst), flush=True)
 print("RESULT: %d drives, %d tracked frames compared with the oracle chain, %d mismatching drives, worst relative pose difference %.3g" % (runs, frames, len(bad), worst))
-print("reference-key-frame branches seen (sequence-frames):", branches)
+print("reference-key-frame branches seen (sequence-frames):", branches, "; drives the lockstep (granular) driver cannot represent:", skipped)
 for b in bad[:10]:
     print("MISMATCH", b)

@@ -148,3 +148,31 @@ def test_one_kernel_version_of_search_local_points():
                        env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_search_by_projection_frame_wide_window_retry():
+    """retry_below / retry_th: a frame whose search finds fewer matches than retry_below is searched again from scratch with
+    retry_th inside the same launch (Tracking.cc:1342-1349); the others keep their first result.  Expected = the oracle called
+    twice, per frame."""
+    sizes = [(2000, 2000), (400, 300), (2064, 150), (120, 90)]
+    probs = [synth.make_proj_frame_problem(2600 + 10 * i, nc, nl, dup_frac=0.1) for i, (nc, nl) in enumerate(sizes)]
+    ncur = max(nc for nc, _ in sizes)
+    geom = P.grid_geom(synth.front_grid_geom(1280, 720))
+    cs, ci = P.build_grid_host([p["cur_kps"] for p in probs], geom, O.grid_build, ncur)
+    first, second = {}, {}
+    for th, store in ((4.0, first), (15.0, second)):
+        a, out, keep = P.proj_frame_args(probs, cs, ci, th=th, cur_stride=ncur)
+        O.call("orc_match_projection_frame", a)
+        store.update(match=out["match_cur_to_last"].copy(), n=out["nmatches"].copy())
+    R = int(np.sort(first["n"])[len(sizes) // 2]) + 1     # half of the frames retry
+    assert (first["n"] < R).any() and (first["n"] >= R).any(), first["n"]
+    a, out, keep = P.proj_frame_args(probs, cs, ci, th=4.0, cur_stride=ncur)
+    retried = np.full(len(sizes), -7, np.int32)
+    cabi.fill(a, retry_below=R, retry_th=15.0, retried=retried)
+    H.call("fb_match_projection_frame", a)
+    for b in range(len(sizes)):
+        src = second if first["n"][b] < R else first
+        assert retried[b] == (1 if first["n"][b] < R else 0)
+        assert out["nmatches"][b] == src["n"][b]
+        n = len(probs[b]["cur_kps"])
+        np.testing.assert_array_equal(out["match_cur_to_last"][b, :n], src["match"][b, :n])

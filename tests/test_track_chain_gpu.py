@@ -39,7 +39,7 @@ def _cmp_view(g, o, tag):
         rel = float(np.abs(g["Tcw"][b] - o["Tcw"][b]).max() / max(1.0, np.abs(o["Tcw"][b]).max()))
         worst = max(worst, rel)
         assert rel <= REL_TOL, (tag, b, rel)
-    assert np.array_equal(g["counts"][:14], o["counts"][:14]), (tag, g["counts"][:14].T, o["counts"][:14].T)
+    assert np.array_equal(g["counts"][:15], o["counts"][:15]), (tag, g["counts"][:15].T, o["counts"][:15].T)
     return worst
 
 
@@ -187,7 +187,16 @@ def test_chain_host_images():
     tc.close()
 
 
-def _run_modes(B, K, wh, bwh, fx, seed, modes, rekey_at=(), short_list_seq=None, empty_kf_seq=None, use_lists=True, voc_kL=(5, 5), verbose=False):
+def _yaw(delta12, angle):
+    """detlaT with a yaw error: E * detlaT, E = rotation about the camera's y axis."""
+    c, s_ = np.cos(angle), np.sin(angle)
+    E = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]], np.float64)
+    M = delta12.reshape(3, 4).astype(np.float64)
+    return (E @ M).astype(np.float32).reshape(12)
+
+
+def _run_modes(B, K, wh, bwh, fx, seed, modes, rekey_at=(), short_list_seq=None, empty_kf_seq=None, use_lists=True, voc_kL=(5, 5), verbose=False,
+               few_points=None, yaw_error=None):
     """A drive where the caller chooses per frame between TrackWithMotionModel, TrackReferenceKeyFrame and the fall-back
     (modes[k] in "motion" / "reference" / "motion+reference"), TrackLocalMap behind each, new key frames after the frames in
     rekey_at.  Returns what the branches saw."""
@@ -210,6 +219,9 @@ def _run_modes(B, K, wh, bwh, fx, seed, modes, rekey_at=(), short_list_seq=None,
     mp0 = mp0.copy()
     if empty_kf_seq is not None:
         mp0[empty_kf_seq, :] = -1     # the first key frame of this sequence has no map points
+    for bb_, npts_ in (few_points or {}).items():   # a first frame with only npts_ map points
+        keep_ = np.nonzero(mp0[bb_] >= 0)[0][npts_:]
+        mp0[bb_, keep_] = -1
     vv, vk, first_leaf = make_vocabulary(seed + 1, k=voc_kL[0], L=voc_kL[1])
     tc.set_vocabulary(vk, voc_kL[1])
     oc.set_vocabulary(vk, voc_kL[1])
@@ -219,10 +231,14 @@ def _run_modes(B, K, wh, bwh, fx, seed, modes, rekey_at=(), short_list_seq=None,
     oc.init_first(mp0, mpb0, Tcw0)
     tc.make_keyframe("last")
     oc.make_keyframe("last")
-    kf_at, seen, worst = 0, dict(ref_ok=0, gated=0, bird_branch=0), 0.0
+    kf_at, seen, worst = 0, dict(ref_ok=0, gated=0, bird_branch=0, retried=0, below20=0), 0.0
     for k in range(1, K):
         f, b, c = seq.render(k)
         d, dk = seq.delta(k), seq.delta_between(kf_at, k)
+        if yaw_error and k in yaw_error:   # a bad odometry increment for one sequence: the th = 15 window misses, 2 * th finds
+            bb_, ang_ = yaw_error[k]
+            d = d.copy()
+            d[bb_] = _yaw(d[bb_], ang_)
         tc.set_delta(d)
         tc.set_delta_kf(dk)
         tc.track_modes(f, b, c, mask_d, mode=modes[k])
@@ -235,8 +251,10 @@ def _run_modes(B, K, wh, bwh, fx, seed, modes, rekey_at=(), short_list_seq=None,
         if "reference" in modes[k]:
             bow, pts = cnt[cabi.FB_CNT["BOW_MATCHES"]], cnt[cabi.FB_CNT["BIRD_POINTS"]]
             seen["ref_ok"] += int((bow >= 15).sum()); seen["gated"] += int((bow < 15).sum()); seen["bird_branch"] += int((pts < 10).sum())
+        if "motion" in modes[k]:
+            seen["retried"] += int(cnt[cabi.FB_CNT["PROJ_RETRIED"]].sum()); seen["below20"] += int((cnt[cabi.FB_CNT["PROJ_MATCHES"]] < 20).sum())
         if verbose:
-            print("frame", k, modes[k], cnt[:14].T.tolist())
+            print("frame", k, modes[k], cnt[:15].T.tolist())
         if k in rekey_at:             # CreateNewKeyFrame from the frame just tracked
             tc.make_keyframe("last")
             oc.make_keyframe("last")
@@ -375,3 +393,13 @@ def test_frame_bow_entry_points_against_the_array_api():
         n = int(vcur["n"][bb])
         assert (kept["map_point"][bb, :n] == 5).all()
     tc.close()
+
+
+def test_chain_wide_window_retry_and_early_return():
+    """Tracking.cc:1342-1352 per sequence inside the fused chain: a sequence whose first SearchByProjection (th = 15) finds fewer
+    than 20 matches is searched again with 2 * th in the same launch and goes on when that finds 20 (sequence 0: 80 map points
+    and a 3.4-degree yaw error in its first odometry increment); one that stays below 20 "returns false" -- matches committed,
+    pose and flags untouched, no discard (sequence 1: 12 map points in its first frame)."""
+    modes = {1: "motion", 2: "motion", 3: "motion"}
+    seen, worst = _run_modes(2, 4, (640, 480), (384, 384), 250.0, 9950, modes, few_points={0: 80, 1: 12}, yaw_error={1: (0, 0.06)}, verbose=True)
+    assert seen["retried"] >= 2 and seen["below20"] >= 1, seen
