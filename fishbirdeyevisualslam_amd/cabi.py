@@ -250,7 +250,7 @@ class MapPointsBird(C.Structure):
 
 class TrackArgs(C.Structure):
     _fields_ = [("map", MapPoints), ("mpb", MapPointsBird), ("d_delta", _vp), ("d_local_mp", _vp), ("d_n_local_mp", _vp),
-                ("d_local_mpb", _vp), ("d_n_local_mpb", _vp), ("wB", _f32), ("wF", _f32)]
+                ("d_local_mpb", _vp), ("d_n_local_mpb", _vp), ("wB", _f32), ("wF", _f32), ("gate_local_map", _i32), ("defer_outlier_drop", _i32)]
 
 
 class FrameView(C.Structure):
@@ -305,7 +305,7 @@ EXPORTS = [
     "fb_frame_predict_pose_dev", "fb_frame_clear_map_points_dev", "fb_frame_set_map_points_dev",
     "fb_frame_bird_mappoint_match_dev", "fb_frame_search_by_projection_dev", "fb_frame_pose_optimization_dev",
     "fb_frame_discard_outliers_dev", "fb_frame_match_bird_points_dev", "fb_frame_search_local_points_dev",
-    "fb_frame_finish_dev", "fb_frame_track_dev", "fb_frame_track_motion_model_dev", "fb_frame_track_local_map_dev",
+    "fb_frame_finish_dev", "fb_frame_drop_outliers_dev", "fb_frame_track_dev", "fb_frame_track_motion_model_dev", "fb_frame_track_local_map_dev",
     "fb_frame_copy_dev", "fb_frame_compute_bow_dev", "fb_frame_bow_view_dev", "fb_frame_search_by_bow_dev", "fb_frame_track_reference_dev", "fb_frame_track_using_bird_dev", "fb_frame_view_dev", "fb_frame_download", "fb_frame_counts",
     "fb_local_ba", "fb_local_ba_dev", "fb_local_ba_sharded", "fb_local_ba_sharded_rccl", "fb_rccl_get_unique_id", "fb_rccl_comm_init", "fb_rccl_comm_destroy", "fb_rccl_comm_info", "fb_global_ba",
 ]

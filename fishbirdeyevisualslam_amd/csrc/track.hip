@@ -270,13 +270,16 @@ __global__ __launch_bounds__(WG) void k_discard(FrameDev F, MapDev map, int32_t 
 // only_below > 0 (TrackReferenceKeyFrame, Tracking.cc:1196-1200): numPt = GetBirdMapPointsNum() (Frame.cc:1081-1092) is
 // counted first and a sequence holding that many bird points or more skips the step (its BirdviewMatch count reads 0).
 __global__ __launch_bounds__(WG) void k_bird_commit(FrameDev cur, FrameDev ref, BirdMapDev mpb, const int32_t *m12,
-                                                    float window, int32_t *counts, int B, int only_below) {
+                                                    float window, int32_t *counts, int B, int only_below, const int32_t *gate_row,
+                                                    int gate_min, const int32_t *m8_count) {
   extern __shared__ int s_first[];  // [cap] smallest passing query per train slot
   __shared__ int s_w[WG / 64];
   __shared__ float s_Twc1[12], s_T2[12];
   const int b = blockIdx.x, tid = threadIdx.x, cap = cur.cap;
   const size_t fo = (size_t)b * cap;
   const int nref = min(ref.nb[b], cap);
+  if (gate_row && gate_row[b] < gate_min) return;  // TrackLocalMap does not run for this sequence (Tracking.cc:642: if (bOK))
+  if (tid == 0) counts[FB_CNT_BIRDVIEW_MATCHES * B + b] = m8_count[b];  // (the matcher counted into scratch: a gated sequence keeps its counter)
   if (only_below > 0) {
     int have = 0;
     const int ncur = min(cur.nb[b], cap);
@@ -352,10 +355,14 @@ struct FrustumK { fb_camera cam; float log_scale_factor; int n_levels; };
 //   1. points the frame holds: bad ones are dropped from the frame, the others are marked seen (mnLastFrameSeen = mnId)
 //   2. every other good point of mvpLocalMapPoints: isInFrustum(pMP, 0.5) -> the dense track members M2 reads
 __global__ __launch_bounds__(WG) void k_local_points(FrameDev F, MapDev map, const int32_t *local, const int32_t *n_local, int lcap,
-                                                     FrustumK K, LocalScratch S, int32_t *counts, int B) {
+                                                     FrustumK K, LocalScratch S, int32_t *counts, int B, const int32_t *gate_row, int gate_min) {
   __shared__ int s_w[WG / 64];
   __shared__ float s_T[12], s_Ow[3];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (gate_row && gate_row[b] < gate_min) {  // no TrackLocalMap for this sequence: M2 gets an empty list
+    if (tid == 0) S.n_eff[b] = 0;
+    return;
+  }
   const size_t fo = (size_t)b * F.cap, mo = (size_t)b * map.stride, lo = (size_t)b * lcap;
   const int nmap = min(max(map.n[b], 0), map.stride);
   if (tid < 12) s_T[tid] = F.Tcw[(size_t)b * 12 + tid];
@@ -401,21 +408,42 @@ __global__ __launch_bounds__(WG) void k_local_points(FrameDev F, MapDev map, con
 }
 
 // End of a tracked frame: mnMatchesInliers (Tracking.cc:1411-1424), clean VO matches (:690-701), drop outliers (:721-725)
-__global__ __launch_bounds__(WG) void k_finish(FrameDev F, MapDev map, int32_t *counts, int B) {
+// gate_row / gate_min: sequences whose first stage failed did not run TrackLocalMap (nothing to count, nothing to clean);
+// min_inliers: TrackLocalMap returns mnMatchesInliers >= 30 (Tracking.cc:1438) and the clean-up sits inside if (bOK) (:681);
+// keep_outliers: the final "mvpMapPoints[i] = NULL for outliers" (:721-725) is left to fb_frame_drop_outliers_dev, for a host
+// that creates its key frame in between (:716-718: the outliers pass to the new key frame)
+__global__ __launch_bounds__(WG) void k_finish(FrameDev F, MapDev map, int32_t *counts, int B, const int32_t *gate_row, int gate_min,
+                                               int min_inliers, int keep_outliers) {
   __shared__ int s_w[WG / 64];
   const int b = blockIdx.x, n = min(F.n[b], F.cap);
+  if (gate_row && gate_row[b] < gate_min) return;
   int inl = 0;
   for (int i = threadIdx.x; i < n; i += WG) {
     const size_t o = (size_t)b * F.cap + i;
     const int id = F.mp[o];
     if (id < 0) continue;
-    const bool obs = map.obs_pos[(size_t)b * map.stride + id] != 0;
-    if (!F.outlier[o] && obs) inl++;
-    if (!obs) { F.outlier[o] = 0; F.mp[o] = -1; }   // Observations() < 1
-    else if (F.outlier[o]) F.mp[o] = -1;            // mvbOutlier stays set, as in the reference
+    if (!F.outlier[o] && map.obs_pos[(size_t)b * map.stride + id] != 0) inl++;
   }
   inl = block_sum(inl, s_w);
   if (threadIdx.x == 0) counts[FB_CNT_MATCHES_INLIERS * B + b] = inl;
+  if (inl < min_inliers) return;   // bOK = false: mState = LOST, the frame keeps its members (Tracking.cc:668-675)
+  for (int i = threadIdx.x; i < n; i += WG) {
+    const size_t o = (size_t)b * F.cap + i;
+    const int id = F.mp[o];
+    if (id < 0) continue;
+    const bool obs = map.obs_pos[(size_t)b * map.stride + id] != 0;
+    if (!obs) { F.outlier[o] = 0; F.mp[o] = -1; }                     // Observations() < 1
+    else if (F.outlier[o] && !keep_outliers) F.mp[o] = -1;            // mvbOutlier stays set, as in the reference
+  }
+}
+// Tracking.cc:721-725 on its own (after a key-frame decision), for the sequences whose clean-up ran
+__global__ __launch_bounds__(WG) void k_drop_outliers(FrameDev F, const int32_t *counts, int B, int min_inliers) {
+  const int b = blockIdx.x, n = min(F.n[b], F.cap);
+  if (counts[FB_CNT_MATCHES_INLIERS * B + b] < min_inliers) return;
+  for (int i = threadIdx.x; i < n; i += WG) {
+    const size_t o = (size_t)b * F.cap + i;
+    if (F.mp[o] >= 0 && F.outlier[o]) F.mp[o] = -1;
+  }
 }
 
 __global__ __launch_bounds__(TT) void k_set_map_points(FrameDev F, const int32_t *mp, const int32_t *mpb) {
@@ -797,14 +825,14 @@ int m3_impl(fb_frame *cur, const fb_frame *last, const fb_map_points *map, float
 }
 
 int local_impl(fb_frame *f, const fb_map_points *map, const int32_t *d_local, const int32_t *d_n_local, float th,
-               const fb_matcher_params *matcher, hipStream_t s) {
+               const fb_matcher_params *matcher, hipStream_t s, const int32_t *gate_row = nullptr, int gate_min = 0) {
   const int B = f->B, cap = f->cap, lcap = f->P.local_mp_cap;
   LocalScratch S{f->l_seen.as<uint8_t>(), f->l_blocked.as<uint8_t>(), f->l_inview.as<uint8_t>(), f->l_obs.as<uint8_t>(),
                  f->l_proj.as<float>(), f->l_level.as<int32_t>(), f->l_cos.as<float>(), f->l_desc.as<uint8_t>(), f->l_n.as<int32_t>()};
   FrustumK K{f->cam, f->logScale, f->P.orb.nlevels};
   {
     fb::ProfScope prof_(fb::P_FRUSTUM, s);
-    k_local_points<<<B, WG, 0, s>>>(f->dev(), map_dev(map), d_local, d_n_local, lcap, K, S, f->counts.as<int32_t>(), B);
+    k_local_points<<<B, WG, 0, s>>>(f->dev(), map_dev(map), d_local, d_n_local, lcap, K, S, f->counts.as<int32_t>(), B, gate_row, gate_min);
     FB_HIP(hipGetLastError());
   }
   fb_proj_points_args A;
@@ -822,7 +850,7 @@ int local_impl(fb_frame *f, const fb_map_points *map, const int32_t *d_local, co
 }
 
 int bird_points_impl(fb_frame *cur, fb_frame *ref, fb_map_points_bird *mpb, int window_size, float filter_size,
-                     const fb_matcher_params *matcher, int only_below, hipStream_t s) {
+                     const fb_matcher_params *matcher, int only_below, hipStream_t s, const int32_t *gate_row = nullptr, int gate_min = 0) {
   fb_birdview_args A;
   memset(&A, 0, sizeof(A));
   A.batch = cur->B; A.cur_stride = cur->cap; A.ref_stride = cur->cap;
@@ -831,14 +859,14 @@ int bird_points_impl(fb_frame *cur, fb_frame *ref, fb_map_points_bird *mpb, int 
   A.n_ref = ref->nb.as<int32_t>(); A.ref_kps = ref->bkps.as<fb_keypoint>(); A.ref_desc = ref->bdesc.as<uint8_t>();
   A.grid = cur->gB; A.window_size = window_size; A.matcher = *matcher;
   A.match_ref_to_cur = cur->m8_m12.as<int32_t>(); A.match_dist = cur->m8_dist.as<int32_t>();
-  A.nmatches = cur->cnt(FB_CNT_BIRDVIEW_MATCHES); A.n_dmatches = cur->m8_nd.as<int32_t>();
+  A.nmatches = cur->m8_n.as<int32_t>(); A.n_dmatches = cur->m8_nd.as<int32_t>();
   FB_TRY(fb_match_birdview_dev(&A, s));
   const size_t lds = (size_t)cur->cap * 4;
   if (lds > 150 * 1024) { fb::set_error("fb_frame_match_bird_points: %d key points per frame beyond the LDS slot table", cur->cap); return FB_ERR_CAPACITY; }
   FB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bird_commit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   fb::ProfScope prof_(fb::P_TRACK_GLUE, s);
   k_bird_commit<<<cur->B, WG, lds, s>>>(cur->dev(), ref->dev(), bird_dev(mpb), cur->m8_m12.as<int32_t>(), filter_size,
-                                       cur->counts.as<int32_t>(), cur->B, only_below);
+                                       cur->counts.as<int32_t>(), cur->B, only_below, gate_row, gate_min, cur->m8_n.as<int32_t>());
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -906,16 +934,28 @@ int motion_model_impl(fb_frame *cur, fb_frame *last, const fb_track_args *T, hip
   return discard_impl(cur, &T->map, FB_CNT_PROJ_MATCHES, 20, s);                                       // :1358-1376
 }
 
-// TrackLocalMap (Tracking.cc:1387-1441) + the end of Track (:1411-1424, 690-701, 721-725)
-int local_map_impl(fb_frame *cur, fb_frame *ref, const fb_track_args *T, hipStream_t s) {
+int finish_impl(fb_frame *f, const fb_map_points *map, const int32_t *gate_row, int gate_min, int keep_outliers, hipStream_t s) {
+  fb::ProfScope prof_(fb::P_TRACK_GLUE, s);
+  k_finish<<<f->B, WG, 0, s>>>(f->dev(), map_dev(map), f->counts.as<int32_t>(), f->B, gate_row, gate_min, 30, keep_outliers);
+  FB_HIP(hipGetLastError());
+  return FB_OK;
+}
+
+// TrackLocalMap (Tracking.cc:1387-1441) + the end of Track (:1411-1424, 690-701, 721-725).  gated: a sequence whose first
+// stage failed (nmatchesMap < 10: TrackWithMotionModel :1384 / TrackReferenceKeyFrame :1243 returned false; the counter is
+// still 0 when the stage returned early) is left alone, as if (bOK) of Tracking.cc:642 leaves it
+int local_map_impl(fb_frame *cur, fb_frame *ref, const fb_track_args *T, hipStream_t s, bool gated) {
   fb_map_points_bird mpb = T->mpb;
-  FB_TRY(bird_points_impl(cur, ref, &mpb, 10, 0.05f, &M09, 0, s));                                     // :1392 -> :2724-2733
-  FB_TRY(local_impl(cur, &T->map, T->d_local_mp, T->d_n_local_mp, 1.0f, &M08, s));                     // :1396 -> :1947-1997
+  const int32_t *gr = gated ? cur->cnt(FB_CNT_MATCHES_MAP) : nullptr;
+  const int gm = 10;
+  FB_TRY(bird_points_impl(cur, ref, &mpb, 10, 0.05f, &M09, 0, s, gr, gm));                             // :1392 -> :2724-2733
+  FB_TRY(local_impl(cur, &T->map, T->d_local_mp, T->d_n_local_mp, 1.0f, &M08, s, gr, gm));             // :1396 -> :1947-1997
   Commit C2;
   memset(&C2, 0, sizeof(C2));
   C2.kind = 2; C2.match = cur->m_local.as<int32_t>(); C2.src_mp = T->d_local_mp; C2.src_stride = cur->P.local_mp_cap;
+  C2.gate = gr; C2.gate_min = gm;
   FB_TRY(edges_and_pose(cur, &T->map, &mpb, FB_POSE_FRONT_BIRD, T->wB, T->wF, 1, C2, s));              // :1400
-  return fb_frame_finish_dev(cur, &T->map, s);
+  return finish_impl(cur, &T->map, gr, gm, T->defer_outlier_drop, s);
 }
 
 }  // namespace
@@ -982,8 +1022,14 @@ int fb_frame_search_local_points_dev(fb_frame *f, const fb_map_points *map, cons
 int fb_frame_finish_dev(fb_frame *f, const fb_map_points *map, void *stream) {
   FB_TRY(fb::check_device());
   FB_ARG(f && map_ok(f, map));
+  return finish_impl(f, map, nullptr, 0, 0, fb::as_stream(stream));
+}
+
+int fb_frame_drop_outliers_dev(fb_frame *f, void *stream) {
+  FB_TRY(fb::check_device());
+  FB_ARG(f);
   fb::ProfScope prof_(fb::P_TRACK_GLUE, fb::as_stream(stream));
-  k_finish<<<f->B, WG, 0, fb::as_stream(stream)>>>(f->dev(), map_dev(map), f->counts.as<int32_t>(), f->B);
+  k_drop_outliers<<<f->B, WG, 0, fb::as_stream(stream)>>>(f->dev(), f->counts.as<int32_t>(), f->B, 30);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -997,14 +1043,14 @@ int fb_frame_track_motion_model_dev(fb_frame *cur, fb_frame *last, const fb_trac
 int fb_frame_track_local_map_dev(fb_frame *cur, fb_frame *ref, const fb_track_args *T, void *stream) {
   FB_TRY(fb::check_device());
   FB_ARG(cur && ref && cur != ref && cur->B == ref->B && cur->cap == ref->cap && track_args_ok(cur, T));
-  return local_map_impl(cur, ref, T, fb::as_stream(stream));
+  return local_map_impl(cur, ref, T, fb::as_stream(stream), T->gate_local_map != 0);
 }
 
 int fb_frame_track_dev(fb_frame *cur, fb_frame *last, const fb_track_args *T, void *stream) {
   FB_TRY(fb::check_device());
   FB_ARG(cur && last && cur != last && cur->B == last->B && cur->cap == last->cap && track_args_ok(cur, T) && T->d_delta);
   FB_TRY(motion_model_impl(cur, last, T, fb::as_stream(stream)));
-  return local_map_impl(cur, last, T, fb::as_stream(stream));
+  return local_map_impl(cur, last, T, fb::as_stream(stream), true);   // if (bOK) bOK = TrackLocalMap(), per sequence
 }
 
 int fb_frame_compute_bow_dev(fb_frame *f, const fb_vocabulary *voc, void *stream) {

@@ -83,7 +83,7 @@ class TrackChain:
         self.targs = cabi.TrackArgs()
         fill(self.targs.map, stride=mc, **self.map)
         fill(self.targs.mpb, stride=bc, **self.mpb)
-        fill(self.targs, d_delta=self.delta, wB=1.0, wF=1.0)
+        fill(self.targs, d_delta=self.delta, wB=1.0, wF=1.0, gate_local_map=1)   # if (bOK) bOK = TrackLocalMap(), per sequence
         self._hv = {}
 
     def close(self):
@@ -251,11 +251,17 @@ class TrackChain:
             raise NotImplementedError("granular entry points: a sequence has fewer than 20 matches (retry / early return is per sequence)")
         check(L.fb_frame_pose_optimization_dev(cur, C.byref(T.map), C.byref(T.mpb), cabi.FB_POSE_FRONT_BIRD, C.c_float(1.0), C.c_float(1.0), 0, s), "pose 1")
         check(L.fb_frame_discard_outliers_dev(cur, C.byref(T.map), s), "discard")
+        if (self.counts("cur")[0][cabi.FB_CNT["MATCHES_MAP"]] < 10).any():
+            raise NotImplementedError("granular entry points: TrackWithMotionModel failed for a sequence (the fall-back is per sequence)")
         check(L.fb_frame_match_bird_points_dev(cur, last, C.byref(T.mpb), 10, C.c_float(0.05), C.byref(m09), s), "M8 + filter")
         check(L.fb_frame_search_local_points_dev(cur, C.byref(T.map), lm[0], lm[1], C.c_float(1.0), C.byref(m08), s), "local points")
         check(L.fb_frame_pose_optimization_dev(cur, C.byref(T.map), C.byref(T.mpb), cabi.FB_POSE_FRONT_BIRD, C.c_float(1.0), C.c_float(1.0), 1, s), "pose 2")
         check(L.fb_frame_finish_dev(cur, C.byref(T.map), s), "finish")
         self.k += 1
+
+    def drop_outliers(self, which="last"):
+        """Tracking.cc:721-725 after the host's key-frame decision (targs.defer_outlier_drop = 1)."""
+        check(self.L.fb_frame_drop_outliers_dev(self._which(which), self._stream()), "fb_frame_drop_outliers_dev")
 
     # ---- results ----
     def _which(self, which):

@@ -868,6 +868,10 @@ int fb_frame_search_local_points_dev(fb_frame *f, const fb_map_points *map, cons
 /* End of Tracking::Track for a tracked frame (Tracking.cc:1411-1424 mnMatchesInliers; :690-701 clean VO matches;
  * :721-725 mvpMapPoints[i] = NULL for outliers) -- after it the frame is what mLastFrame = Frame(mCurrentFrame) copies. */
 int fb_frame_finish_dev(fb_frame *f, const fb_map_points *map, void *stream);
+/* (both end-of-Track entry points follow `if (bOK)` of Tracking.cc:681 per sequence: the clean-up runs where
+ * FB_CNT_MATCHES_INLIERS >= 30, Tracking.cc:1438; a sequence below keeps its members, as a LOST frame does)
+ * Tracking.cc:721-725 on its own, after a key-frame decision (fb_track_args.defer_outlier_drop). */
+int fb_frame_drop_outliers_dev(fb_frame *f, void *stream);
 
 /* The OK-state path of Tracking::Track in one call: TrackWithMotionModel (Tracking.cc:1312-1385) + TrackLocalMap
  * (:1387-1441) + the end-of-Track clean-up, i.e. predict_pose, M9, M3 (th = 15), PoseOptimizationWithBird, discard,
@@ -881,6 +885,14 @@ typedef struct fb_track_args {
   const int32_t *d_local_mp, *d_n_local_mp;   /* mvpLocalMapPoints (NULL = whole table)                                 */
   const int32_t *d_local_mpb, *d_n_local_mpb; /* vlocalMPB (NULL = whole table)                                         */
   float wB, wF;                     /* Optimizer.h:52 defaults 1, 1                                                     */
+  /* fb_frame_track_local_map_dev: 1 = per sequence `if (bOK) bOK = TrackLocalMap()` (Tracking.cc:642): a sequence whose first
+   * stage returned false (FB_CNT_MATCHES_MAP < 10; the counter is still 0 after an early return) is left alone -- no bird
+   * points created, no matching, pose and flags untouched, counters of the stage 0.  0 = every sequence of the handle runs
+   * (the host decided for all of them).  fb_frame_track_dev always gates.                                               */
+  int32_t gate_local_map;
+  /* 1 = leave the final "mvpMapPoints[i] = NULL for outliers" (Tracking.cc:721-725) to fb_frame_drop_outliers_dev: the
+   * reference creates its key frame in between (:716-718) and lets the outliers pass to it.                              */
+  int32_t defer_outlier_drop;
 } fb_track_args;
 int fb_frame_track_dev(fb_frame *cur, fb_frame *last, const fb_track_args *args, void *stream);
 /* The two halves of fb_frame_track_dev on their own, for a host that reads the counters in between (Tracking.cc:529-540:

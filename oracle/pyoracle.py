@@ -193,7 +193,7 @@ class OracleChain:
         self.keep["MB"] = {k: np.ascontiguousarray(v).copy() for k, v in MB.items()}
         cabi.fill(self.targs.map, stride=self.map_cap, **self.keep["M"])
         cabi.fill(self.targs.mpb, stride=self.bird_cap, **self.keep["MB"])
-        cabi.fill(self.targs, wB=1.0, wF=1.0)
+        cabi.fill(self.targs, wB=1.0, wF=1.0, gate_local_map=1)
         if self.use_lists:
             self.keep["lists"] = [np.ascontiguousarray(x).copy() for x in (local_mp[0], local_mp[1], local_mpb[0], local_mpb[1])]
             l = self.keep["lists"]
@@ -254,6 +254,10 @@ class OracleChain:
             cabi.fill(self.targs, d_delta=self.keep["delta"])
         assert self.L.orc_frame_track_local_map(self.cur, self.last, C.byref(self.targs)) == 0
         self.k += 1
+
+    def drop_outliers(self, which="last"):
+        f = self.last if which == "last" else self.cur
+        assert self.L.orc_frame_drop_outliers(f) == 0
 
     def view(self, which="last"):
         f = self.last if which == "last" else (self.kf if which == "kf" else self.cur)

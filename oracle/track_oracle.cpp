@@ -482,7 +482,7 @@ void search_local_points(orc_frame *cur, const fb_track_args *T, const fb_map_po
 }
 
 // mnMatchesInliers (Tracking.cc:1411-1424), clean VO matches (:690-701), drop outliers (:721-725)
-void finish_frame(orc_frame *cur, const fb_map_points *map) {
+void finish_frame(orc_frame *cur, const fb_map_points *map, bool keep_outliers = false) {
   const size_t B = cur->B, cap = cur->cap;
   for (size_t b = 0; b < B; b++) {
     int inl = 0;
@@ -491,21 +491,37 @@ void finish_frame(orc_frame *cur, const fb_map_points *map) {
       if (cur->mp[o] < 0) continue;
       if (!cur->outlier[o] && map->obs_pos[b * map->stride + cur->mp[o]]) inl++;
     }
+    cnt(cur, FB_CNT_MATCHES_INLIERS)[b] = inl;
+    if (inl < 30) continue;  // TrackLocalMap returned false (:1438): bOK = false, the block of :681-726 is skipped
     for (int i = 0; i < cur->n[b]; i++) {
       const size_t o = b * cap + i;
       if (cur->mp[o] >= 0 && !map->obs_pos[b * map->stride + cur->mp[o]]) { cur->outlier[o] = 0; cur->mp[o] = -1; }
     }
+    if (keep_outliers) continue;  // the caller creates its key frame first (:716-718) and drops the outliers afterwards
     for (int i = 0; i < cur->n[b]; i++) {
       const size_t o = b * cap + i;
       if (cur->mp[o] >= 0 && cur->outlier[o]) cur->mp[o] = -1;
     }
-    cnt(cur, FB_CNT_MATCHES_INLIERS)[b] = inl;
   }
 }
 
 // TrackLocalMap (Tracking.cc:1387-1441) + the end of Track
-void track_local_map(orc_frame *cur, orc_frame *last, const fb_track_args *T, fb_map_points_bird *mpb) {
+void track_local_map(orc_frame *cur, orc_frame *last, const fb_track_args *T, fb_map_points_bird *mpb, bool gated) {
   const fb_map_points *map = &T->map;
+  // gated: `if (bOK) bOK = TrackLocalMap()` (Tracking.cc:642) per sequence -- a sequence whose first stage returned false
+  // (nmatchesMap < 10) is not touched.  Done here by running the batch and putting such sequences back as they were.
+  const size_t B = cur->B, cap = cur->cap;
+  std::vector<uint8_t> skip(B, 0);
+  orc_frame keepCur, keepLast;
+  std::vector<int32_t> keepN(B, 0);
+  bool anySkip = false;
+  if (gated)
+    for (size_t b = 0; b < B; b++)
+      if (cnt(cur, FB_CNT_MATCHES_MAP)[b] < 10) { skip[b] = 1; anySkip = true; }
+  if (anySkip) {
+    keepCur = *cur; keepLast = *last;
+    for (size_t b = 0; b < B; b++) keepN[b] = mpb->n[b];
+  }
   double t0 = now();
   per_frame_matched_bird_points(cur, last, mpb, 0);                                              // :1392
   double t1 = now();
@@ -518,7 +534,19 @@ void track_local_map(orc_frame *cur, orc_frame *last, const fb_track_args *T, fb
   pose_optimization(cur, map, mpb, FB_POSE_FRONT_BIRD, T->wB, T->wF, FB_CNT_POSE2_INLIERS);      // :1400
   t1 = now();
   cur->stage_s[7] = t1 - t0;
-  finish_frame(cur, map);
+  finish_frame(cur, map, T->defer_outlier_drop != 0);
+  if (anySkip)
+    for (size_t b = 0; b < B; b++) {
+      if (!skip[b]) continue;
+      std::copy(keepCur.mp.begin() + b * cap, keepCur.mp.begin() + (b + 1) * cap, cur->mp.begin() + b * cap);
+      std::copy(keepCur.mpb.begin() + b * cap, keepCur.mpb.begin() + (b + 1) * cap, cur->mpb.begin() + b * cap);
+      std::copy(keepCur.outlier.begin() + b * cap, keepCur.outlier.begin() + (b + 1) * cap, cur->outlier.begin() + b * cap);
+      std::copy(keepCur.boutlier.begin() + b * cap, keepCur.boutlier.begin() + (b + 1) * cap, cur->boutlier.begin() + b * cap);
+      std::copy(keepCur.Tcw.begin() + b * 12, keepCur.Tcw.begin() + (b + 1) * 12, cur->Tcw.begin() + b * 12);
+      std::copy(keepLast.mpb.begin() + b * cap, keepLast.mpb.begin() + (b + 1) * cap, last->mpb.begin() + b * cap);
+      for (int slot = 0; slot < FB_CNT_COUNT; slot++) cnt(cur, slot)[b] = keepCur.counts[(size_t)slot * B + b];
+      mpb->n[b] = keepN[b];  // the MapPointBirds the skipped TrackLocalMap appended do not exist
+    }
 }
 
 }  // namespace
@@ -555,7 +583,20 @@ int orc_frame_track_motion_model(orc_frame *cur, orc_frame *last, const fb_track
 
 int orc_frame_track_local_map(orc_frame *cur, orc_frame *last, const fb_track_args *T) {
   fb_map_points_bird mpbv = T->mpb;
-  track_local_map(cur, last, T, &mpbv);
+  track_local_map(cur, last, T, &mpbv, T->gate_local_map != 0);
+  return FB_OK;
+}
+
+// Tracking.cc:721-725 on its own (fb_track_args.defer_outlier_drop), for the sequences whose clean-up ran
+int orc_frame_drop_outliers(orc_frame *f) {
+  const size_t B = f->B, cap = f->cap;
+  for (size_t b = 0; b < B; b++) {
+    if (cnt(f, FB_CNT_MATCHES_INLIERS)[b] < 30) continue;
+    for (int i = 0; i < f->n[b]; i++) {
+      const size_t o = b * cap + i;
+      if (f->mp[o] >= 0 && f->outlier[o]) f->mp[o] = -1;
+    }
+  }
   return FB_OK;
 }
 
@@ -638,7 +679,9 @@ int orc_frame_track_using_bird(orc_frame *cur, orc_frame *src, orc_frame *last, 
 
 int orc_frame_track(orc_frame *cur, orc_frame *last, const fb_track_args *T) {
   orc_frame_track_motion_model(cur, last, T);
-  return orc_frame_track_local_map(cur, last, T);
+  fb_map_points_bird mpbv = T->mpb;
+  track_local_map(cur, last, T, &mpbv, true);   // if (bOK) bOK = TrackLocalMap(), per sequence
+  return FB_OK;
 }
 
 int orc_frame_view(orc_frame *f, fb_frame_view *v) {

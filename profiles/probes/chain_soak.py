@@ -32,7 +32,8 @@ while time.time() - t0 < budget:
             few = {int(g.integers(0, B)): int(g.choice([8, 30, 60, 80, 120]))} if g.random() < 0.4 else None
             yaw = {int(g.integers(1, K)): (int(g.integers(0, B)), float(g.choice([0.03, 0.06, 0.08])))} if g.random() < 0.4 else None
             seen, w = T._run_modes(B, K, wh, bwh, fx, seed, modes, rekey_at=rekey, short_list_seq=pick(), empty_kf_seq=pick(),
-                                   use_lists=kw["use_lists"], voc_kL=(int(g.choice([4, 5, 8])), 5), few_points=few, yaw_error=yaw)
+                                   use_lists=kw["use_lists"], voc_kL=(int(g.choice([4, 5, 8])), 5), few_points=few, yaw_error=yaw,
+                                   defer_drop=bool(g.random() < 0.3))
             for k_, v_ in seen.items():
                 branches[k_] = branches.get(k_, 0) + v_
         else:

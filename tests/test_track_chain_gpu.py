@@ -196,7 +196,7 @@ def _yaw(delta12, angle):
 
 
 def _run_modes(B, K, wh, bwh, fx, seed, modes, rekey_at=(), short_list_seq=None, empty_kf_seq=None, use_lists=True, voc_kL=(5, 5), verbose=False,
-               few_points=None, yaw_error=None):
+               few_points=None, yaw_error=None, defer_drop=False):
     """A drive where the caller chooses per frame between TrackWithMotionModel, TrackReferenceKeyFrame and the fall-back
     (modes[k] in "motion" / "reference" / "motion+reference"), TrackLocalMap behind each, new key frames after the frames in
     rekey_at.  Returns what the branches saw."""
@@ -231,6 +231,10 @@ def _run_modes(B, K, wh, bwh, fx, seed, modes, rekey_at=(), short_list_seq=None,
     oc.init_first(mp0, mpb0, Tcw0)
     tc.make_keyframe("last")
     oc.make_keyframe("last")
+    if defer_drop:   # the host creates its key frame between the clean-up and the outlier drop (Tracking.cc:716-725)
+        for ch in (tc, oc):
+            cabi.fill(ch.targs, defer_outlier_drop=1)
+        cabi.fill(tc.targs_kf, defer_outlier_drop=1)
     kf_at, seen, worst = 0, dict(ref_ok=0, gated=0, bird_branch=0, retried=0, below20=0), 0.0
     for k in range(1, K):
         f, b, c = seq.render(k)
@@ -245,8 +249,18 @@ def _run_modes(B, K, wh, bwh, fx, seed, modes, rekey_at=(), short_list_seq=None,
         oc.track_modes(h(f), h(b), h(c), seq.mask, d, dk, mode=modes[k])
         g, o = tc.view(), oc.view()
         worst = max(worst, _cmp_view(g, o, "frame %d (%s)" % (k, modes[k])))
+        if defer_drop:
+            seen["kept_outliers"] = seen.get("kept_outliers", 0) + int(((o["map_point"] >= 0) & (o["outlier"] != 0)).sum())
+            tc.drop_outliers()
+            oc.drop_outliers()
+            g, o = tc.view(), oc.view()
+            _cmp_view(g, o, "frame %d after the outlier drop" % k)
+            assert not ((o["map_point"] >= 0) & (o["outlier"] != 0) & (o["counts"][cabi.FB_CNT["MATCHES_INLIERS"]] >= 30)[:, None]).any()
         gt, ot = tc.bird_table_host(), oc.bird_table_host()
-        assert np.array_equal(gt["n"], ot["n"]) and np.array_equal(gt["desc"], ot["desc"])
+        assert np.array_equal(gt["n"], ot["n"])
+        for bb in range(B):
+            nt = int(ot["n"][bb])
+            assert np.array_equal(gt["desc"][bb, :nt], ot["desc"][bb, :nt]), ("bird table descriptors", k, bb)
         cnt = o["counts"]
         if "reference" in modes[k]:
             bow, pts = cnt[cabi.FB_CNT["BOW_MATCHES"]], cnt[cabi.FB_CNT["BIRD_POINTS"]]
@@ -284,8 +298,9 @@ def test_chain_track_using_bird():
     reference key frame, GetLocalMapForBird, the numPt <= 10 branch (sequence 1: a short vlocalMPB list), BirdOptimization
     (bird edges only), GetPerFrameMatchedBirdPoints; then the tracker finds its way back through the reference key frame."""
     modes = {1: "motion", 2: "bird", 3: "bird_kf", 4: "reference", 5: "bird", 6: "motion+reference"}
-    seen, worst = _run_modes(2, 7, (640, 480), (384, 384), 250.0, 9900, modes, rekey_at=(1,), short_list_seq=1, verbose=True)
-    print("track-using-bird path: worst relative pose difference %.3g" % worst)
+    seen, worst = _run_modes(2, 7, (640, 480), (384, 384), 250.0, 9900, modes, rekey_at=(1,), short_list_seq=1, verbose=True, defer_drop=True)
+    assert seen.get("kept_outliers", 0) > 0, seen   # the deferred drop had something to drop
+    print("track-using-bird path: worst relative pose difference %.3g; outliers kept for the key frame: %d" % (worst, seen["kept_outliers"]))
 
 
 def test_frame_bow_entry_points_against_the_array_api():
