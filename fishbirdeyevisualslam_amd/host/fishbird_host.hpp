@@ -558,6 +558,7 @@ class DeviceFrame {
     check(fb_frame_track_local_map_dev(h_, tmpRefFrame.h_, &T, stream));
     return Result(stream);
   }
+  void DropOutliers(void *stream = nullptr) { check(fb_frame_drop_outliers_dev(h_, stream)); }  // Tracking.cc:721-725, after the key-frame decision
   void ComputeBoW(const fb_vocabulary &d_voc, void *stream = nullptr) { check(fb_frame_compute_bow_dev(h_, &d_voc, stream)); }  // Frame.cc:628-635
   void CopyFrom(const DeviceFrame &f, void *stream = nullptr) { check(fb_frame_copy_dev(h_, f.h_, stream)); }  // Frame(const Frame&), KeyFrame(Frame&, ...)
 
@@ -575,6 +576,8 @@ class DeviceFrame {
     T.map = map.points; T.mpb = map.birdPoints; T.d_delta = d_deltaT;
     T.d_local_mp = map.localPoints; T.d_n_local_mp = map.nLocalPoints; T.d_local_mpb = map.localBirdPoints; T.d_n_local_mpb = map.nLocalBirdPoints;
     T.wB = wB; T.wF = wF;
+    T.gate_local_map = 1;       // every step follows its sequence's own bOK
+    T.defer_outlier_drop = 0;   // set to 1 by a caller that copies its key frame before DropOutliers()
     return T;
   }
   fb_frame_params p_;
