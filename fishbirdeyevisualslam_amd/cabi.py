@@ -250,7 +250,7 @@ class MapPointsBird(C.Structure):
 
 class TrackArgs(C.Structure):
     _fields_ = [("map", MapPoints), ("mpb", MapPointsBird), ("d_delta", _vp), ("d_local_mp", _vp), ("d_n_local_mp", _vp),
-                ("d_local_mpb", _vp), ("d_n_local_mpb", _vp), ("wB", _f32), ("wF", _f32), ("gate_local_map", _i32), ("defer_outlier_drop", _i32)]
+                ("d_local_mpb", _vp), ("d_n_local_mpb", _vp), ("wB", _f32), ("wF", _f32), ("gate_local_map", _i32), ("defer_outlier_drop", _i32), ("min_inliers", _i32)]
 
 
 class FrameView(C.Structure):

@@ -482,6 +482,7 @@ struct fb_frame {
   // mBowVec / mFeatVec (Frame.h:128-129), allocated by the first fb_frame_compute_bow_dev
   fb::DevBuf bow_nw, bow_ids, bow_vals, fv_nn, fv_ids, fv_start, fv_items;
   bool bowDone = false;   // !mBowVec.empty() (in the order the calls were enqueued)
+  int minInliers = 30;    // the threshold the last end-of-Track clean-up used (fb_frame_drop_outliers_dev follows it)
   // images from host callers
   fb::DevBuf img_f, img_b, img_c, img_m;
   uint8_t *pin = nullptr;
@@ -934,9 +935,11 @@ int motion_model_impl(fb_frame *cur, fb_frame *last, const fb_track_args *T, hip
   return discard_impl(cur, &T->map, FB_CNT_PROJ_MATCHES, 20, s);                                       // :1358-1376
 }
 
-int finish_impl(fb_frame *f, const fb_map_points *map, const int32_t *gate_row, int gate_min, int keep_outliers, hipStream_t s) {
+int finish_impl(fb_frame *f, const fb_map_points *map, const int32_t *gate_row, int gate_min, int keep_outliers, hipStream_t s,
+                int min_inliers = 0) {
+  f->minInliers = min_inliers > 0 ? min_inliers : 30;
   fb::ProfScope prof_(fb::P_TRACK_GLUE, s);
-  k_finish<<<f->B, WG, 0, s>>>(f->dev(), map_dev(map), f->counts.as<int32_t>(), f->B, gate_row, gate_min, 30, keep_outliers);
+  k_finish<<<f->B, WG, 0, s>>>(f->dev(), map_dev(map), f->counts.as<int32_t>(), f->B, gate_row, gate_min, f->minInliers, keep_outliers);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }
@@ -955,7 +958,7 @@ int local_map_impl(fb_frame *cur, fb_frame *ref, const fb_track_args *T, hipStre
   C2.kind = 2; C2.match = cur->m_local.as<int32_t>(); C2.src_mp = T->d_local_mp; C2.src_stride = cur->P.local_mp_cap;
   C2.gate = gr; C2.gate_min = gm;
   FB_TRY(edges_and_pose(cur, &T->map, &mpb, FB_POSE_FRONT_BIRD, T->wB, T->wF, 1, C2, s));              // :1400
-  return finish_impl(cur, &T->map, gr, gm, T->defer_outlier_drop, s);
+  return finish_impl(cur, &T->map, gr, gm, T->defer_outlier_drop, s, T->min_inliers);
 }
 
 }  // namespace
@@ -1029,7 +1032,7 @@ int fb_frame_drop_outliers_dev(fb_frame *f, void *stream) {
   FB_TRY(fb::check_device());
   FB_ARG(f);
   fb::ProfScope prof_(fb::P_TRACK_GLUE, fb::as_stream(stream));
-  k_drop_outliers<<<f->B, WG, 0, fb::as_stream(stream)>>>(f->dev(), f->counts.as<int32_t>(), f->B, 30);
+  k_drop_outliers<<<f->B, WG, 0, fb::as_stream(stream)>>>(f->dev(), f->counts.as<int32_t>(), f->B, f->minInliers);
   FB_HIP(hipGetLastError());
   return FB_OK;
 }

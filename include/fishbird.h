@@ -893,6 +893,9 @@ typedef struct fb_track_args {
   /* 1 = leave the final "mvpMapPoints[i] = NULL for outliers" (Tracking.cc:721-725) to fb_frame_drop_outliers_dev: the
    * reference creates its key frame in between (:716-718) and lets the outliers pass to it.                              */
   int32_t defer_outlier_drop;
+  /* TrackLocalMap's success threshold on mnMatchesInliers: 0 = 30 (Tracking.cc:1438); a host that relocalised less than
+   * mMaxFrames frames ago passes 50 (:1435-1436).                                                                        */
+  int32_t min_inliers;
 } fb_track_args;
 int fb_frame_track_dev(fb_frame *cur, fb_frame *last, const fb_track_args *args, void *stream);
 /* The two halves of fb_frame_track_dev on their own, for a host that reads the counters in between (Tracking.cc:529-540:

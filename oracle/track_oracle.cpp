@@ -56,6 +56,7 @@ struct orc_frame {
   std::vector<uint8_t> desc, bdesc, outlier, boutlier;
   std::vector<float> bcam, Tcw;
   // mBowVec / mFeatVec (Frame.h:128-129), empty until ComputeBoW
+  int min_inliers = 30;   // threshold of the last end-of-Track clean-up
   bool bow_done = false;
   std::vector<int32_t> bow_nw, fv_nn, fv_start, fv_items;
   std::vector<uint32_t> bow_ids, fv_ids;
@@ -482,7 +483,8 @@ void search_local_points(orc_frame *cur, const fb_track_args *T, const fb_map_po
 }
 
 // mnMatchesInliers (Tracking.cc:1411-1424), clean VO matches (:690-701), drop outliers (:721-725)
-void finish_frame(orc_frame *cur, const fb_map_points *map, bool keep_outliers = false) {
+void finish_frame(orc_frame *cur, const fb_map_points *map, bool keep_outliers = false, int min_inliers = 30) {
+  cur->min_inliers = min_inliers;
   const size_t B = cur->B, cap = cur->cap;
   for (size_t b = 0; b < B; b++) {
     int inl = 0;
@@ -492,7 +494,7 @@ void finish_frame(orc_frame *cur, const fb_map_points *map, bool keep_outliers =
       if (!cur->outlier[o] && map->obs_pos[b * map->stride + cur->mp[o]]) inl++;
     }
     cnt(cur, FB_CNT_MATCHES_INLIERS)[b] = inl;
-    if (inl < 30) continue;  // TrackLocalMap returned false (:1438): bOK = false, the block of :681-726 is skipped
+    if (inl < min_inliers) continue;  // TrackLocalMap returned false (:1435-1438): bOK = false, the block of :681-726 is skipped
     for (int i = 0; i < cur->n[b]; i++) {
       const size_t o = b * cap + i;
       if (cur->mp[o] >= 0 && !map->obs_pos[b * map->stride + cur->mp[o]]) { cur->outlier[o] = 0; cur->mp[o] = -1; }
@@ -534,7 +536,7 @@ void track_local_map(orc_frame *cur, orc_frame *last, const fb_track_args *T, fb
   pose_optimization(cur, map, mpb, FB_POSE_FRONT_BIRD, T->wB, T->wF, FB_CNT_POSE2_INLIERS);      // :1400
   t1 = now();
   cur->stage_s[7] = t1 - t0;
-  finish_frame(cur, map, T->defer_outlier_drop != 0);
+  finish_frame(cur, map, T->defer_outlier_drop != 0, T->min_inliers > 0 ? T->min_inliers : 30);
   if (anySkip)
     for (size_t b = 0; b < B; b++) {
       if (!skip[b]) continue;
@@ -591,7 +593,7 @@ int orc_frame_track_local_map(orc_frame *cur, orc_frame *last, const fb_track_ar
 int orc_frame_drop_outliers(orc_frame *f) {
   const size_t B = f->B, cap = f->cap;
   for (size_t b = 0; b < B; b++) {
-    if (cnt(f, FB_CNT_MATCHES_INLIERS)[b] < 30) continue;
+    if (cnt(f, FB_CNT_MATCHES_INLIERS)[b] < f->min_inliers) continue;
     for (int i = 0; i < f->n[b]; i++) {
       const size_t o = b * cap + i;
       if (f->mp[o] >= 0 && f->outlier[o]) f->mp[o] = -1;

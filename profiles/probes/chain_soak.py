@@ -33,7 +33,7 @@ while time.time() - t0 < budget:
             yaw = {int(g.integers(1, K)): (int(g.integers(0, B)), float(g.choice([0.03, 0.06, 0.08])))} if g.random() < 0.4 else None
             seen, w = T._run_modes(B, K, wh, bwh, fx, seed, modes, rekey_at=rekey, short_list_seq=pick(), empty_kf_seq=pick(),
                                    use_lists=kw["use_lists"], voc_kL=(int(g.choice([4, 5, 8])), 5), few_points=few, yaw_error=yaw,
-                                   defer_drop=bool(g.random() < 0.3))
+                                   defer_drop=bool(g.random() < 0.3), min_inliers=int(g.choice([0, 0, 50, 300, 100000])))
             for k_, v_ in seen.items():
                 branches[k_] = branches.get(k_, 0) + v_
         else:

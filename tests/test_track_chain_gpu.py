@@ -196,7 +196,7 @@ def _yaw(delta12, angle):
 
 
 def _run_modes(B, K, wh, bwh, fx, seed, modes, rekey_at=(), short_list_seq=None, empty_kf_seq=None, use_lists=True, voc_kL=(5, 5), verbose=False,
-               few_points=None, yaw_error=None, defer_drop=False):
+               few_points=None, yaw_error=None, defer_drop=False, min_inliers=0):
     """A drive where the caller chooses per frame between TrackWithMotionModel, TrackReferenceKeyFrame and the fall-back
     (modes[k] in "motion" / "reference" / "motion+reference"), TrackLocalMap behind each, new key frames after the frames in
     rekey_at.  Returns what the branches saw."""
@@ -231,6 +231,10 @@ def _run_modes(B, K, wh, bwh, fx, seed, modes, rekey_at=(), short_list_seq=None,
     oc.init_first(mp0, mpb0, Tcw0)
     tc.make_keyframe("last")
     oc.make_keyframe("last")
+    if min_inliers:  # TrackLocalMap's success threshold (30; 50 shortly after a relocalisation, Tracking.cc:1435-1438)
+        for ch in (tc, oc):
+            cabi.fill(ch.targs, min_inliers=min_inliers)
+        cabi.fill(tc.targs_kf, min_inliers=min_inliers)
     if defer_drop:   # the host creates its key frame between the clean-up and the outlier drop (Tracking.cc:716-725)
         for ch in (tc, oc):
             cabi.fill(ch.targs, defer_outlier_drop=1)
@@ -255,7 +259,7 @@ def _run_modes(B, K, wh, bwh, fx, seed, modes, rekey_at=(), short_list_seq=None,
             oc.drop_outliers()
             g, o = tc.view(), oc.view()
             _cmp_view(g, o, "frame %d after the outlier drop" % k)
-            assert not ((o["map_point"] >= 0) & (o["outlier"] != 0) & (o["counts"][cabi.FB_CNT["MATCHES_INLIERS"]] >= 30)[:, None]).any()
+            assert not ((o["map_point"] >= 0) & (o["outlier"] != 0) & (o["counts"][cabi.FB_CNT["MATCHES_INLIERS"]] >= (min_inliers or 30))[:, None]).any(), "outliers left after the drop"
         gt, ot = tc.bird_table_host(), oc.bird_table_host()
         assert np.array_equal(gt["n"], ot["n"])
         for bb in range(B):
@@ -418,3 +422,11 @@ def test_chain_wide_window_retry_and_early_return():
     modes = {1: "motion", 2: "motion", 3: "motion"}
     seen, worst = _run_modes(2, 4, (640, 480), (384, 384), 250.0, 9950, modes, few_points={0: 80, 1: 12}, yaw_error={1: (0, 0.06)}, verbose=True)
     assert seen["retried"] >= 2 and seen["below20"] >= 1, seen
+
+
+def test_chain_lost_frames_keep_their_members():
+    """A frame whose TrackLocalMap fails (mnMatchesInliers below the threshold, here an impossible one) is a LOST frame: the
+    block of Tracking.cc:681-726 does not run, so it keeps its outliers and its points without observations."""
+    modes = {1: "motion", 2: "motion", 3: "motion"}
+    seen, worst = _run_modes(2, 4, (640, 480), (384, 384), 250.0, 9960, modes, min_inliers=100000, defer_drop=True, verbose=True)
+    assert seen.get("kept_outliers", 0) > 0, seen
