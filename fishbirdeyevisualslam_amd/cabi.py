@@ -260,7 +260,7 @@ class FrameView(C.Structure):
 
 
 FB_CNT = dict(BIRD_KF_MATCHES=0, PROJ_MATCHES=1, POSE1_INLIERS=2, MATCHES=3, MATCHES_MAP=4, BIRDVIEW_MATCHES=5, BIRD_INLIERS=6,
-              BIRD_NEW=7, TO_MATCH=8, LOCAL_MATCHES=9, POSE2_INLIERS=10, MATCHES_INLIERS=11, BOW_MATCHES=12, BIRD_POINTS=13, PROJ_RETRIED=14)
+              BIRD_NEW=7, TO_MATCH=8, LOCAL_MATCHES=9, POSE2_INLIERS=10, MATCHES_INLIERS=11, BOW_MATCHES=12, BIRD_POINTS=13, PROJ_RETRIED=14, BIRD_POINTS_FINAL=15)
 FB_CNT_COUNT = 16
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), _i32, _i32)

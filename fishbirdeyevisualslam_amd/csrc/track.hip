@@ -346,6 +346,14 @@ __global__ __launch_bounds__(WG) void k_bird_commit(FrameDev cur, FrameDev ref, 
     counts[FB_CNT_BIRD_INLIERS * B + b] = totalKept;
     counts[FB_CNT_BIRD_NEW * B + b] = totalNew;
   }
+  __syncthreads();  // (this workgroup's own writes to cur.mpb)
+  {
+    int have = 0;
+    const int ncur = min(cur.nb[b], cap);
+    for (int i = tid; i < ncur; i += WG) have += cur.mpb[fo + i] >= 0;
+    have = block_sum(have, s_w);
+    if (tid == 0) counts[FB_CNT_BIRD_POINTS_FINAL * B + b] = have;
+  }
 }
 
 struct LocalScratch { uint8_t *seen, *blocked, *inview, *obs; float *proj; int32_t *level; float *cosv; uint8_t *desc; int32_t *n_eff; };

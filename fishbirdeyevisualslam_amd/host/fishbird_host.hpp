@@ -524,6 +524,11 @@ class DeviceFrame {
     int count(int slot, int b = 0) const { return counts[(size_t)slot * (counts.size() / FB_CNT_COUNT) + b]; }
     bool trackedWithMotionModel(int b = 0) const { return count(FB_CNT_PROJ_MATCHES, b) >= 20 && count(FB_CNT_MATCHES_MAP, b) >= 10; }  // Tracking.cc:1351,1384
     bool trackedLocalMap(int b = 0) const { return count(FB_CNT_MATCHES_INLIERS, b) >= 30; }                                              // :1438
+    // Tracking::BirdNeedKF (Tracking.cc:2063-2083) on the counters of a frame tracked with TrackUsingBird
+    bool birdNeedKF(int b = 0) const {
+      const int kf = count(FB_CNT_BIRD_KF_MATCHES, b), numPt = count(FB_CNT_BIRD_POINTS_FINAL, b);
+      return kf < 0.7 * numPt || (kf < 10 && numPt > 10);
+    }
     bool trackedReferenceKeyFrame(int b = 0) const { return count(FB_CNT_BOW_MATCHES, b) >= 15 && count(FB_CNT_MATCHES_MAP, b) >= 10; }   // :1212,1243
   };
   // Tracking::Track, state OK: this frame against `last`; d_deltaT = rows 0..2 of detlaT (Tracking.cc:1316) on the device

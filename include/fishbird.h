@@ -807,6 +807,8 @@ enum {
   FB_CNT_BOW_MATCHES,         /* nmatches = SearchByBoW(mpReferenceKF, cur, ...)     Tracking.cc:1207                   */
   FB_CNT_BIRD_POINTS,         /* numPt = GetBirdMapPointsNum()                       Tracking.cc:1196                   */
   FB_CNT_PROJ_RETRIED,        /* 1 = SearchByProjection ran again with 2 * th        Tracking.cc:1342-1349              */
+  FB_CNT_BIRD_POINTS_FINAL,   /* GetBirdMapPointsNum() after the last GetPerFrameMatchedBirdPoints of the frame
+                                 (numPt of BirdNeedKF, Tracking.cc:2067)                                                */
   FB_CNT_COUNT = 16
 };
 

@@ -409,6 +409,9 @@ void per_frame_matched_bird_points(orc_frame *cur, orc_frame *last, fb_map_point
       }
       cnt(cur, FB_CNT_BIRD_INLIERS)[b] = inlier;
       cnt(cur, FB_CNT_BIRD_NEW)[b] = buildNew;
+      int numPt = 0;  // GetBirdMapPointsNum() as BirdNeedKF reads it afterwards (Tracking.cc:2067)
+      for (int i = 0; i < cur->nb[b]; i++) numPt += cur->mpb[b * cap + i] >= 0;
+      cnt(cur, FB_CNT_BIRD_POINTS_FINAL)[b] = numPt;
     }
   }
 }

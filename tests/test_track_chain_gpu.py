@@ -39,7 +39,7 @@ def _cmp_view(g, o, tag):
         rel = float(np.abs(g["Tcw"][b] - o["Tcw"][b]).max() / max(1.0, np.abs(o["Tcw"][b]).max()))
         worst = max(worst, rel)
         assert rel <= REL_TOL, (tag, b, rel)
-    assert np.array_equal(g["counts"][:15], o["counts"][:15]), (tag, g["counts"][:15].T, o["counts"][:15].T)
+    assert np.array_equal(g["counts"][:16], o["counts"][:16]), (tag, g["counts"][:16].T, o["counts"][:16].T)
     return worst
 
 
