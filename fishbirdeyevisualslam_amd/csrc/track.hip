@@ -928,12 +928,26 @@ const fb_matcher_params M09 = {0.9f, 1};  // ORBmatcher matcher(0.9,true), Track
 const fb_matcher_params M08 = {0.8f, 1};  // ORBmatcher matcher(0.8), Tracking.cc:1988
 const fb_matcher_params M07 = {0.7f, 1};  // ORBmatcher matcher(0.7,true), Tracking.cc:1207
 
+// The bird-side step of a stage runs on the handle's own stream beside the front-side step (they touch disjoint members of
+// the frame and both only read its pose): fork after the producer of what both need, join before the edge kernel.  Not while
+// every kernel is bracketed for the per-kernel table (the table shows each kernel on its own).
+struct SideStream {
+  fb_frame *f; hipStream_t s; bool on;
+  SideStream(fb_frame *f_, hipStream_t s_) : f(f_), s(s_), on(!(fb::g_prof_on && fb::g_prof_only < 0) && !getenv("FB_TRACK_NO_FORK")) {}
+  hipStream_t side() const { return on ? f->sBird : s; }
+  int fork() { if (on) { FB_HIP(hipEventRecord(f->evFork, s)); FB_HIP(hipStreamWaitEvent(f->sBird, f->evFork, 0)); } return FB_OK; }
+  int join() { if (on) { FB_HIP(hipEventRecord(f->evJoin, f->sBird)); FB_HIP(hipStreamWaitEvent(s, f->evJoin, 0)); } return FB_OK; }
+};
+
 // TrackWithMotionModel (Tracking.cc:1312-1385)
 int motion_model_impl(fb_frame *cur, fb_frame *last, const fb_track_args *T, hipStream_t s) {
   fb_map_points_bird mpb = T->mpb;
   FB_TRY(fb_frame_predict_pose_dev(cur, last, T->d_delta, s));                                         // :1314-1320
-  FB_TRY(m9_impl(cur, &mpb, T->d_local_mpb, T->d_n_local_mpb, 10, 0.05f, &M09, s));                    // :1322-1323 -> :1999-2012
+  SideStream side(cur, s);
+  FB_TRY(side.fork());
+  FB_TRY(m9_impl(cur, &mpb, T->d_local_mpb, T->d_n_local_mpb, 10, 0.05f, &M09, side.side()));          // :1322-1323 -> :1999-2012
   FB_TRY(m3_impl(cur, last, &T->map, 15.0f, &M09, s, 20));                                             // :1339-1349 (incl. the 2 * th retry)
+  FB_TRY(side.join());
   Commit C1 = commit_m9(cur, T->d_local_mpb);
   C1.match = cur->m_front.as<int32_t>(); C1.src_mp = last->mp.as<int32_t>(); C1.src_stride = cur->cap;
   // if (nmatches < 20) return false (:1351): the matches are committed, but such a sequence gets no edges (the optimiser leaves
@@ -959,8 +973,11 @@ int local_map_impl(fb_frame *cur, fb_frame *ref, const fb_track_args *T, hipStre
   fb_map_points_bird mpb = T->mpb;
   const int32_t *gr = gated ? cur->cnt(FB_CNT_MATCHES_MAP) : nullptr;
   const int gm = 10;
-  FB_TRY(bird_points_impl(cur, ref, &mpb, 10, 0.05f, &M09, 0, s, gr, gm));                             // :1392 -> :2724-2733
+  SideStream side(cur, s);
+  FB_TRY(side.fork());
+  FB_TRY(bird_points_impl(cur, ref, &mpb, 10, 0.05f, &M09, 0, side.side(), gr, gm));                   // :1392 -> :2724-2733
   FB_TRY(local_impl(cur, &T->map, T->d_local_mp, T->d_n_local_mp, 1.0f, &M08, s, gr, gm));             // :1396 -> :1947-1997
+  FB_TRY(side.join());
   Commit C2;
   memset(&C2, 0, sizeof(C2));
   C2.kind = 2; C2.match = cur->m_local.as<int32_t>(); C2.src_mp = T->d_local_mp; C2.src_stride = cur->P.local_mp_cap;
