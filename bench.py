@@ -617,7 +617,7 @@ def track_chain_leg(rank, local_rank, batches=(1, 8, 256), steps=(200, 100, 20),
                 worst = max(worst, rel)
                 if rel > REL_TOL:
                     bad.append("frame %d sequence %d: pose %.3g" % (k, bb, rel))
-            if not np.array_equal(g["counts"][:12], o["counts"][:12]):
+            if not np.array_equal(g["counts"][:16], o["counts"][:16]):
                 bad.append("frame %d: counters" % k)
         out["parity_check"] = {"sequences": parity_pairs, "consecutive_frames": parity_frames, "mismatches": len(bad), "details": bad[:8],
                                "worst_relative_pose_difference": worst,
