@@ -36,10 +36,33 @@ constexpr int MATCH_THREADS = 1024;
 struct TargetLds {  // target frame staged in LDS
   const uint4 *desc;     // [n][2]
   const float2 *xy;      // [n]
-  const uint8_t *oct;    // [n]
+  const uint8_t *oct;    // [n] (nullptr when the kernel's callbacks do not ask for it: Carve::withOct)
   const uint16_t *cs;    // [ncell+1]
-  const uint16_t *items; // [n]
+  const uint32_t *items; // [n] key point index | octave << 16 in cell order: the level test of a walk needs no second load
+  uint32_t descLds;      // LDS byte address of the descriptor table, or DESC_NOT_IN_LDS (then `desc` points into HBM / L2)
 };
+constexpr uint32_t DESC_NOT_IN_LDS = 0xFFFFFFFFu;
+
+// Distance of a query to key point i of the staged frame.  `desc` is a generic pointer (LDS or global, decided at launch), so
+// reading through it is a FLAT load; the wave-uniform branch gives each side a typed load (ds_read_b128 /
+// global_load_dwordx4).  Worth 2 % of k_proj_frame.  (Where that kernel's first round goes is still open: the walk skeleton
+// alone is 19 k of its 135 k cycles -- probe build -DFB_WALK_NO_F --, the rest is spent in the callbacks, whose loads, queueing
+// and arithmetic account for a fraction of it.)
+__device__ __forceinline__ int target_hamming(const TargetLds &T, const uint32_t a[8], int i) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 b0, b1;
+  if (T.descLds != DESC_NOT_IN_LDS) {
+    typedef __attribute__((address_space(3))) const u32x4 lds_u4;
+    lds_u4 *p = reinterpret_cast<lds_u4 *>((uintptr_t)(T.descLds + (uint32_t)i * 32u));
+    b0 = p[0]; b1 = p[1];
+  } else {
+    typedef __attribute__((address_space(1))) const u32x4 glb_u4;
+    glb_u4 *p = reinterpret_cast<glb_u4 *>((uintptr_t)(T.desc + (size_t)i * 2));
+    b0 = p[0]; b1 = p[1];
+  }
+  return __popc(a[0] ^ b0.x) + __popc(a[1] ^ b0.y) + __popc(a[2] ^ b0.z) + __popc(a[3] ^ b0.w) +
+         __popc(a[4] ^ b1.x) + __popc(a[5] ^ b1.y) + __popc(a[6] ^ b1.z) + __popc(a[7] ^ b1.w);
+}
 
 // Frame::GetFeaturesInArea (Frame.cc:493-546, inclusive cell loops) and
 // Frame::GetFeaturesInAreaBirdview (Frame.cc:572-626, exclusive loops, no min offset).
@@ -80,7 +103,11 @@ __device__ __forceinline__ void for_area(const fb_grid_geom &g, const TargetLds 
   auto flush = [&]() {
     for (int t = qn - 1; t >= 0; t--) {  // position t: 0 = newest (low half of q0)
       const uint32_t w = (t >> 1) == 0 ? q0 : ((t >> 1) == 1 ? q1 : ((t >> 1) == 2 ? q2 : q3));
+#ifndef FB_WALK_NO_F   // (probe builds: the walk skeleton alone, results wrong)
       f((int)((t & 1) ? (w >> 16) : (w & 0xFFFFu)));
+#else
+      asm volatile("" :: "v"(w));
+#endif
     }
     qn = 0;
   };
@@ -88,18 +115,19 @@ __device__ __forceinline__ void for_area(const fb_grid_geom &g, const TargetLds 
     const int cbase = ix * g.rows;
     // cells (ix, nMinCellY..nMaxCellY) are contiguous in the CSR (cell id = ix*rows+iy)
     const int j0 = T.cs[cbase + nMinCellY], j1 = T.cs[cbase + nMaxCellY + 1];
-    // one LDS wait per item instead of three dependent ones (item -> octave -> position): octave and position of item j are
-    // requested together, then item j + 1, and only the first two are waited for
-    int idxNext = j0 < j1 ? (int)T.items[j0] : 0;
+    uint32_t itNext = j0 < j1 ? T.items[j0] : 0u;
     for (int j = j0; j < j1; j++) {
-      const int idx = idxNext;
-      const int o = T.oct[idx];
-      const float2 p = T.xy[idx];
-      idxNext = T.items[min(j + 1, j1 - 1)];
+      // an item rejected by its level costs no LDS wait (the octave rides in the item word, the next item is in flight): the
+      // windows of a dense region scan hundreds of items (up to 290 per walk on the bench's drive, 3.5 of them pass both tests)
+      const uint32_t it = itNext;
+      itNext = T.items[min(j + 1, j1 - 1)];
+      const int idx = (int)(it & 0xFFFFu);
       if (bCheckLevels) {
+        const int o = (int)(it >> 16);
         if (o < minLevel) continue;
         if (maxLevel >= 0 && o > maxLevel) continue;
       }
+      const float2 p = T.xy[idx];
       const float distx = p.x - x, disty = p.y - y;
       if (fabsf(distx) < r && fabsf(disty) < r) {
         if (qn == 8) flush();
@@ -141,16 +169,18 @@ __device__ __forceinline__ void xform(const float *T, const float *X, float *o) 
 // LDS carve for a target frame of n keypoints / ncell cells. All offsets 16-B aligned.
 struct Carve {
   size_t desc, xy, oct, cs, items, end;
+  bool hasOct;
   // withDesc = false: the descriptor table stays in HBM/L2 (frames too large for LDS, e.g. the 2*nFeatures
   // initialisation extractor); only the key point positions, octaves and the grid are staged
-  __host__ __device__ Carve(int n, int ncell, bool withDesc = true) {
+  __host__ __device__ Carve(int n, int ncell, bool withDesc = true, bool withOct = true) {
     auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    hasOct = withOct;
     desc = 0;
     xy = up(desc + (withDesc ? (size_t)n * 32 : 0));
     oct = up(xy + (size_t)n * 8);
-    cs = up(oct + (size_t)n);
+    cs = up(oct + (withOct ? (size_t)n : 0));
     items = up(cs + (size_t)(ncell + 1) * 2);
-    end = up(items + (size_t)n * 2);
+    end = up(items + (size_t)n * 4);
   }
 };
 
@@ -161,7 +191,7 @@ __device__ __forceinline__ TargetLds stage_target(uint8_t *smem, const Carve &cv
   float2 *lxy = reinterpret_cast<float2 *>(smem + cv.xy);
   uint8_t *loct = smem + cv.oct;
   uint16_t *lcs = reinterpret_cast<uint16_t *>(smem + cv.cs);
-  uint16_t *litems = reinterpret_cast<uint16_t *>(smem + cv.items);
+  uint32_t *litems = reinterpret_cast<uint32_t *>(smem + cv.items);
   const int tid = threadIdx.x, nt = blockDim.x;
   // descriptor table: n*32 B as 16-byte vectors (rows are 32-B aligned in the C-ABI arrays)
   const uint4 *src = reinterpret_cast<const uint4 *>(desc);
@@ -171,12 +201,16 @@ __device__ __forceinline__ TargetLds stage_target(uint8_t *smem, const Carve &cv
   for (int i = tid; i < n; i += nt) {
     const fb_keypoint k = kps[i];
     lxy[i] = make_float2(k.x, k.y);
-    loct[i] = (uint8_t)k.octave;
+    if (cv.hasOct) loct[i] = (uint8_t)k.octave;
   }
   for (int i = tid; i <= ncell; i += nt) lcs[i] = (uint16_t)cs[i];
   const int nitems = cs[ncell];
-  for (int i = tid; i < nitems; i += nt) litems[i] = (uint16_t)items[i];
-  TargetLds T{withDesc ? reinterpret_cast<const uint4 *>(ldesc) : src, lxy, loct, lcs, litems};
+  for (int i = tid; i < nitems; i += nt) {
+    const int idx = items[i];
+    litems[i] = (uint32_t)idx | ((uint32_t)(kps[idx].octave & 0xff) << 16);
+  }
+  TargetLds T{withDesc ? reinterpret_cast<const uint4 *>(ldesc) : src, lxy, cv.hasOct ? loct : nullptr, lcs, litems,
+              withDesc ? (uint32_t)(uintptr_t)ldesc : DESC_NOT_IN_LDS};
   return T;
 }
 
@@ -205,6 +239,7 @@ __device__ unsigned long long g_m3_stamps[8];  // probe build only (block 0): st
 #endif
 
 __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args A, int cacheK, int descInLds) {
+  // (its callbacks never ask for a target key point's octave by index: no by-index octave array in LDS, Carve::withOct = false)
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   typedef unsigned short u16;
   constexpr int NONE16 = 0xFFFF;
@@ -213,7 +248,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
   const size_t co = (size_t)b * A.cur_stride, lo = (size_t)b * A.last_stride;
   const int ncur = A.n_cur[b], nlast = A.n_last[b];
   M3_T0()
-  const Carve cv(A.cur_stride, ncell, descInLds != 0);
+  const Carve cv(A.cur_stride, ncell, descInLds != 0, false);
   const TargetLds T = stage_target(smem, cv, ncur, ncell, A.cur_kps + co, A.cur_desc + co * 32,
                                    A.cur_cell_start + (size_t)b * (ncell + 1), A.cur_cell_items + co, descInLds != 0);
   int *ownerA = reinterpret_cast<int *>(smem + cv.end);  // [cur_stride]
@@ -275,7 +310,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
           for_area<false>(A.grid, T, u, v, radius, oct - 1, oct + 1, [&](int i2) {
             const int own = owner[i2];
             if (own == -1) return;      // occupied on entry: never a candidate
-            const int dist = fb::hamming256(d, T.desc + i2 * 2);
+            const int dist = target_hamming(T, d, i2);
             if (fill && dist <= TH_HIGH) {  // stable insertion into the sorted top-K (equal keys keep walk order)
               nElig++;
               // (once an entry has been displaced everything behind it moves down one place: comparing the displaced
@@ -451,7 +486,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_kf(fb_proj_kf_args A, in
         int bestDist = 256;
         for_area<false>(A.grid, T, u, v, radius, lvl - 1, lvl + 1, [&](int i2) {
           if (ownerA[i2] < q) return;
-          const int dist = fb::hamming256(d, T.desc + i2 * 2);
+          const int dist = target_hamming(T, d, i2);
           if (dist < bestDist) { bestDist = dist; best = i2; }
         });
         if (bestDist > A.orb_dist) best = NONE;
@@ -549,7 +584,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_points(fb_proj_points_ar
         for_area<false>(A.grid, T, A.mp_proj[(mo + q) * 2], A.mp_proj[(mo + q) * 2 + 1], r * A.scale_factors[lvl],
                         lvl - 1, lvl, [&](int idx) {
           if (ownerA[idx] < q) return;
-          const int dist = fb::hamming256(d, T.desc + idx * 2);
+          const int dist = target_hamming(T, d, idx);
           if (dist < bestDist) {
             bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = T.oct[idx]; bestIdx = idx;
           } else if (dist < bestDist2) {
@@ -637,7 +672,7 @@ __global__ __launch_bounds__(M2_CAND_THREADS) void k_m2_candidates(fb_proj_point
     for_area<false>(A.grid, T, A.mp_proj[(mo + q) * 2], A.mp_proj[(mo + q) * 2 + 1], m2_radius(A, mo + q, A.th != 1.0f, lvl), lvl - 1, lvl,
                     [&](int idx) {
       if (n < M2_K) {
-        const int dist = fb::hamming256(d, T.desc + idx * 2);
+        const int dist = target_hamming(T, d, idx);
         out[n] = ((uint32_t)dist << 20) | ((uint32_t)T.oct[idx] << 16) | (uint32_t)idx;
       }
       n++;
@@ -700,7 +735,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_m2_resolve(fb_proj_points_arg
           for_area<false>(A.grid, T, A.mp_proj[(mo + q) * 2], A.mp_proj[(mo + q) * 2 + 1], m2_radius(A, mo + q, bFactor, lvl), lvl - 1, lvl,
                           [&](int idx) {
             if (ownerA[idx] < q) return;
-            take(idx, fb::hamming256(d, T.desc + idx * 2), (int)T.oct[idx]);
+            take(idx, target_hamming(T, d, idx), (int)T.oct[idx]);
           });
         }
         if (bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && bestDist > A.matcher.nnratio * bestDist2)) best = bestIdx;
@@ -774,7 +809,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_bird_mappoints(fb_bird_mp_arg
     int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx = -1;
     for_area<true>(A.grid, T, ptx, pty, (float)A.window_size, -1, -1, [&](int i2) {
       if (i2 >= ncur) return;
-      const int dist = fb::hamming256(d, T.desc + i2 * 2);
+      const int dist = target_hamming(T, d, i2);
       if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = i2; }
       else if (dist < bestDist2) bestDist2 = dist;
     });
@@ -827,7 +862,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_birdview(fb_birdview_args A, 
       int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx = -1;
       for_area<true>(A.grid, T, kp1.x, kp1.y, (float)A.window_size, kp1.octave, kp1.octave, [&](int i2) {
         if (i2 >= ncur) return;
-        const int dist = fb::hamming256(d, T.desc + i2 * 2);
+        const int dist = target_hamming(T, d, i2);
         if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = i2; }
         else if (dist < bestDist2) bestDist2 = dist;
       });
@@ -978,8 +1013,8 @@ __global__ void k_bird_keys_to_cam(const fb_keypoint *__restrict__ kps, const in
   dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
 }
 
-size_t match_lds_bytes(int cur_stride, int ncell, int extra_ints, bool withDesc = true) {
-  return Carve(cur_stride, ncell, withDesc).end + (size_t)extra_ints * 4;
+size_t match_lds_bytes(int cur_stride, int ncell, int extra_ints, bool withDesc = true, bool withOct = true) {
+  return Carve(cur_stride, ncell, withDesc, withOct).end + (size_t)extra_ints * 4;
 }
 
 // LDS plan of a matcher: the target frame's descriptor table goes to LDS when everything fits, otherwise it stays in
@@ -1080,10 +1115,10 @@ int fb_match_projection_frame_dev(const fb_proj_frame_args *A, void *stream) {
   const int base_ints = 2 * A->cur_stride + 2 * A->last_stride + 4;
   // preference: descriptors in LDS + cache, descriptors in LDS, cache only, neither
   int cacheK = CACHE_K, descInLds = 1;
-  size_t lds = match_lds_bytes(A->cur_stride, ncell, base_ints + cacheK * A->last_stride);
-  if (lds > LDS_BUDGET) { cacheK = 0; lds = match_lds_bytes(A->cur_stride, ncell, base_ints); }
-  if (lds > LDS_BUDGET) { cacheK = CACHE_K; descInLds = 0; lds = match_lds_bytes(A->cur_stride, ncell, base_ints + cacheK * A->last_stride, false); }
-  if (lds > LDS_BUDGET) { cacheK = 0; lds = match_lds_bytes(A->cur_stride, ncell, base_ints, false); }
+  size_t lds = match_lds_bytes(A->cur_stride, ncell, base_ints + cacheK * A->last_stride, true, false);
+  if (lds > LDS_BUDGET) { cacheK = 0; lds = match_lds_bytes(A->cur_stride, ncell, base_ints, true, false); }
+  if (lds > LDS_BUDGET) { cacheK = CACHE_K; descInLds = 0; lds = match_lds_bytes(A->cur_stride, ncell, base_ints + cacheK * A->last_stride, false, false); }
+  if (lds > LDS_BUDGET) { cacheK = 0; lds = match_lds_bytes(A->cur_stride, ncell, base_ints, false, false); }
   FB_TRY(check_lds(lds, "fb_match_projection_frame"));
   FB_TRY(set_max_lds(k_proj_frame, lds));
   fb::ProfScope prof_(fb::P_PROJ_FRAME, fb::as_stream(stream));
