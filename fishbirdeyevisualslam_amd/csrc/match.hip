@@ -45,9 +45,9 @@ constexpr uint32_t DESC_NOT_IN_LDS = 0xFFFFFFFFu;
 
 // Distance of a query to key point i of the staged frame.  `desc` is a generic pointer (LDS or global, decided at launch), so
 // reading through it is a FLAT load; the wave-uniform branch gives each side a typed load (ds_read_b128 /
-// global_load_dwordx4).  Worth 2 % of k_proj_frame.  (Where that kernel's first round goes is still open: the walk skeleton
-// alone is 19 k of its 135 k cycles -- probe build -DFB_WALK_NO_F --, the rest is spent in the callbacks, whose loads, queueing
-// and arithmetic account for a fraction of it.)
+// global_load_dwordx4).  Worth 2 % of k_proj_frame.  (Probe builds of that kernel's first round: callbacks compiled out 19 k
+// of 135 k cycles, constant instead of this distance 131 k, no top-K insertion 21 k -- the insertion block of full_search is
+// where the time goes)
 __device__ __forceinline__ int target_hamming(const TargetLds &T, const uint32_t a[8], int i) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   u32x4 b0, b1;
@@ -329,10 +329,12 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
         }
       }
     }
-    if (fill) {
-      const int n = nElig < cacheK ? nElig : cacheK;
-      for (int k = 0; k < cacheK; k++) cache[(size_t)q * cacheK + k] = top[k < CACHE_K ? k : 0];
-      meta[q] = (uint8_t)(n | (nElig <= cacheK ? 0x80 : 0));
+    if (fill) {  // (fill implies cacheK == CACHE_K: a run-time bound here makes `top` an indexed array instead of registers)
+      const int n = nElig < CACHE_K ? nElig : CACHE_K;
+      uint32_t *cq = cache + (uint32_t)q * CACHE_K;
+#pragma unroll
+      for (int k = 0; k < CACHE_K; k++) cq[k] = top[k];
+      meta[q] = (uint8_t)(n | (nElig <= CACHE_K ? 0x80 : 0));
     }
     return best;
   };
