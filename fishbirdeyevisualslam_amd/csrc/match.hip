@@ -23,6 +23,8 @@
 // By induction on q the iteration converges to exactly the serial result (query 0 is final
 // after round 0, query q after at most round q); in practice 2-3 rounds.
 #include "fb_common.h"
+
+#include <type_traits>
 #include "fb_frame_geom.h"
 
 namespace {
@@ -284,11 +286,13 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
   M3_TICK(1)
 
   // full grid walk of query q against the claims in `owner`; fill = also (re)build the query's cache
-  auto full_search = [&](int q, const int *owner, bool fill) -> int {
+  // fillTag: std::true_type = also (re)build the query's cache.  The callback only APPENDS the eligible candidates (distance
+  // <= TH_HIGH, walk order) to eight registers; the stable top-K selection runs after the walk, once, in straight-line code.
+  // More than eight eligible candidates: the cache is left empty and incomplete, i.e. later rounds walk again.
+  auto full_search = [&](int q, const int *owner, auto fillTag) -> int {
+    constexpr bool fill = decltype(fillTag)::value;
     int best = NONE;
-    uint32_t top[CACHE_K];
-#pragma unroll
-    for (int k = 0; k < CACHE_K; k++) top[k] = 0xFFFFFFFFu;
+    uint32_t e0 = 0xFFFFFFFFu, e1 = e0, e2 = e0, e3 = e0, e4 = e0, e5 = e0, e6 = e0, e7 = e0;  // newest in e0
     int nElig = 0;
     if (A.last_valid[lo + q]) {
       float X[3] = {A.last_xw[(lo + q) * 3], A.last_xw[(lo + q) * 3 + 1], A.last_xw[(lo + q) * 3 + 2]};
@@ -311,16 +315,10 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
             const int own = owner[i2];
             if (own == -1) return;      // occupied on entry: never a candidate
             const int dist = target_hamming(T, d, i2);
-            if (fill && dist <= TH_HIGH) {  // stable insertion into the sorted top-K (equal keys keep walk order)
+            if (fill && dist <= TH_HIGH) {
               nElig++;
-              // (once an entry has been displaced everything behind it moves down one place: comparing the displaced
-              // entry again would let it jump over an equal-distance neighbour and break the walk order among ties)
-              uint32_t e = ((uint32_t)dist << 16) | (uint32_t)i2;
-              bool shift = false;
-#pragma unroll
-              for (int k = 0; k < CACHE_K; k++) {
-                if (shift || (e >> 16) < (top[k] >> 16)) { const uint32_t t = top[k]; top[k] = e; e = t; shift = true; }
-              }
+              e7 = e6; e6 = e5; e5 = e4; e4 = e3; e3 = e2; e2 = e1; e1 = e0;
+              e0 = ((uint32_t)dist << 16) | (uint32_t)i2;
             }
             if (own < q) return;        // taken by an earlier query
             if (dist < bestDist) { bestDist = dist; best = i2; }
@@ -329,12 +327,31 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
         }
       }
     }
-    if (fill) {  // (fill implies cacheK == CACHE_K: a run-time bound here makes `top` an indexed array instead of registers)
-      const int n = nElig < CACHE_K ? nElig : CACHE_K;
+    if (fill) {
+      // stable top-K by distance over the recorded candidates, oldest first (equal keys keep walk order; once an entry has
+      // been displaced everything behind it moves down one place: comparing the displaced entry again would let it jump over
+      // an equal-distance neighbour and break the walk order among ties)
+      uint32_t top[CACHE_K];
+#pragma unroll
+      for (int k = 0; k < CACHE_K; k++) top[k] = 0xFFFFFFFFu;
+      const bool over = nElig > 8;
+      const uint32_t ent[8] = {e7, e6, e5, e4, e3, e2, e1, e0};  // position 7 = newest; the oldest recorded one is at 8 - nElig
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if (i >= 8 - nElig && !over) {
+          uint32_t e = ent[i];
+          bool shift = false;
+#pragma unroll
+          for (int k = 0; k < CACHE_K; k++) {
+            if (shift || (e >> 16) < (top[k] >> 16)) { const uint32_t t = top[k]; top[k] = e; e = t; shift = true; }
+          }
+        }
+      }
+      const int n = over ? 0 : (nElig < CACHE_K ? nElig : CACHE_K);
       uint32_t *cq = cache + (uint32_t)q * CACHE_K;
 #pragma unroll
       for (int k = 0; k < CACHE_K; k++) cq[k] = top[k];
-      meta[q] = (uint8_t)(n | (nElig <= CACHE_K ? 0x80 : 0));
+      meta[q] = (uint8_t)(n | ((nElig <= CACHE_K) ? 0x80 : 0));
     }
     return best;
   };
@@ -353,14 +370,14 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
       const int q = perm[pq];
       int best = NONE;
       if (round == 0 || cacheK == 0) {
-        best = full_search(q, ownerA, cacheK > 0);
+        best = cacheK > 0 ? full_search(q, ownerA, std::true_type{}) : full_search(q, ownerA, std::false_type{});
       } else {
         const int m = meta[q], n = m & 0x7f;
         for (int k = 0; k < n; k++) {
           const int i2 = (int)(cache[(size_t)q * cacheK + k] & 0xFFFFu);
           if (!(ownerA[i2] < q)) { best = i2; break; }
         }
-        if (best == NONE && n > 0 && !(m & 0x80)) best = full_search(q, ownerA, false);
+        if (best == NONE && !(m & 0x80)) best = full_search(q, ownerA, std::false_type{});
       }
       const int best16 = best == NONE ? NONE16 : best;
       assignB[q] = (u16)best16;
@@ -1116,7 +1133,8 @@ int fb_match_projection_frame_dev(const fb_proj_frame_args *A, void *stream) {
   // ints: two owner arrays; per query two u16 assignments + u16 processing order + one meta byte (2 ints) + the cache
   const int base_ints = 2 * A->cur_stride + 2 * A->last_stride + 4;
   // preference: descriptors in LDS + cache, descriptors in LDS, cache only, neither
-  int cacheK = CACHE_K, descInLds = 1;
+  static const bool noCache = getenv("FB_M3_NO_CACHE") != nullptr;  // measurements: every round walks the grid again
+  int cacheK = noCache ? 0 : CACHE_K, descInLds = 1;
   size_t lds = match_lds_bytes(A->cur_stride, ncell, base_ints + cacheK * A->last_stride, true, false);
   if (lds > LDS_BUDGET) { cacheK = 0; lds = match_lds_bytes(A->cur_stride, ncell, base_ints, true, false); }
   if (lds > LDS_BUDGET) { cacheK = CACHE_K; descInLds = 0; lds = match_lds_bytes(A->cur_stride, ncell, base_ints + cacheK * A->last_stride, false, false); }
