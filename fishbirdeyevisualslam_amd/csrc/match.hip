@@ -286,11 +286,10 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
   M3_TICK(1)
 
   // full grid walk of query q against the claims in `owner`; fill = also (re)build the query's cache
-  // fillTag: std::true_type = also (re)build the query's cache.  The callback only APPENDS the eligible candidates (distance
+  // fill = also (re)build the query's cache.  The callback only APPENDS the eligible candidates (distance
   // <= TH_HIGH, walk order) to eight registers; the stable top-K selection runs after the walk, once, in straight-line code.
   // More than eight eligible candidates: the cache is left empty and incomplete, i.e. later rounds walk again.
-  auto full_search = [&](int q, const int *owner, auto fillTag) -> int {
-    constexpr bool fill = decltype(fillTag)::value;
+  auto full_search = [&](int q, const int *owner, const bool fill) -> int {
     int best = NONE;
     uint32_t e0 = 0xFFFFFFFFu, e1 = e0, e2 = e0, e3 = e0, e4 = e0, e5 = e0, e6 = e0, e7 = e0;  // newest in e0
     int nElig = 0;
@@ -369,16 +368,17 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_proj_frame(fb_proj_frame_args
     for (int pq = tid; pq < nlast; pq += nt) {
       const int q = perm[pq];
       int best = NONE;
-      if (round == 0 || cacheK == 0) {
-        best = cacheK > 0 ? full_search(q, ownerA, std::true_type{}) : full_search(q, ownerA, std::false_type{});
-      } else {
+      bool walk = round == 0 || cacheK == 0;
+      const bool fillNow = walk && cacheK > 0;
+      if (!walk) {
         const int m = meta[q], n = m & 0x7f;
         for (int k = 0; k < n; k++) {
           const int i2 = (int)(cache[(size_t)q * cacheK + k] & 0xFFFFu);
           if (!(ownerA[i2] < q)) { best = i2; break; }
         }
-        if (best == NONE && !(m & 0x80)) best = full_search(q, ownerA, std::false_type{});
+        walk = best == NONE && !(m & 0x80);
       }
+      if (walk) best = full_search(q, ownerA, fillNow);   // ONE call site: one copy of the walk and its callbacks in the kernel
       const int best16 = best == NONE ? NONE16 : best;
       assignB[q] = (u16)best16;
       if (best16 != assignA[q]) s_changed = 1;
